@@ -1,0 +1,213 @@
+/*
+ * include/skred_amd.h -- C ABI of the MI355X-native skred render path.
+ *
+ * One hot path is implemented: the per-voice render loop of skred's audio
+ * callback, `synth()` (reference synth.c:502-630, declared synth.h:8, called
+ * only from the miniaudio data_callback `synth_callback`, skred.c:107-116).
+ *
+ * Two boundaries are exported by libskred_amd.so:
+ *
+ *  (1) BANK MODE (this header): a runtime-N "voice bank" whose per-voice fields
+ *      carry the reference's own names and types (synth.def:12-89; structs
+ *      synth-types.h:13-38) but with N voices instead of VOICE_MAX=64
+ *      (skred.h:9).  State lives in HBM between calls; every call renders
+ *      `num_frames` frames for all voices with hand-written HIP kernels.
+ *
+ *  (2) DROP-IN MODE (include/skred_synth_abi.h): the literal synth.h surface
+ *      -- `synth()`, the setters and the 75 global arrays -- backed by (1).
+ *
+ * Plain pointers and sizes only: no C++ or torch types cross this boundary.
+ * All functions return 0 on success or a negative SKRED_E_* code; the product
+ * path has NO CPU fallback: without a usable HIP device every entry point that
+ * would touch the GPU fails with SKRED_E_NO_DEVICE.
+ */
+#ifndef SKRED_AMD_H
+#define SKRED_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKRED_AMD_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+enum {
+  SKRED_OK = 0,
+  SKRED_E_NO_DEVICE = -1,   /* no HIP device / HIP call failed (see skred_amd_last_error) */
+  SKRED_E_BAD_ARG = -2,
+  SKRED_E_NO_MEM = -3,
+  SKRED_E_RANGE = -4,       /* voice window or table offset outside the bank / pool */
+  SKRED_E_UNSUPPORTED = -5, /* feature of synth() not implemented by the kernels (see flags) */
+};
+
+/* ---- structs kept from the reference (layout-identical) ---------------- */
+
+/* == mmf_t, synth-types.h:13-23 (48 bytes): RBJ biquad state + coefficients */
+typedef struct {
+  float x1, x2;             /* input delay line  */
+  float y1, y2;             /* output delay line */
+  float b0, b1, b2;         /* feed-forward      */
+  float a1, a2;             /* feedback          */
+  float last_freq, last_resonance;
+  int32_t last_mode;
+} skred_mmf_t;
+
+/* == envelope_t, synth-types.h:25-38 (56 bytes): linear ADSR keyed on the global sample counter */
+typedef struct {
+  float a, d, s, r;         /* seconds (control path only) */
+  float attack_time;        /* samples */
+  float decay_time;         /* samples */
+  float sustain_level;      /* 0..1    */
+  float release_time;       /* samples */
+  uint64_t sample_start;    /* synth_sample_count at note-on  */
+  uint64_t sample_release;  /* synth_sample_count at note-off, 0 = held */
+  int32_t is_active;
+  float velocity;
+} skred_envelope_t;
+
+/* ---- the voice bank (host view) --------------------------------------- */
+
+/*
+ * Host-side structure-of-arrays view of N voices.  Every member is the array
+ * of the same name in synth.def:12-89 with `VOICE_MAX` replaced by
+ * `n_voices`; the one exception is `voice_table`, a raw `float*` in the
+ * reference (synth.def:14), which becomes `voice_table_offset`: the index of
+ * the table's first sample inside the table pool handed to
+ * skred_bank_set_tables_f32().
+ *
+ * Only the fields synth() reads or writes are present.
+ * A bank view may simply point at the 64-entry global arrays of the drop-in
+ * facade -- that is how drop-in mode is implemented.
+ */
+typedef struct skred_voice_bank {
+  int32_t n_voices;
+
+  /* oscillator (osc_next, synth.c:217-275) */
+  float   *voice_phase;            /* rw */
+  float   *voice_phase_inc;
+  int64_t *voice_table_offset;     /* replaces float *voice_table[] */
+  int32_t *voice_table_size;
+  int32_t *voice_one_shot;
+  int32_t *voice_finished;         /* rw */
+  int32_t *voice_loop_enabled;
+  int32_t *voice_loop_valid;
+  float   *voice_loop_start_f;
+  float   *voice_loop_end_f;
+  int32_t *voice_direction;
+  int32_t *voice_wave_table_index; /* only compared with WAVE_TABLE_NOISE_ALT (synth.c:543) */
+
+  /* sample chain (synth.c:560-593) */
+  float   *voice_sample;           /* rw */
+  float   *voice_sample_hold;      /* rw */
+  int32_t *voice_sample_hold_count;/* rw */
+  int32_t *voice_sample_hold_max;
+  int32_t *voice_quantize;
+  float   *voice_amp;
+  int32_t *voice_use_amp_envelope;
+  int32_t *voice_smoother_enable;
+  float   *voice_smoother_gain;    /* rw */
+  float   *voice_smoother_smoothing;
+  int32_t *voice_filter_mode;
+  skred_mmf_t      *voice_filter;        /* rw: x1 x2 y1 y2 */
+  skred_envelope_t *voice_amp_envelope;  /* rw: is_active   */
+
+  /* pan / mix (synth.c:595-612) */
+  float   *voice_pan_left;         /* rw only under pan modulation */
+  float   *voice_pan_right;
+  int32_t *voice_disconnect;
+
+  /* cross-voice modulation + phase distortion (synth.c:548-558,584-587,597-602,262-267) */
+  int32_t *voice_freq_mod_osc;
+  float   *voice_freq_mod_depth;
+  float   *voice_freq_scale;
+  int32_t *voice_amp_mod_osc;
+  float   *voice_amp_mod_depth;
+  int32_t *voice_pan_mod_osc;
+  float   *voice_pan_mod_depth;
+  int32_t *voice_cz_mod_osc;
+  float   *voice_cz_mod_depth;
+  int32_t *voice_cz_mode;
+  float   *voice_cz_distortion;
+} skred_voice_bank_t;
+
+/* Scalars synth() keeps outside the per-voice arrays. */
+typedef struct skred_globals {
+  uint64_t synth_sample_count;       /* synth.c:85; pre-incremented per frame (synth.c:521) */
+  uint64_t noise_rng;                /* synth()'s static LCG state (synth.c:504,508,525)  */
+  float volume_final;                /* synth.c:90  = volume_user * AMY_FACTOR            */
+  float volume_smoother_gain;        /* synth.c:91  rw                                     */
+  float volume_smoother_smoothing;   /* synth.c:92                                         */
+  float reserved;
+} skred_globals_t;
+
+#define SKRED_WAVE_TABLE_NOISE_ALT 6 /* skred.h:30 */
+
+/* render flags */
+enum {
+  SKRED_INTERP_TRUNCATE = 0, /* table[(int)phase] -- what the reference does (synth.c:268-274) */
+  SKRED_INTERP_LINEAR   = 1, /* north-star mode; defined by oracle/cpu_ref.c, not by the reference */
+};
+
+/* ---- device-side bank -------------------------------------------------- */
+
+typedef struct skred_bank skred_bank_t; /* opaque; owns HBM state for n voices on one GPU */
+
+int  skred_amd_abi_version(void);
+int  skred_amd_device_count(void);                 /* <=0: no usable GPU */
+const char *skred_amd_last_error(void);            /* thread-local text of the last failure */
+
+int  skred_bank_create(int device, int n_voices, skred_bank_t **out);
+void skred_bank_destroy(skred_bank_t *bank);
+int  skred_bank_n_voices(const skred_bank_t *bank);
+
+/* Table pool: every table a voice can name, concatenated (floats).  Replaces the
+ * malloc'd wave_table_data[] tables (synth.def:1, synth.c:1224).  Tables that fit
+ * are staged into LDS by the kernel; larger pools are gathered from HBM/L2. */
+int  skred_bank_set_tables_f32(skred_bank_t *bank, const float *pool, size_t n_floats);
+
+/* Pack `count` voices starting at host index `src_first` into device slots
+ * [dst_first, dst_first+count).  Host arrays stay the source of truth. */
+int  skred_bank_upload(skred_bank_t *bank, const skred_voice_bank_t *host,
+                       int src_first, int dst_first, int count);
+/* Copy the read-write fields (marked rw above) back into the host view. */
+int  skred_bank_download(skred_bank_t *bank, skred_voice_bank_t *host,
+                         int src_first, int dst_first, int count);
+
+int  skred_bank_set_globals(skred_bank_t *bank, const skred_globals_t *g);
+int  skred_bank_get_globals(skred_bank_t *bank, skred_globals_t *g);
+
+/*
+ * Render `num_frames` frames of every voice (the two nested loops of
+ * synth.c:520-613) and leave this GPU's PRE-master-volume stereo sum in
+ * `d_partial` (device pointer, float[num_frames][2]).  `d_stems` (device,
+ * float[num_frames][n_voices][2], the `user` buffer layout of synth.c:533-534,
+ * 607-611) may be NULL.  Advances synth_sample_count and the noise LCG.
+ * `stream` is a hipStream_t (NULL = default stream).  Asynchronous.
+ */
+int  skred_bank_render(skred_bank_t *bank, int num_frames, int interp,
+                       float *d_partial, float *d_stems, void *stream);
+
+/*
+ * Master volume stage (synth.c:616-624): serial one-pole smoothing of the
+ * gain, multiply, and interleave into `d_out` (device, float[num_frames]
+ * [num_channels], channels 0 and 1 written).  In a multi-GPU run this is
+ * called on the root after the RCCL sum of the partials.  Asynchronous.
+ */
+int  skred_bank_master(skred_bank_t *bank, const float *d_sum, int num_frames,
+                       int num_channels, float *d_out, void *stream);
+
+/* Whole synth() contract on host buffers: render + master + D2H (+ stems). Synchronous. */
+int  skred_bank_render_host(skred_bank_t *bank, float *buffer, int num_frames,
+                            int num_channels, int interp, float *stems_or_null);
+
+/* Timing of the most recent skred_bank_render() on its stream, via hipEvents
+ * recorded around the render kernel itself (ms; <0 if unavailable). Synchronises. */
+float skred_bank_last_render_ms(skred_bank_t *bank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKRED_AMD_H */

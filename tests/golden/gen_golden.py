@@ -1,0 +1,410 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the UNMODIFIED reference.
+
+Runs only where /root/reference exists (the build container).  It drives
+oracle/_ref/libskred_ref.so -- the reference sources compiled in place by
+`make -C oracle ref` -- through its own control path (wire(), i.e. the same text
+protocol a user types) and its own audio callback (synth_callback -> synth() + seq()),
+and stores inputs + expected outputs as small .npz fixtures:
+
+  tables / table_*      the wavetables the voices reference (float pool)
+  s<k>_in_<field>       full voice state before segment k (field names of synth.def)
+  s<k>_globals_in/out   JSON: synth_sample_count, noise LCG state, volume smoother
+  s<k>_mix              reference output frames [F][2]  (post master volume)
+  s<k>_stems_sha256     sha256 of the `user` stem buffer bytes [F][64][2]
+  s<k>_stems            stems of the listed voices only (when few voices are active)
+  s<k>_out_<field>      read-write voice state after segment k
+
+No reference source text is stored: fixtures are data.  Each case runs in a fresh process
+because synth() keeps function-static state (first-call latch, noise LCG: synth.c:503-511).
+
+usage: python tests/golden/gen_golden.py [--case NAME] [--list]
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from skred_amd.bank import ENV_DTYPE, FIELDS, MMF_DTYPE, RW_FIELDS, GlobalsC, VoiceBank  # noqa: E402
+
+REF_DIR = os.environ.get("SKRED_REFERENCE", "/root/reference")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libskred_ref.so")
+LCG_A, LCG_C, M64 = 6364136223846793005, 1442695040888963407, (1 << 64) - 1
+
+
+class Ref:
+    """The reference process image, driven through ctypes."""
+
+    def __init__(self):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
+        self.L = C.CDLL(REF_SO)
+        self.L.ref_boot()
+        self.L.ref_stems.restype = C.POINTER(C.c_float)
+        self.L.ref_ext_table.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_float, C.c_float]
+        self.V = self.L.ref_voice_max()
+        self.W = self.L.ref_wave_table_max()
+        assert self.L.ref_sizeof_mmf() == MMF_DTYPE.itemsize
+        assert self.L.ref_sizeof_envelope() == ENV_DTYPE.itemsize
+        self.frames_done = 0          # frames rendered so far == LCG draws so far (synth.c:525)
+
+    # -- raw views of the reference's global arrays (synth.def) --
+    def arr(self, name, dtype, n=None):
+        n = self.V if n is None else n
+        dt = np.dtype(dtype)
+        raw = (C.c_char * (dt.itemsize * n)).in_dll(self.L, name)
+        return np.frombuffer(raw, dtype=dt, count=n)
+
+    def scalar(self, name, ctype):
+        return ctype.in_dll(self.L, name)
+
+    def wire(self, line: str):
+        for part in line.split("\n"):
+            if part.strip():
+                r = self.L.ref_wire(part.encode())
+                assert r == 0, (part, r)
+
+    def load_patch(self, n: int):
+        r = self.L.ref_load_patch(REF_DIR.encode(), n)
+        assert r == 0, r
+
+    def ext_table(self, slot, data, rate=44100.0, one_shot=0, loop_enabled=0, loop_start=0,
+                  loop_end=None, midi_note=69.0, offset_hz=0.0):
+        data = np.ascontiguousarray(data, np.float32)
+        le = (len(data) - 1) if loop_end is None else loop_end
+        r = self.L.ref_ext_table(slot, data.ctypes.data, len(data), rate, one_shot, loop_enabled,
+                                 loop_start, le, midi_note, offset_hz)
+        assert r == 0, r
+
+    def noise_rng(self) -> int:
+        s = 1                                     # audio_rng_init(&synth_random, 1), synth.c:508
+        for _ in range(self.frames_done):
+            s = (s * LCG_A + LCG_C) & M64
+        return s
+
+    def globals(self) -> GlobalsC:
+        return GlobalsC(self.scalar("synth_sample_count", C.c_uint64).value, self.noise_rng(),
+                        self.scalar("volume_final", C.c_float).value,
+                        self.scalar("volume_smoother_gain", C.c_float).value,
+                        self.scalar("volume_smoother_smoothing", C.c_float).value, 0.0)
+
+    def snapshot(self):
+        """(VoiceBank, tables pool) of the current reference state."""
+        b = VoiceBank(self.V)
+        tptr = self.arr("voice_table", "<u8")
+        tsize = self.arr("voice_table_size", "<i4")
+        pool, offs, seen = [], np.zeros(self.V, np.int64), {}
+        pos = 0
+        for v in range(self.V):
+            p, n = int(tptr[v]), int(tsize[v])
+            if p == 0 or n <= 0:
+                continue
+            if (p, n) not in seen:
+                data = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).copy()
+                seen[(p, n)] = pos
+                pool.append(data)
+                pos += n
+            offs[v] = seen[(p, n)]
+        for name, dt, _ in FIELDS:
+            if name == "voice_table_offset":
+                b.a[name] = offs
+            else:
+                b.a[name] = self.arr(name, dt).copy()
+        tables = np.concatenate(pool) if pool else np.zeros(1, np.float32)
+        return b, tables.astype(np.float32)
+
+    def render(self, frames: int, block: int = 512):
+        """frames of audio through synth_callback in `block`-frame calls (skred.h:12 default)."""
+        mix = np.zeros((frames, 2), np.float32)
+        stems = np.zeros((frames, self.V, 2), np.float32)
+        sp = self.L.ref_stems()
+        p = 0
+        while p < frames:
+            n = min(block, frames - p)
+            self.L.ref_callback(mix[p:].ctypes.data_as(C.c_void_p), n)
+            stems[p:p + n] = np.ctypeslib.as_array(sp, shape=(n, self.V, 2))
+            p += n
+        self.frames_done += frames
+        return mix, stems
+
+
+def fnv1a32(b: bytes) -> str:
+    h = 0x811C9DC5
+    for x in b:
+        h = ((h ^ x) * 0x01000193) & 0xFFFFFFFF
+    return "%08x" % h
+
+
+class Case:
+    def __init__(self, name, desc):
+        self.name, self.desc = name, desc
+        self.out = {}
+        self.meta = {"case": name, "description": desc, "sample_rate": 44100, "segments": [],
+                     "generator": "tests/golden/gen_golden.py", "flags": "-O2 -ffp-contract=off"}
+        self.k = 0
+        self.tables = None
+
+    def segment(self, ref: Ref, frames, block=512, keep_stems=(), note=""):
+        bank, tables = ref.snapshot()
+        if self.tables is None:
+            self.tables = tables
+            self.out["tables"] = tables
+        else:
+            assert tables.shape == self.tables.shape and (tables == self.tables).all(), \
+                "table pool changed between segments"
+        g_in = ref.globals()
+        mix, stems = ref.render(frames, block)
+        bank_out, _ = ref.snapshot()
+        g_out = ref.globals()
+        p = f"s{self.k}_"
+        self.out.update(bank.to_arrays(p + "in_"))
+        self.out.update(bank_out.to_arrays(p + "out_", RW_FIELDS))
+        self.out[p + "mix"] = mix
+        self.out[p + "globals_in"] = np.array(json.dumps(g_in.to_dict()))
+        self.out[p + "globals_out"] = np.array(json.dumps(g_out.to_dict()))
+        self.out[p + "stems_sha256"] = np.array(hashlib.sha256(stems.tobytes()).hexdigest())
+        keep = list(keep_stems)
+        if keep:
+            self.out[p + "stems"] = np.ascontiguousarray(stems[:, keep, :])
+            self.out[p + "stems_voices"] = np.array(keep, np.int32)
+        self.meta["segments"].append({"frames": frames, "block": block, "note": note,
+                                      "mix_fnv1a32": fnv1a32(mix.tobytes()),
+                                      "mix_rms": float(np.sqrt((mix.astype(np.float64) ** 2).mean())),
+                                      "mix_peak": float(np.abs(mix).max())})
+        self.k += 1
+
+    def save(self):
+        self.out["meta"] = np.array(json.dumps(self.meta))
+        path = os.path.join(HERE, self.name + ".npz")
+        np.savez_compressed(path, **self.out)
+        print(f"wrote {path} ({os.path.getsize(path)} bytes) segments={self.k}")
+        for s in self.meta["segments"]:
+            print("   ", s)
+
+
+def lcg_uniform(n, seed):
+    """n floats in [-1,1) from the reference's LCG recurrence (synth.c:110-123)."""
+    out = np.zeros(n, np.float32)
+    s = seed
+    for i in range(n):
+        s = (s * LCG_A + LCG_C) & M64
+        hi = (s >> 32) & 0xFFFFFFFF
+        if hi >= 1 << 31:
+            hi -= 1 << 32
+        out[i] = np.float32(hi) / np.float32(2147483648.0)
+    return out
+
+
+# ---------------------------------------------------------------- the cases
+
+def case_c0_0sk():
+    """BASELINE config 0: 0.sk, 1 s, 512-frame callbacks.  Anchor from SURVEY §8c: FNV-1a 4160cd81."""
+    ref = Ref()
+    ref.load_patch(0)
+    c = Case("c0_0sk", "reference patch 0.sk (sine carrier v0, FM by muted v1 > v0: one-frame-delay "
+                        "modulator semantics), 44100 frames in 512-frame callbacks")
+    c.segment(ref, 44100, 512, keep_stems=(0, 1))
+    assert c.meta["segments"][0]["mix_fnv1a32"] == "4160cd81", c.meta["segments"][0]
+    c.save()
+
+
+def case_c1_sine_adsr():
+    """BASELINE config 1 shape at N=64: sine + ADSR (+ default amp smoother), note-off mid-way,
+    then long enough for the envelope to end and the smoother to decay through the subnormals."""
+    ref = Ref()
+    u = (lcg_uniform(192, 0x5EED) + 1.0) * 0.5
+    for v in range(64):
+        f = 27.5 * 2.0 ** (7.0 * float(u[v]))
+        pan = float(u[64 + v]) * 2.0 - 1.0
+        amp = 0.25 + float(u[128 + v])
+        ref.wire(f"v{v} w0 f{f:.6f} a{amp:.6f} p{pan:.6f} t0.01,0.1,0.7,0.2 l{0.5 + 0.5 * float(u[v]):.4f}")
+    c = Case("c1_sine_adsr64", "64 sine voices (w0), distinct freq/amp/pan, ADSR t0.01,0.1,0.7,0.2 "
+                               "triggered with l<vel>; note-off after 2048 frames; run past release end "
+                               "and through the subnormal tail of the amp smoother")
+    c.segment(ref, 2048, 512, note="attack+decay+sustain")
+    for v in range(64):
+        ref.wire(f"v{v} l0")
+    c.segment(ref, 2048, 512, note="release starts")
+    c.segment(ref, 8192, 512, note="release ends (8820 frames), is_active -> 0")
+    c.segment(ref, 12288, 100, note="smoother tail decays through subnormals to 0; 100-frame callbacks")
+    c.save()
+
+
+def case_c2_mixed_filter():
+    """BASELINE config 2 shape at N=64: mixed tables + biquad modes 1..5."""
+    ref = Ref()
+    u = (lcg_uniform(256, 0xC2) + 1.0) * 0.5
+    waves = [0, 4, 1, 2, 3]
+    for v in range(64):
+        f = 27.5 * 2.0 ** (6.0 * float(u[v]))
+        pan = float(u[64 + v]) * 2.0 - 1.0
+        k = 100.0 * (80.0 ** float(u[128 + v]))
+        q = 0.5 + 3.5 * float(u[192 + v])
+        ref.wire(f"v{v} w{waves[v % 5]} f{f:.6f} a1 p{pan:.6f} J{1 + v % 5} K{k:.4f} Q{q:.4f}")
+    c = Case("c2_mixed_filter64", "64 voices cycling sine/triangle/square/saw tables (w0,w4,w1,w2,w3) "
+                                  "through RBJ biquad modes 1..5 with varied K/Q")
+    c.segment(ref, 4096, 512)
+    c.save()
+
+
+def case_c2_notamy():
+    """Config 2/3 tables: the notamy float LUT pyramids installed into EXT slots (the reference
+    itself never loads them: SURVEY D3), voices spread over all pyramid levels, filter on."""
+    ref = Ref()
+    luts = np.load(os.path.join(HERE, "notamy_luts.npz"))
+    names = json.loads(str(luts["names"]))
+    slot = 200
+    slots = []
+    for nm in names:
+        ref.ext_table(slot, luts["f32_" + nm])
+        slots.append((slot, len(luts["f32_" + nm])))
+        slot += 1
+    u = (lcg_uniform(192, 0xA3) + 1.0) * 0.5
+    for v in range(64):
+        s, _ = slots[v % len(slots)]
+        f = 55.0 * 2.0 ** (6.0 * float(u[v]))
+        pan = float(u[64 + v]) * 2.0 - 1.0
+        k = 200.0 * (30.0 ** float(u[128 + v]))
+        ref.wire(f"v{v} w{s} f{f:.6f} a0.8 p{pan:.6f} J{1 + v % 4} K{k:.4f} Q{0.6 + (v % 7) * 0.4:.3f}")
+    c = Case("c2_notamy64", "notamy sine/triangle/impulse float LUTs (all pyramid levels, sizes 8..1024) "
+                            "as cyclic tables in EXT slots 200+, biquad modes 1..4")
+    c.segment(ref, 4096, 512)
+    c.save()
+
+
+# geometry (length, loopstart, loopend, midinote) of a few pcm_map entries, notamy/pcm_large.h:11-20
+PCM_GEOM = [(707, 342, 684, 89), (8186, 4282, 7439, 39), (2766, 1377, 2744, 45),
+            (1311, 898, 1288, 52), (2276, 1164, 2254, 51)]
+
+
+def case_c4_pcm():
+    """BASELINE config 5 shape, truncate mode: one-shot PCM-like tables (synthetic, seeded) with the
+    real pcm_map geometry: forward, reverse, looped, finishing mid-block."""
+    ref = Ref()
+    for i, (n, ls, le, note) in enumerate(PCM_GEOM):
+        data = lcg_uniform(n, 0x9C3 + i)
+        data = np.convolve(data, np.ones(5, np.float32) / 5.0, mode="same").astype(np.float32)
+        data /= np.abs(data).max()
+        hz = 440.0 * 2.0 ** ((note - 69.0) / 12.0)
+        ref.ext_table(200 + i, data, rate=22050.0, one_shot=1, loop_enabled=0, loop_start=ls,
+                      loop_end=le, midi_note=float(note), offset_hz=hz)
+    lines = []
+    v = 0
+    for i, (n, ls, le, note) in enumerate(PCM_GEOM):
+        hz = 440.0 * 2.0 ** ((note - 69.0) / 12.0)
+        for mode in range(4):
+            f = hz * [1.0, 0.37, 2.9, 7.3][(mode + i) % 4]
+            pan = -0.9 + 0.09 * v
+            if mode == 0:   # forward one-shot
+                lines.append(f"v{v} w{200 + i} f{f:.5f} a1 p{pan:.3f} T")
+            elif mode == 1:  # reverse one-shot
+                lines.append(f"v{v} w{200 + i} f{f:.5f} a1 p{pan:.3f} b1 T")
+            elif mode == 2:  # forward, looped between the map's loop points
+                lines.append(f"v{v} w{200 + i} f{f:.5f} a1 p{pan:.3f} B1 T")
+            else:            # reverse, looped
+                lines.append(f"v{v} w{200 + i} f{f:.5f} a1 p{pan:.3f} B1 b1 T")
+            v += 1
+    for ln in lines:
+        ref.wire(ln)
+    c = Case("c4_pcm_oneshot", "20 voices on 5 synthetic one-shot tables with pcm_map geometry: forward / "
+                               "reverse / looped / reverse-looped; several finish mid-block and freeze")
+    c.segment(ref, 3000, 512, keep_stems=tuple(range(v)))
+    # retrigger a few finished voices, change direction of a looping one
+    ref.wire("v0 T\nv1 T\nv6 b1\nv9 T")
+    c.segment(ref, 3000, 512, keep_stems=tuple(range(v)), note="after retrigger of v0 v1 v9, v6 reversed")
+    c.save()
+
+
+def case_edge_basic():
+    """Edge cases without cross-voice modulation."""
+    ref = Ref()
+    ref.wire("v0 w0 f440 a0")                              # amp == 0: skipped, state frozen
+    ref.wire("v1 w0 f330 a1 h7")                           # sample & hold
+    ref.wire("v2 w4 f220 a1 q4")                           # bit crush
+    ref.wire("v3 w0 f500 a1 m1")                           # disconnected from the mix
+    ref.wire("v4 w6 a0.5")                                 # shared per-frame LCG noise
+    ref.wire("v5 w5 f3 a0.5 p-0.5")                        # noise table
+    ref.wire("v6 w0 f440 a1 s0")                           # smoother off
+    ref.wire("v7 w0 f441 a1 s0.5")                         # fast smoother
+    ref.wire("v8 w3 f100 a1 b1")                           # cyclic table played backwards
+    ref.wire("v9 w0 f30000 a1 p0.3")                       # inc > size/2
+    ref.wire("v10 w2 f44000 a1 p-0.3")                     # inc ~ size: general fmodf wrap
+    ref.wire("v11 w0 f440 a1 t0.001,0.002,0.5,0.003 l1")   # short envelope, released below
+    ref.wire("v12 w1 f60 a1 J5 K1200 Q2")                  # all-pass
+    ref.wire("v13 w0 f0 a1")                               # zero increment
+    ref.wire("v14 w0 f1234.5 a1 h3 q6 J1 K900 Q1.5 p0.7")  # S&H + crush + filter together
+    ref.wire("v15 w0 f880 a1 t0,0,1,0 l0.5")               # flat envelope with velocity
+    ref.wire("v16 w0 f2 a1 p1")                            # sub-audio, hard right
+    ref.wire("V0.5")                                       # master volume change (smoothed)
+    c = Case("edge_basic", "skip/hold/crush/mute/noise/smoother/reverse/fast-wrap/short-ADSR/all-pass "
+                           "voices, master volume step")
+    c.segment(ref, 1024, 512, keep_stems=tuple(range(17)))
+    ref.wire("v11 l0\nv0 a1\nv6 a0\nv2 f3000\nV1")
+    c.segment(ref, 1024, 512, keep_stems=tuple(range(17)), note="v11 released, v0 un-muted, v6 amp 0")
+    c.segment(ref, 700, 33, keep_stems=tuple(range(17)), note="odd block size 33")
+    c.save()
+
+
+def case_edge_mod():
+    """Cross-voice modulation (FM/AM/pan/CZ) and phase distortion: SURVEY §8f rank 2."""
+    ref = Ref()
+    ref.wire("v0 w0 f440 a1 F1,5")          # FM, modulator index > carrier (previous frame's value)
+    ref.wire("v1 w0 f3 a20 m1")
+    ref.wire("v2 w0 f2 a10 m1")             # FM, modulator index < carrier (this frame's value)
+    ref.wire("v3 w0 f200 a1 F2,3")
+    ref.wire("v4 w0 f300 a1 A5,0.5")        # AM
+    ref.wire("v5 w0 f4 a1 m1")
+    ref.wire("v6 w1 f250 a1 P7,0.8")        # pan modulation
+    ref.wire("v7 w0 f1 a1 m1")
+    for i in range(7):                      # CZ modes 1..7
+        ref.wire(f"v{8 + i} w0 f{110 + 7 * i} a1 c{i + 1},{0.15 + 0.1 * i:.2f}")
+    ref.wire("v15 w0 f110 a1 c1,0.2 C16,0.3")  # CZ amount modulated
+    ref.wire("v16 w0 f0.5 a1 m1")
+    ref.wire("v17 w0 f330 a1 A17,0.9")         # self amplitude modulation
+    ref.wire("v18 w4 f120 a1 F19,2 A19,0.7 P19,0.5 J1 K800 Q2")  # everything from one modulator
+    ref.wire("v19 w0 f5 a2 m1")
+    ref.wire("v20 w0 f100 a1 F3,1")            # chain: v2 -> v3 -> v20
+    c = Case("edge_mod", "FM / AM / pan-mod / CZ modes 1..7 / CZ-mod / self-AM / modulation chain")
+    c.segment(ref, 2048, 512, keep_stems=tuple(range(21)))
+    c.save()
+
+
+CASES = {
+    "c0_0sk": case_c0_0sk,
+    "c1_sine_adsr64": case_c1_sine_adsr,
+    "c2_mixed_filter64": case_c2_mixed_filter,
+    "c2_notamy64": case_c2_notamy,
+    "c4_pcm_oneshot": case_c4_pcm,
+    "edge_basic": case_edge_basic,
+    "edge_mod": case_edge_mod,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case")
+    ap.add_argument("--list", action="store_true")
+    a = ap.parse_args()
+    if a.list:
+        print("\n".join(CASES))
+        return
+    if a.case:
+        CASES[a.case]()
+        return
+    for name in CASES:   # fresh process per case: synth() has function-static state
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""Reader for the golden fixtures written by tests/golden/gen_golden.py."""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from skred_amd.bank import RW_FIELDS, GlobalsC, VoiceBank, globals_from_json
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["c0_0sk", "c1_sine_adsr64", "c2_mixed_filter64", "c2_notamy64", "c4_pcm_oneshot",
+         "edge_basic", "edge_mod"]
+# cases whose voices are independent (no FM/AM/pan/CZ modulators)
+MOD_FREE_CASES = ["c1_sine_adsr64", "c2_mixed_filter64", "c2_notamy64", "c4_pcm_oneshot", "edge_basic"]
+
+
+@dataclass
+class Segment:
+    index: int
+    frames: int
+    block: int
+    bank_in: VoiceBank
+    bank_out_rw: dict            # read-write fields after the segment
+    g_in: GlobalsC
+    g_out: GlobalsC
+    mix: np.ndarray              # [F][2] post-master
+    stems_sha256: str            # of float32 [F][64][2]
+    stems: Optional[np.ndarray]  # [F][len(stems_voices)][2]
+    stems_voices: Optional[np.ndarray]
+
+
+@dataclass
+class Golden:
+    name: str
+    meta: dict
+    tables: np.ndarray
+    segments: List[Segment]
+
+
+def load(name: str) -> Golden:
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    segs = []
+    for k, sm in enumerate(meta["segments"]):
+        p = f"s{k}_"
+        segs.append(Segment(
+            index=k, frames=sm["frames"], block=sm["block"],
+            bank_in=VoiceBank.from_arrays(z, p + "in_"),
+            bank_out_rw={f: z[p + "out_" + f] for f in RW_FIELDS},
+            g_in=globals_from_json(str(z[p + "globals_in"])),
+            g_out=globals_from_json(str(z[p + "globals_out"])),
+            mix=z[p + "mix"], stems_sha256=str(z[p + "stems_sha256"]),
+            stems=z[p + "stems"] if (p + "stems") in z else None,
+            stems_voices=z[p + "stems_voices"] if (p + "stems_voices") in z else None))
+    return Golden(name, meta, np.ascontiguousarray(z["tables"], np.float32), segs)
+
+
+def expected_out_bank(seg: Segment) -> VoiceBank:
+    b = seg.bank_in.copy()
+    for f, v in seg.bank_out_rw.items():
+        b.a[f] = np.ascontiguousarray(v).astype(b.a[f].dtype, copy=True)
+    return b
+
+
+def sha256(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def bits_equal(a: np.ndarray, b: np.ndarray) -> bool:
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return a.shape == b.shape and bool((a.view(np.uint32) == b.view(np.uint32)).all())

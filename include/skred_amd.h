@@ -207,6 +207,12 @@ int  skred_bank_render_host(skred_bank_t *bank, float *buffer, int num_frames,
  * recorded around the render kernel itself (ms; <0 if unavailable). Synchronises. */
 float skred_bank_last_render_ms(skred_bank_t *bank);
 
+/* The render kernel of every skred_bank_render() call is bracketed by a hipEvent pair on the
+ * call's stream (ring of 256).  reset() starts a measurement window; summary() synchronises and
+ * reports mean / min kernel duration (ms) over the calls since the reset (at most the last 256). */
+void skred_bank_timing_reset(skred_bank_t *bank);
+int  skred_bank_timing_summary(skred_bank_t *bank, float *mean_ms, float *min_ms, int *count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,9 @@ _LIBS = {}
 def build(fast: bool = False) -> str:
     """Compile cpu_ref.c with the parity flags (or, fast=True, the reference's own -O3 -march=native)."""
     name = "libskred_cpuref_fast.so" if fast else "libskred_cpuref.so"
-    subprocess.run(["make", "-s", "-C", HERE, "_build/" + name], check=True)
+    # the -march=native build is only valid on the machine that made it: always remake it
+    cmd = ["make", "-s", "-C", HERE] + (["-B"] if fast else []) + ["_build/" + name]
+    subprocess.run(cmd, check=True)
     return os.path.join(HERE, "_build", name)
 
 

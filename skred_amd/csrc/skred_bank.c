@@ -1,0 +1,418 @@
+/*
+ * skred_bank.c -- C host shim behind include/skred_amd.h (bank mode).
+ *
+ * Plain C on purpose (the reference's host code is C, north_star: "Host code stays in C and
+ * reaches the HIP kernels through a thin C-ABI shim").  It owns the HBM copy of a voice bank,
+ * packs the reference-named host arrays (synth.def:12-89) into the 16-byte device planes of
+ * skred_device_layout.h, and sequences the kernels of skred_kernels.hip.  There is no CPU
+ * rendering here: every failure to reach the GPU is reported, never papered over.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "skred_amd.h"
+#include "skred_device_layout.h"
+
+/* launchers in skred_kernels.hip */
+int sk_launch_render(const sk_render_args_t *args, int n_workgroups, hipStream_t stream);
+int sk_launch_reduce(const float *partial, float *out, int W, int ncols, hipStream_t stream);
+int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels,
+                     float target, float k, float *gain_state, hipStream_t stream);
+
+#define SK_TIMING_RING 256
+
+struct skred_bank {
+  int device;
+  int n_voices, n_padded, n_groups;
+  sk_plane_t *d_ro[SKP_COUNT];
+  sk_plane_t *d_rw[SKS_COUNT];
+  float *d_tables;
+  size_t table_floats;        /* real pool size       */
+  size_t table_floats_padded; /* rounded up to 4      */
+  float *d_partial;           /* [n_wg][F][2]         */
+  size_t partial_cap;         /* floats               */
+  float *d_gain_state;        /* master smoother gain */
+  float *d_sum, *d_out, *d_stems; /* scratch of skred_bank_render_host */
+  size_t sum_cap, out_cap, stems_cap;
+  skred_globals_t g;
+  uint32_t features;
+  hipEvent_t ev0[SK_TIMING_RING], ev1[SK_TIMING_RING]; /* around the render kernel of each call */
+  int n_timed;                /* render calls since the last timing reset */
+};
+
+static __thread char g_err[512];
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(call)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (call);                                                        \
+    if (e_ != hipSuccess)                                                          \
+      return fail(SKRED_E_NO_DEVICE, "%s -> %s", #call, hipGetErrorString(e_));   \
+  } while (0)
+
+const char *skred_amd_last_error(void) { return g_err; }
+int skred_amd_abi_version(void) { return SKRED_AMD_ABI_VERSION; }
+
+int skred_amd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+/* ------------------------------------------------------------------ create / destroy */
+
+static int grow(float **buf, size_t *cap, size_t need) {
+  if (*cap >= need) return SKRED_OK;
+  if (*buf) { hipFree(*buf); *buf = NULL; *cap = 0; }
+  HIP_TRY(hipMalloc((void **)buf, need * sizeof(float)));
+  *cap = need;
+  return SKRED_OK;
+}
+
+int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
+  if (!out || n_voices <= 0) return fail(SKRED_E_BAD_ARG, "skred_bank_create: bad arguments");
+  *out = NULL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SKRED_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(SKRED_E_BAD_ARG, "device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  skred_bank_t *b = (skred_bank_t *)calloc(1, sizeof(*b));
+  if (!b) return fail(SKRED_E_NO_MEM, "calloc");
+  b->device = device;
+  b->n_voices = n_voices;
+  b->n_groups = (n_voices + SK_GROUP - 1) / SK_GROUP;
+  b->n_padded = b->n_groups * SK_GROUP;
+  const size_t plane_bytes = (size_t)b->n_padded * sizeof(sk_plane_t);
+  for (int p = 0; p < SKP_COUNT; p++) {
+    HIP_TRY(hipMalloc((void **)&b->d_ro[p], plane_bytes));
+    HIP_TRY(hipMemset(b->d_ro[p], 0, plane_bytes));
+  }
+  for (int p = 0; p < SKS_COUNT; p++) {
+    HIP_TRY(hipMalloc((void **)&b->d_rw[p], plane_bytes));
+    HIP_TRY(hipMemset(b->d_rw[p], 0, plane_bytes));
+  }
+  /* every slot starts inert (skipped by the kernel) until a voice is uploaded into it */
+  sk_plane_t *inert = (sk_plane_t *)calloc((size_t)b->n_padded, sizeof(sk_plane_t));
+  if (!inert) return fail(SKRED_E_NO_MEM, "calloc");
+  for (int v = 0; v < b->n_padded; v++) inert[v].w[2] = SKF_INERT;
+  hipError_t e = hipMemcpy(b->d_ro[SKP_TAB], inert, plane_bytes, hipMemcpyHostToDevice);
+  free(inert);
+  HIP_TRY(e);
+  HIP_TRY(hipMalloc((void **)&b->d_gain_state, 4 * sizeof(float)));
+  HIP_TRY(hipMemset(b->d_gain_state, 0, 4 * sizeof(float)));
+  for (int i = 0; i < SK_TIMING_RING; i++) {
+    HIP_TRY(hipEventCreate(&b->ev0[i]));
+    HIP_TRY(hipEventCreate(&b->ev1[i]));
+  }
+  /* synth.c:85-92 defaults: volume_user 1 * AMY_FACTOR, LCG seeded with 1 (synth.c:508) */
+  b->g.synth_sample_count = 0;
+  b->g.noise_rng = 1;
+  b->g.volume_final = 0.025f;
+  b->g.volume_smoother_gain = 0.0f;
+  b->g.volume_smoother_smoothing = 0.002f;
+  *out = b;
+  return SKRED_OK;
+}
+
+void skred_bank_destroy(skred_bank_t *b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  for (int p = 0; p < SKP_COUNT; p++) if (b->d_ro[p]) hipFree(b->d_ro[p]);
+  for (int p = 0; p < SKS_COUNT; p++) if (b->d_rw[p]) hipFree(b->d_rw[p]);
+  if (b->d_tables) hipFree(b->d_tables);
+  if (b->d_partial) hipFree(b->d_partial);
+  if (b->d_gain_state) hipFree(b->d_gain_state);
+  if (b->d_sum) hipFree(b->d_sum);
+  if (b->d_out) hipFree(b->d_out);
+  if (b->d_stems) hipFree(b->d_stems);
+  for (int i = 0; i < SK_TIMING_RING; i++) {
+    if (b->ev0[i]) hipEventDestroy(b->ev0[i]);
+    if (b->ev1[i]) hipEventDestroy(b->ev1[i]);
+  }
+  free(b);
+}
+
+int skred_bank_n_voices(const skred_bank_t *b) { return b ? b->n_voices : 0; }
+
+/* ------------------------------------------------------------------ tables */
+
+int skred_bank_set_tables_f32(skred_bank_t *b, const float *pool, size_t n_floats) {
+  if (!b || !pool || n_floats == 0) return fail(SKRED_E_BAD_ARG, "set_tables: bad arguments");
+  if (n_floats > 0x7FFFFFF0u) return fail(SKRED_E_RANGE, "table pool too large");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->d_tables) { hipFree(b->d_tables); b->d_tables = NULL; }
+  b->table_floats = n_floats;
+  b->table_floats_padded = (n_floats + 3) & ~(size_t)3;
+  HIP_TRY(hipMalloc((void **)&b->d_tables, b->table_floats_padded * sizeof(float)));
+  HIP_TRY(hipMemset(b->d_tables, 0, b->table_floats_padded * sizeof(float)));
+  HIP_TRY(hipMemcpy(b->d_tables, pool, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  return SKRED_OK;
+}
+
+/* ------------------------------------------------------------------ pack / unpack */
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_first, int dst_first, int count) {
+  if (!b || !h || count < 0) return fail(SKRED_E_BAD_ARG, "upload: bad arguments");
+  if (src_first < 0 || src_first + count > h->n_voices || dst_first < 0 || dst_first + count > b->n_voices)
+    return fail(SKRED_E_RANGE, "upload window [%d,+%d) -> [%d,+%d) outside bank", src_first, count, dst_first, count);
+  if (count == 0) return SKRED_OK;
+  HIP_TRY(hipSetDevice(b->device));
+  const int NP = SKP_COUNT + SKS_COUNT;
+  sk_plane_t *st = (sk_plane_t *)calloc((size_t)NP * (size_t)count, sizeof(sk_plane_t));
+  if (!st) return fail(SKRED_E_NO_MEM, "upload staging");
+  uint32_t features = (dst_first == 0 && count == b->n_voices) ? 0u : b->features;
+  for (int i = 0; i < count; i++) {
+    const int v = src_first + i;
+    sk_plane_t *ro = st, *rw = st + (size_t)SKP_COUNT * count;
+#define RO(p) ro[(size_t)(p) * count + i]
+#define RW(p) rw[(size_t)(p) * count + i]
+    const int size = h->voice_table_size[v];
+    const int64_t off = h->voice_table_offset[v];
+    const int noise = h->voice_wave_table_index[v] == SKRED_WAVE_TABLE_NOISE_ALT;
+    uint32_t flags = 0;
+    int usable = 1;
+    if (!noise) {
+      if (size <= 0) usable = 0;   /* the reference would dereference a NULL/empty table here */
+      else if (off < 0 || (uint64_t)off + (uint64_t)size > b->table_floats) {
+        free(st);
+        return fail(SKRED_E_RANGE, "voice %d: table [%lld,+%d) outside pool of %zu floats", v, (long long)off, size, b->table_floats);
+      }
+    }
+    if (!usable) flags |= SKF_INERT;
+    const int windowed = h->voice_loop_enabled[v] && h->voice_loop_valid[v];   /* synth.c:235-238 */
+    const float lo = windowed ? h->voice_loop_start_f[v] : 0.0f;
+    const float hi = windowed ? h->voice_loop_end_f[v] : (float)size;
+    if (h->voice_one_shot[v]) flags |= SKF_ONE_SHOT;
+    if (h->voice_loop_enabled[v]) flags |= SKF_LOOPING;
+    if (h->voice_direction[v]) flags |= SKF_REVERSE;
+    if (h->voice_use_amp_envelope[v]) { flags |= SKF_USE_ENV; features |= SKB_ANY_ENV; }
+    if (h->voice_filter_mode[v]) { flags |= SKF_FILTER; features |= SKB_ANY_FILTER; }
+    if (h->voice_smoother_enable[v]) flags |= SKF_SMOOTH;
+    if (h->voice_disconnect[v]) flags |= SKF_MUTED;
+    if (noise) { flags |= SKF_NOISE; features |= SKB_ANY_NOISE; }
+    const int has_mod = h->voice_freq_mod_osc[v] >= 0 || h->voice_amp_mod_osc[v] >= 0 ||
+                        h->voice_pan_mod_osc[v] >= 0 || h->voice_cz_mode[v] != 0;
+    if (has_mod) { flags |= SKF_HAS_MOD; features |= SKB_ANY_MOD; }
+    int quant = h->voice_quantize[v], hold = h->voice_sample_hold_max[v];
+    if (quant < 0 || quant > 30) quant = quant < 0 ? 0 : 30;
+    if (hold < 0) hold = 0;
+    if (hold > 0xFFFFFF) hold = 0xFFFFFF;
+    if (quant || hold) features |= SKB_ANY_HOLDQ;
+    const skred_envelope_t *e = &h->voice_amp_envelope[v];
+    const skred_mmf_t *f = &h->voice_filter[v];
+
+    RO(SKP_OSC).w[0] = f2u(h->voice_phase_inc[v]); RO(SKP_OSC).w[1] = f2u(lo);
+    RO(SKP_OSC).w[2] = f2u(hi);                    RO(SKP_OSC).w[3] = f2u(h->voice_amp[v]);
+    RO(SKP_TAB).w[0] = (uint32_t)(int32_t)(usable && !noise ? off : 0);
+    RO(SKP_TAB).w[1] = (uint32_t)size; RO(SKP_TAB).w[2] = flags;
+    RO(SKP_TAB).w[3] = (uint32_t)quant | ((uint32_t)hold << 8);
+    RO(SKP_ENV_T).w[0] = f2u(e->attack_time);   RO(SKP_ENV_T).w[1] = f2u(e->decay_time);
+    RO(SKP_ENV_T).w[2] = f2u(e->sustain_level); RO(SKP_ENV_T).w[3] = f2u(e->release_time);
+    RO(SKP_ENV_S).w[0] = (uint32_t)(e->sample_start & 0xFFFFFFFFu);
+    RO(SKP_ENV_S).w[1] = (uint32_t)(e->sample_start >> 32);
+    RO(SKP_ENV_S).w[2] = (uint32_t)(e->sample_release & 0xFFFFFFFFu);
+    RO(SKP_ENV_S).w[3] = (uint32_t)(e->sample_release >> 32);
+    RO(SKP_GAIN).w[0] = f2u(e->velocity); RO(SKP_GAIN).w[1] = f2u(h->voice_smoother_smoothing[v]);
+    RO(SKP_GAIN).w[2] = f2u(f->b0);       RO(SKP_GAIN).w[3] = f2u(f->b1);
+    RO(SKP_FILT).w[0] = f2u(f->b2); RO(SKP_FILT).w[1] = f2u(f->a1);
+    RO(SKP_FILT).w[2] = f2u(f->a2); RO(SKP_FILT).w[3] = f2u(h->voice_cz_distortion[v]);
+    RO(SKP_MODI).w[0] = (uint32_t)h->voice_freq_mod_osc[v]; RO(SKP_MODI).w[1] = (uint32_t)h->voice_amp_mod_osc[v];
+    RO(SKP_MODI).w[2] = (uint32_t)h->voice_pan_mod_osc[v];  RO(SKP_MODI).w[3] = (uint32_t)h->voice_cz_mod_osc[v];
+    RO(SKP_MODF).w[0] = f2u(h->voice_freq_mod_depth[v]); RO(SKP_MODF).w[1] = f2u(h->voice_freq_scale[v]);
+    RO(SKP_MODF).w[2] = f2u(h->voice_amp_mod_depth[v]);  RO(SKP_MODF).w[3] = f2u(h->voice_pan_mod_depth[v]);
+    RO(SKP_MODX).w[0] = f2u(h->voice_cz_mod_depth[v]); RO(SKP_MODX).w[1] = (uint32_t)h->voice_cz_mode[v];
+
+    RW(SKS_OSC).w[0] = f2u(h->voice_phase[v]); RW(SKS_OSC).w[1] = f2u(h->voice_smoother_gain[v]);
+    RW(SKS_OSC).w[2] = f2u(f->x1);             RW(SKS_OSC).w[3] = f2u(f->x2);
+    RW(SKS_FILT).w[0] = f2u(f->y1); RW(SKS_FILT).w[1] = f2u(f->y2);
+    RW(SKS_FILT).w[2] = f2u(h->voice_sample[v]);
+    RW(SKS_FILT).w[3] = (h->voice_finished[v] ? SKR_FINISHED : 0u) | (e->is_active ? SKR_ENV_ACTIVE : 0u);
+    RW(SKS_MISC).w[0] = f2u(h->voice_sample_hold[v]); RW(SKS_MISC).w[1] = (uint32_t)h->voice_sample_hold_count[v];
+    RW(SKS_MISC).w[2] = f2u(h->voice_pan_left[v]);    RW(SKS_MISC).w[3] = f2u(h->voice_pan_right[v]);
+#undef RO
+#undef RW
+  }
+  const size_t bytes = (size_t)count * sizeof(sk_plane_t);
+  hipError_t e = hipSuccess;
+  for (int p = 0; p < SKP_COUNT && e == hipSuccess; p++)
+    e = hipMemcpy(b->d_ro[p] + dst_first, st + (size_t)p * count, bytes, hipMemcpyHostToDevice);
+  for (int p = 0; p < SKS_COUNT && e == hipSuccess; p++)
+    e = hipMemcpy(b->d_rw[p] + dst_first, st + (size_t)(SKP_COUNT + p) * count, bytes, hipMemcpyHostToDevice);
+  free(st);
+  HIP_TRY(e);
+  b->features = features;
+  return SKRED_OK;
+}
+
+int skred_bank_download(skred_bank_t *b, skred_voice_bank_t *h, int src_first, int dst_first, int count) {
+  if (!b || !h || count < 0) return fail(SKRED_E_BAD_ARG, "download: bad arguments");
+  if (src_first < 0 || src_first + count > b->n_voices || dst_first < 0 || dst_first + count > h->n_voices)
+    return fail(SKRED_E_RANGE, "download window outside bank");
+  if (count == 0) return SKRED_OK;
+  HIP_TRY(hipSetDevice(b->device));
+  sk_plane_t *st = (sk_plane_t *)malloc((size_t)SKS_COUNT * (size_t)count * sizeof(sk_plane_t));
+  if (!st) return fail(SKRED_E_NO_MEM, "download staging");
+  HIP_TRY(hipDeviceSynchronize());
+  hipError_t e = hipSuccess;
+  for (int p = 0; p < SKS_COUNT && e == hipSuccess; p++)
+    e = hipMemcpy(st + (size_t)p * count, b->d_rw[p] + src_first, (size_t)count * sizeof(sk_plane_t), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { free(st); HIP_TRY(e); }
+  for (int i = 0; i < count; i++) {
+    const int v = dst_first + i;
+    const sk_plane_t *s0 = &st[(size_t)SKS_OSC * count + i];
+    const sk_plane_t *s1 = &st[(size_t)SKS_FILT * count + i];
+    const sk_plane_t *s2 = &st[(size_t)SKS_MISC * count + i];
+    h->voice_phase[v] = u2f(s0->w[0]);
+    h->voice_smoother_gain[v] = u2f(s0->w[1]);
+    h->voice_filter[v].x1 = u2f(s0->w[2]); h->voice_filter[v].x2 = u2f(s0->w[3]);
+    h->voice_filter[v].y1 = u2f(s1->w[0]); h->voice_filter[v].y2 = u2f(s1->w[1]);
+    h->voice_sample[v] = u2f(s1->w[2]);
+    h->voice_finished[v] = (s1->w[3] & SKR_FINISHED) ? 1 : 0;
+    h->voice_amp_envelope[v].is_active = (s1->w[3] & SKR_ENV_ACTIVE) ? 1 : 0;
+    h->voice_sample_hold[v] = u2f(s2->w[0]);
+    h->voice_sample_hold_count[v] = (int32_t)s2->w[1];
+    h->voice_pan_left[v] = u2f(s2->w[2]);
+    h->voice_pan_right[v] = u2f(s2->w[3]);
+  }
+  free(st);
+  return SKRED_OK;
+}
+
+/* ------------------------------------------------------------------ globals */
+
+int skred_bank_set_globals(skred_bank_t *b, const skred_globals_t *g) {
+  if (!b || !g) return fail(SKRED_E_BAD_ARG, "set_globals");
+  HIP_TRY(hipSetDevice(b->device));
+  b->g = *g;
+  HIP_TRY(hipMemcpy(b->d_gain_state, &g->volume_smoother_gain, sizeof(float), hipMemcpyHostToDevice));
+  return SKRED_OK;
+}
+
+int skred_bank_get_globals(skred_bank_t *b, skred_globals_t *g) {
+  if (!b || !g) return fail(SKRED_E_BAD_ARG, "get_globals");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&b->g.volume_smoother_gain, b->d_gain_state, sizeof(float), hipMemcpyDeviceToHost));
+  *g = b->g;
+  return SKRED_OK;
+}
+
+/* ------------------------------------------------------------------ render */
+
+int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_partial, float *d_stems, void *stream) {
+  if (!b || !d_partial || num_frames <= 0) return fail(SKRED_E_BAD_ARG, "render: bad arguments");
+  if (interp != SKRED_INTERP_TRUNCATE && interp != SKRED_INTERP_LINEAR) return fail(SKRED_E_BAD_ARG, "render: interp %d", interp);
+  if (!b->d_tables) return fail(SKRED_E_BAD_ARG, "render: no table pool set");
+  if (b->features & SKB_ANY_MOD)
+    return fail(SKRED_E_UNSUPPORTED, "bank uses cross-voice modulation / CZ phase distortion: not in this kernel yet");
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int n_wg = b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS;
+  int rc = grow(&b->d_partial, &b->partial_cap, (size_t)n_wg * (size_t)num_frames * 2);
+  if (rc) return rc;
+
+  sk_render_args_t a;
+  memset(&a, 0, sizeof(a));
+  for (int p = 0; p < SKP_COUNT; p++) a.ro[p] = b->d_ro[p];
+  for (int p = 0; p < SKS_COUNT; p++) a.rw[p] = b->d_rw[p];
+  a.tables = b->d_tables;
+  a.partial = b->d_partial;
+  a.stems = d_stems;
+  a.count0 = b->g.synth_sample_count;
+  a.rng0 = b->g.noise_rng;
+  a.n_voices = b->n_voices;
+  a.n_groups = b->n_groups;
+  a.num_frames = num_frames;
+  a.table_floats = (int32_t)b->table_floats;
+  a.lds_table_floats = b->table_floats_padded <= SK_LDS_TABLE_MAX_FLOATS ? (int32_t)b->table_floats_padded : 0;
+  a.interp = interp;
+  a.features = b->features;
+
+  const int slot = b->n_timed % SK_TIMING_RING;
+  HIP_TRY(hipEventRecord(b->ev0[slot], s));
+  hipError_t e = (hipError_t)sk_launch_render(&a, n_wg, s);
+  if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "render launch -> %s", hipGetErrorString(e));
+  HIP_TRY(hipEventRecord(b->ev1[slot], s));
+  b->n_timed++;
+  e = (hipError_t)sk_launch_reduce(b->d_partial, d_partial, n_wg, 2 * num_frames, s);
+  if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "reduce launch -> %s", hipGetErrorString(e));
+
+  /* advance the timeline exactly as synth.c:521,525 do: one count and one LCG draw per frame */
+  b->g.synth_sample_count += (uint64_t)num_frames;
+  uint64_t r = b->g.noise_rng;
+  for (int i = 0; i < num_frames; i++) r = r * 6364136223846793005ULL + 1442695040888963407ULL;
+  b->g.noise_rng = r;
+  return SKRED_OK;
+}
+
+int skred_bank_master(skred_bank_t *b, const float *d_sum, int num_frames, int num_channels, float *d_out, void *stream) {
+  if (!b || !d_sum || !d_out || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "master: bad arguments");
+  HIP_TRY(hipSetDevice(b->device));
+  hipError_t e = (hipError_t)sk_launch_master(d_sum, d_out, num_frames, num_channels, b->g.volume_final,
+                                              b->g.volume_smoother_smoothing, b->d_gain_state, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "master launch -> %s", hipGetErrorString(e));
+  return SKRED_OK;
+}
+
+int skred_bank_render_host(skred_bank_t *b, float *buffer, int num_frames, int num_channels, int interp, float *stems) {
+  if (!b || !buffer || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "render_host: bad arguments");
+  HIP_TRY(hipSetDevice(b->device));
+  int rc;
+  if ((rc = grow(&b->d_sum, &b->sum_cap, (size_t)num_frames * 2))) return rc;
+  if ((rc = grow(&b->d_out, &b->out_cap, (size_t)num_frames * (size_t)num_channels))) return rc;
+  const size_t stem_floats = (size_t)num_frames * (size_t)b->n_voices * 2;
+  if (stems && (rc = grow(&b->d_stems, &b->stems_cap, stem_floats))) return rc;
+  if (num_channels > 2) HIP_TRY(hipMemsetAsync(b->d_out, 0, (size_t)num_frames * num_channels * sizeof(float), NULL));
+  if ((rc = skred_bank_render(b, num_frames, interp, b->d_sum, stems ? b->d_stems : NULL, NULL))) return rc;
+  if ((rc = skred_bank_master(b, b->d_sum, num_frames, num_channels, b->d_out, NULL))) return rc;
+  HIP_TRY(hipMemcpy(buffer, b->d_out, (size_t)num_frames * num_channels * sizeof(float), hipMemcpyDeviceToHost));
+  if (stems) HIP_TRY(hipMemcpy(stems, b->d_stems, stem_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return SKRED_OK;
+}
+
+float skred_bank_last_render_ms(skred_bank_t *b) {
+  if (!b || b->n_timed == 0) return -1.0f;
+  const int slot = (b->n_timed - 1) % SK_TIMING_RING;
+  float ms = -1.0f;
+  if (hipSetDevice(b->device) != hipSuccess) return -1.0f;
+  if (hipEventSynchronize(b->ev1[slot]) != hipSuccess) return -1.0f;
+  if (hipEventElapsedTime(&ms, b->ev0[slot], b->ev1[slot]) != hipSuccess) return -1.0f;
+  return ms;
+}
+
+void skred_bank_timing_reset(skred_bank_t *b) { if (b) b->n_timed = 0; }
+
+int skred_bank_timing_summary(skred_bank_t *b, float *mean_ms, float *min_ms, int *count) {
+  if (!b) return fail(SKRED_E_BAD_ARG, "timing_summary");
+  HIP_TRY(hipSetDevice(b->device));
+  const int n = b->n_timed < SK_TIMING_RING ? b->n_timed : SK_TIMING_RING;
+  double sum = 0.0;
+  float mn = 0.0f;
+  for (int i = 0; i < n; i++) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventSynchronize(b->ev1[i]));
+    HIP_TRY(hipEventElapsedTime(&ms, b->ev0[i], b->ev1[i]));
+    sum += ms;
+    if (i == 0 || ms < mn) mn = ms;
+  }
+  if (mean_ms) *mean_ms = n ? (float)(sum / n) : -1.0f;
+  if (min_ms) *min_ms = n ? mn : -1.0f;
+  if (count) *count = n;
+  return SKRED_OK;
+}

@@ -1,0 +1,95 @@
+/*
+ * skred_device_layout.h -- how a voice bank is laid out in HBM.
+ *
+ * The host view (include/skred_amd.h: skred_voice_bank_t) keeps one array per reference
+ * field (synth.def:12-89).  On the device the ~60 hot fields of a voice are packed into
+ * 16-byte "planes": plane p is an array uint4[n_padded], so a wavefront of 64 consecutive
+ * voices reads or writes one plane with ONE dwordx4 access per lane = 1 KiB contiguous.
+ * Read-only planes (parameters) are loaded once per launch; read-write planes (the serial
+ * recurrences: phase, smoother, biquad delay line ...) are loaded, kept in registers for
+ * all frames of the launch, and stored back once.
+ *
+ * Shared between the C host shim (packing) and the HIP kernels (unpacking).
+ */
+#ifndef SKRED_DEVICE_LAYOUT_H
+#define SKRED_DEVICE_LAYOUT_H
+
+#include <stdint.h>
+
+/* ---- read-only planes ---- */
+enum {
+  SKP_OSC = 0,   /* f32 phase_inc | f32 loop_lo | f32 loop_hi | f32 amp                              */
+  SKP_TAB,       /* i32 table_offset | i32 table_size | u32 flags | u32 quantize | hold_max<<8        */
+  SKP_ENV_T,     /* f32 attack_time | f32 decay_time | f32 sustain_level | f32 release_time          */
+  SKP_ENV_S,     /* u32 sample_start lo,hi | u32 sample_release lo,hi                                 */
+  SKP_GAIN,      /* f32 velocity | f32 smoother_smoothing | f32 b0 | f32 b1                           */
+  SKP_FILT,      /* f32 b2 | f32 a1 | f32 a2 | f32 cz_distortion                                      */
+  SKP_MODI,      /* i32 freq_mod_osc | i32 amp_mod_osc | i32 pan_mod_osc | i32 cz_mod_osc             */
+  SKP_MODF,      /* f32 freq_mod_depth | f32 freq_scale | f32 amp_mod_depth | f32 pan_mod_depth       */
+  SKP_MODX,      /* f32 cz_mod_depth | i32 cz_mode | 0 | 0                                            */
+  SKP_COUNT
+};
+
+/* ---- read-write planes ---- */
+enum {
+  SKS_OSC = 0,   /* f32 phase | f32 smoother_gain | f32 x1 | f32 x2                                   */
+  SKS_FILT,      /* f32 y1 | f32 y2 | f32 voice_sample | u32 rwflags                                  */
+  SKS_MISC,      /* f32 sample_hold | i32 sample_hold_count | f32 pan_left | f32 pan_right            */
+  SKS_COUNT
+};
+
+/* loop_lo / loop_hi are the window osc_next() actually uses (synth.c:235-238):
+ *   loop_enabled && loop_valid ? loop_start_f : 0      and      ... ? loop_end_f : (float)table_size
+ * -- a pure select, resolved on upload. */
+
+/* flags word of SKP_TAB */
+#define SKF_ONE_SHOT   (1u << 0)   /* voice_one_shot                                   */
+#define SKF_LOOPING    (1u << 1)   /* voice_loop_enabled                               */
+#define SKF_REVERSE    (1u << 2)   /* voice_direction                                  */
+#define SKF_USE_ENV    (1u << 3)   /* voice_use_amp_envelope                           */
+#define SKF_FILTER     (1u << 4)   /* voice_filter_mode != 0                           */
+#define SKF_SMOOTH     (1u << 5)   /* voice_smoother_enable                            */
+#define SKF_MUTED      (1u << 6)   /* voice_disconnect                                 */
+#define SKF_NOISE      (1u << 7)   /* voice_wave_table_index == WAVE_TABLE_NOISE_ALT   */
+#define SKF_INERT      (1u << 8)   /* padding voice, or a voice without a table: always skipped */
+#define SKF_HAS_MOD    (1u << 9)   /* names another voice as FM/AM/pan/CZ modulator, or uses CZ */
+
+/* rwflags word of SKS_FILT */
+#define SKR_FINISHED   (1u << 0)   /* voice_finished                 */
+#define SKR_ENV_ACTIVE (1u << 1)   /* voice_amp_envelope.is_active   */
+
+/* bank-wide feature summary (OR over voices), selects kernel paths */
+#define SKB_ANY_NOISE  (1u << 0)
+#define SKB_ANY_FILTER (1u << 1)
+#define SKB_ANY_ENV    (1u << 2)
+#define SKB_ANY_HOLDQ  (1u << 3)   /* sample&hold or bit-crush somewhere */
+#define SKB_ANY_MOD    (1u << 4)
+
+#define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */
+#define SK_CHUNK 64                /* frames between two workgroup-level mix flushes */
+#define SK_LDS_TABLE_MAX_FLOATS 12288  /* 48 KiB: pools up to this size are staged in LDS */
+#define SK_MAX_WORKGROUPS 2048
+
+typedef struct {
+  uint32_t w[4];
+} sk_plane_t;
+
+/* kernel arguments of the render kernel */
+typedef struct {
+  const sk_plane_t *ro[SKP_COUNT];
+  sk_plane_t *rw[SKS_COUNT];
+  const float *tables;     /* HBM pool */
+  float *partial;          /* [n_workgroups][num_frames][2] pre-master partial sums */
+  float *stems;            /* [num_frames][n_voices][2] or NULL */
+  uint64_t count0;         /* synth_sample_count before the first frame */
+  uint64_t rng0;           /* noise LCG state before the first frame */
+  int32_t n_voices;        /* real voices (stems indexing) */
+  int32_t n_groups;        /* n_padded / SK_GROUP */
+  int32_t num_frames;
+  int32_t table_floats;    /* pool size */
+  int32_t lds_table_floats;/* floats staged in LDS (0 or == table_floats) */
+  int32_t interp;
+  uint32_t features;       /* SKB_* */
+} sk_render_args_t;
+
+#endif

@@ -1,0 +1,147 @@
+"""ctypes binding of libskred_amd.so (the C ABI in include/skred_amd.h).
+
+This is plumbing for tests and bench.py; the product is the shared library.  There is no
+fallback of any kind: a missing library or a machine without a usable GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .bank import GlobalsC, VoiceBank, VoiceBankC
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libskred_amd.so")
+
+# every symbol include/skred_amd.h declares
+ABI_SYMBOLS = [
+    "skred_amd_abi_version", "skred_amd_device_count", "skred_amd_last_error",
+    "skred_bank_create", "skred_bank_destroy", "skred_bank_n_voices",
+    "skred_bank_set_tables_f32", "skred_bank_upload", "skred_bank_download",
+    "skred_bank_set_globals", "skred_bank_get_globals",
+    "skred_bank_render", "skred_bank_master", "skred_bank_render_host",
+    "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+class SkredAmdError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library; raise loudly when it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SkredAmdError(f"{LIB_PATH} is missing: build it with `make -C skred_amd/csrc` "
+                            "(there is no CPU fallback for the render path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    L.skred_amd_abi_version.restype = i32
+    L.skred_amd_device_count.restype = i32
+    L.skred_amd_last_error.restype = C.c_char_p
+    L.skred_bank_create.argtypes = [i32, i32, C.POINTER(vp)]
+    L.skred_bank_destroy.argtypes = [vp]
+    L.skred_bank_destroy.restype = None
+    L.skred_bank_n_voices.argtypes = [vp]
+    L.skred_bank_set_tables_f32.argtypes = [vp, vp, C.c_size_t]
+    L.skred_bank_upload.argtypes = [vp, C.POINTER(VoiceBankC), i32, i32, i32]
+    L.skred_bank_download.argtypes = [vp, C.POINTER(VoiceBankC), i32, i32, i32]
+    L.skred_bank_set_globals.argtypes = [vp, C.POINTER(GlobalsC)]
+    L.skred_bank_get_globals.argtypes = [vp, C.POINTER(GlobalsC)]
+    L.skred_bank_render.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.skred_bank_master.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.skred_bank_render_host.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.skred_bank_last_render_ms.argtypes = [vp]
+    L.skred_bank_last_render_ms.restype = C.c_float
+    L.skred_bank_timing_reset.argtypes = [vp]
+    L.skred_bank_timing_reset.restype = None
+    L.skred_bank_timing_summary.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().skred_amd_last_error().decode(errors="replace")
+        raise SkredAmdError(f"{what} failed (rc={rc}): {msg}")
+
+
+class DeviceBank:
+    """A voice bank resident in one GPU's HBM."""
+
+    def __init__(self, n_voices: int, device: int = 0):
+        self.L = load()
+        self.n = int(n_voices)
+        self.device = device
+        h = C.c_void_p()
+        _check(self.L.skred_bank_create(device, self.n, C.byref(h)), "skred_bank_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.skred_bank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_tables(self, pool: np.ndarray):
+        pool = np.ascontiguousarray(pool, np.float32)
+        _check(self.L.skred_bank_set_tables_f32(self.h, pool.ctypes.data, pool.size), "skred_bank_set_tables_f32")
+
+    def upload(self, bank: VoiceBank, src_first: int = 0, dst_first: int = 0, count: Optional[int] = None):
+        count = bank.n - src_first if count is None else count
+        cb = bank.as_c()
+        _check(self.L.skred_bank_upload(self.h, C.byref(cb), src_first, dst_first, count), "skred_bank_upload")
+
+    def download(self, bank: VoiceBank, src_first: int = 0, dst_first: int = 0, count: Optional[int] = None):
+        count = bank.n - dst_first if count is None else count
+        cb = bank.as_c()
+        _check(self.L.skred_bank_download(self.h, C.byref(cb), src_first, dst_first, count), "skred_bank_download")
+
+    def set_globals(self, g: GlobalsC):
+        _check(self.L.skred_bank_set_globals(self.h, C.byref(g)), "skred_bank_set_globals")
+
+    def get_globals(self) -> GlobalsC:
+        g = GlobalsC()
+        _check(self.L.skred_bank_get_globals(self.h, C.byref(g)), "skred_bank_get_globals")
+        return g
+
+    def render(self, frames: int, d_partial: int, d_stems: int = 0, interp: int = 0, stream: int = 0):
+        """Asynchronous render into device pointers (ints), e.g. torch tensor .data_ptr()."""
+        _check(self.L.skred_bank_render(self.h, frames, interp, d_partial, d_stems or None, stream or None),
+               "skred_bank_render")
+
+    def master(self, d_sum: int, frames: int, d_out: int, channels: int = 2, stream: int = 0):
+        _check(self.L.skred_bank_master(self.h, d_sum, frames, channels, d_out, stream or None), "skred_bank_master")
+
+    def render_host(self, frames: int, channels: int = 2, interp: int = 0, want_stems: bool = False):
+        """The synth() contract on host buffers.  Returns (buffer [F][ch], stems [F][N][2] | None)."""
+        buf = np.zeros((frames, channels), np.float32)
+        stems = np.zeros((frames, self.n, 2), np.float32) if want_stems else None
+        _check(self.L.skred_bank_render_host(self.h, buf.ctypes.data, frames, channels, interp,
+                                             stems.ctypes.data if want_stems else None), "skred_bank_render_host")
+        return buf, stems
+
+    def last_render_ms(self) -> float:
+        return float(self.L.skred_bank_last_render_ms(self.h))
+
+    def timing_reset(self):
+        self.L.skred_bank_timing_reset(self.h)
+
+    def timing_summary(self):
+        """(mean_ms, min_ms, count) of the render kernel over the calls since timing_reset()."""
+        mean, mn, cnt = C.c_float(), C.c_float(), C.c_int()
+        _check(self.L.skred_bank_timing_summary(self.h, C.byref(mean), C.byref(mn), C.byref(cnt)),
+               "skred_bank_timing_summary")
+        return float(mean.value), float(mn.value), int(cnt.value)

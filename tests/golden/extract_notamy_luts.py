@@ -9,8 +9,9 @@
 These band-limited single-cycle tables (from shorepine/AMY) are INPUT DATA of the hot path
 (north_star: "wavetable lookup into the notamy/ sine/triangle/impulse LUTs"); no reference C file
 includes them, so there is no reference behaviour attached to them beyond the
-numbers themselves.  Keys:  f32_<name>, i16_<name>, and JSON `names`, `meta` (table_size,
-highest_harmonic, log2_size, scale_factor per table).
+numbers themselves.  Keys:  f32_<name>, i16_<name>, JSON `names`, `meta` (table_size,
+highest_harmonic, log2_size, scale_factor per table), and `pcm_map` [67][5] = (offset, length,
+loopstart, loopend, midinote) of the AMY PCM regions.
 """
 import json
 import os
@@ -56,6 +57,14 @@ def main():
             names.append(nm)
             meta[nm] = {"table_size": int(f[1]), "highest_harmonic": int(f[2]),
                         "log2_size": int(x[2]), "scale_factor": float(x[4])}
+    # pcm_map geometry (offset, length, loopstart, loopend, midinote), notamy/pcm_large.h:10-78; the sample
+    # blob itself (notamy/pcm_samples_large.h) is absent from the mount, so only the geometry exists.
+    ptxt = open(os.path.join(REF, "notamy", "pcm_large.h")).read()
+    rows = re.findall(r"\{\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(?:/\*.*?\*/)?\s*(\d+)\s*\}", ptxt)
+    pm = np.array([[int(x) for x in r] for r in rows], np.int64)
+    assert pm.shape == (67, 5), pm.shape
+    assert int(pm[-1, 0] + pm[-1, 1]) == 1176036, "PCM_LENGTH mismatch"
+    out["pcm_map"] = pm
     out["names"] = np.array(json.dumps(names))
     out["meta"] = np.array(json.dumps(meta))
     path = os.path.join(HERE, "notamy_luts.npz")

@@ -94,6 +94,7 @@ def main():
     import torch.distributed as dist
 
     from skred_amd import banks, device
+    from skred_amd.sharded import ShardedRender
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
@@ -108,7 +109,8 @@ def main():
         total = a.voices
     if a.scaling == "weak":
         total *= world
-    lo, hi = total * rank // world, total * (rank + 1) // world
+    sh = ShardedRender(total, rank, world)
+    lo, hi = sh.lo, sh.hi
     F = a.frames
 
     full, tables, g = banks.RECIPES[recipe](total)
@@ -123,12 +125,14 @@ def main():
     out = torch.zeros(F, 2, device=dev, dtype=torch.float32)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        db.render(F, partial.data_ptr(), 0, interp, stream)
-        if world > 1:
-            dist.reduce(partial, dst=0, op=dist.ReduceOp.SUM)     # RCCL over xGMI: 8*F bytes
-        if rank == 0:
-            db.master(partial.data_ptr(), F, out.data_ptr(), 2, stream)
+    def render_partial(p):
+        db.render(F, p.data_ptr(), 0, interp, stream)
+
+    def master(p, o):
+        db.master(p.data_ptr(), F, o.data_ptr(), 2, stream)
+
+    def step():   # render -> (RCCL reduce of 8*F bytes over xGMI when world > 1) -> master on rank 0
+        sh.step(render_partial, master, partial, out)
 
     def fence():
         torch.cuda.synchronize()

@@ -203,6 +203,14 @@ int  skred_bank_master(skred_bank_t *bank, const float *d_sum, int num_frames,
 int  skred_bank_render_host(skred_bank_t *bank, float *buffer, int num_frames,
                             int num_channels, int interp, float *stems_or_null);
 
+/* Options.  Two kernels implement the render loop: a generic one (every synth() feature the path
+ * supports) and a specialised one chosen automatically for "clean" banks; their per-voice results are
+ * bit-identical.  FORCE_GENERIC pins the generic kernel (used by the parity tests to cross-check). */
+enum { SKRED_OPT_FORCE_GENERIC = 1 };
+enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1 };
+int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
+int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */
+
 /* Timing of the most recent skred_bank_render() on its stream, via hipEvents
  * recorded around the render kernel itself (ms; <0 if unavailable). Synchronises. */
 float skred_bank_last_render_ms(skred_bank_t *bank);

@@ -20,7 +20,8 @@
 
 /* launchers in skred_kernels.hip */
 int sk_launch_render(const sk_render_args_t *args, int n_workgroups, hipStream_t stream);
-int sk_launch_reduce(const float *partial, float *out, int W, int ncols, hipStream_t stream);
+int sk_launch_reduce(const float *partial, float *tmp, float *out, int W, int ncols, hipStream_t stream);
+int sk_reduce_tmp_floats(int ncols);
 int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels,
                      float target, float k, float *gain_state, hipStream_t stream);
 
@@ -37,13 +38,26 @@ struct skred_bank {
   float *d_partial;           /* [n_wg][F][2]         */
   size_t partial_cap;         /* floats               */
   float *d_gain_state;        /* master smoother gain */
+  float *d_redtmp;            /* second-stage scratch of the partial-mix reduction */
+  size_t redtmp_cap;
   float *d_sum, *d_out, *d_stems; /* scratch of skred_bank_render_host */
   size_t sum_cap, out_cap, stems_cap;
+  uint8_t *h_class;           /* per-voice SKC_* bits, shadow used to pick the kernel */
+  int class_dirty;
+  uint32_t fast_mode;         /* SKM_* from classify() */
+  int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
+  int last_kernel;            /* SKRED_KERNEL_* used by the most recent render */
   skred_globals_t g;
   uint32_t features;
   hipEvent_t ev0[SK_TIMING_RING], ev1[SK_TIMING_RING]; /* around the render kernel of each call */
   int n_timed;                /* render calls since the last timing reset */
 };
+
+/* per-voice classification (host shadow) */
+#define SKC_REAL   1u   /* a voice was uploaded into this slot and it can sound (has a table) */
+#define SKC_FILTER 2u
+#define SKC_ENV    4u
+#define SKC_EXOTIC 8u   /* needs the generic kernel: see classify() */
 
 static __thread char g_err[512];
 
@@ -107,10 +121,18 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   /* every slot starts inert (skipped by the kernel) until a voice is uploaded into it */
   sk_plane_t *inert = (sk_plane_t *)calloc((size_t)b->n_padded, sizeof(sk_plane_t));
   if (!inert) return fail(SKRED_E_NO_MEM, "calloc");
-  for (int v = 0; v < b->n_padded; v++) inert[v].w[2] = SKF_INERT;
+  for (int v = 0; v < b->n_padded; v++) { inert[v].w[1] = 1; inert[v].w[2] = SKF_INERT; }   /* table_size 1: fetch stays in bounds */
   hipError_t e = hipMemcpy(b->d_ro[SKP_TAB], inert, plane_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const float one = 1.0f;                          /* loop window [0,1): phase 0 + inc 0 stays in range */
+    for (int v = 0; v < b->n_padded; v++) { memset(&inert[v], 0, sizeof(inert[v])); memcpy(&inert[v].w[2], &one, 4); }
+    e = hipMemcpy(b->d_ro[SKP_OSC], inert, plane_bytes, hipMemcpyHostToDevice);
+  }
   free(inert);
   HIP_TRY(e);
+  b->h_class = (uint8_t *)calloc((size_t)b->n_padded, 1);
+  if (!b->h_class) return fail(SKRED_E_NO_MEM, "calloc");
+  b->class_dirty = 1;
   HIP_TRY(hipMalloc((void **)&b->d_gain_state, 4 * sizeof(float)));
   HIP_TRY(hipMemset(b->d_gain_state, 0, 4 * sizeof(float)));
   for (int i = 0; i < SK_TIMING_RING; i++) {
@@ -138,6 +160,8 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_sum) hipFree(b->d_sum);
   if (b->d_out) hipFree(b->d_out);
   if (b->d_stems) hipFree(b->d_stems);
+  if (b->d_redtmp) hipFree(b->d_redtmp);
+  free(b->h_class);
   for (int i = 0; i < SK_TIMING_RING; i++) {
     if (b->ev0[i]) hipEventDestroy(b->ev0[i]);
     if (b->ev1[i]) hipEventDestroy(b->ev1[i]);
@@ -214,13 +238,25 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
     if (hold < 0) hold = 0;
     if (hold > 0xFFFFFF) hold = 0xFFFFFF;
     if (quant || hold) features |= SKB_ANY_HOLDQ;
+    {
+      uint8_t c = 0;
+      if (usable || noise) c |= SKC_REAL;
+      if (h->voice_filter_mode[v]) c |= SKC_FILTER;
+      if (h->voice_use_amp_envelope[v]) c |= SKC_ENV;
+      const int stops = h->voice_one_shot[v] && !h->voice_loop_enabled[v];
+      const float ph = h->voice_phase[v], pi = h->voice_phase_inc[v];
+      const int finite = (ph - ph == 0.0f) && (pi - pi == 0.0f) && (lo - lo == 0.0f) && (hi - hi == 0.0f) && hi > lo;
+      if (stops || noise || has_mod || quant || hold || h->voice_direction[v] || !h->voice_smoother_enable[v] || !finite)
+        c |= SKC_EXOTIC;
+      b->h_class[dst_first + i] = c;
+    }
     const skred_envelope_t *e = &h->voice_amp_envelope[v];
     const skred_mmf_t *f = &h->voice_filter[v];
 
-    RO(SKP_OSC).w[0] = f2u(h->voice_phase_inc[v]); RO(SKP_OSC).w[1] = f2u(lo);
-    RO(SKP_OSC).w[2] = f2u(hi);                    RO(SKP_OSC).w[3] = f2u(h->voice_amp[v]);
+    RO(SKP_OSC).w[0] = f2u(h->voice_phase_inc[v]); RO(SKP_OSC).w[1] = f2u(usable ? lo : 0.0f);
+    RO(SKP_OSC).w[2] = f2u(usable ? hi : 1.0f);    RO(SKP_OSC).w[3] = f2u(h->voice_amp[v]);
     RO(SKP_TAB).w[0] = (uint32_t)(int32_t)(usable && !noise ? off : 0);
-    RO(SKP_TAB).w[1] = (uint32_t)size; RO(SKP_TAB).w[2] = flags;
+    RO(SKP_TAB).w[1] = (uint32_t)(usable && !noise ? size : 1); RO(SKP_TAB).w[2] = flags;
     RO(SKP_TAB).w[3] = (uint32_t)quant | ((uint32_t)hold << 8);
     RO(SKP_ENV_T).w[0] = f2u(e->attack_time);   RO(SKP_ENV_T).w[1] = f2u(e->decay_time);
     RO(SKP_ENV_T).w[2] = f2u(e->sustain_level); RO(SKP_ENV_T).w[3] = f2u(e->release_time);
@@ -257,8 +293,44 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
   free(st);
   HIP_TRY(e);
   b->features = features;
+  b->class_dirty = 1;
   return SKRED_OK;
 }
+
+/* Pick the kernel.  The fast kernel (skred_kernels.hip: sk_render_fast_kernel) is valid when, over
+ * all voices that can sound: none is "exotic" (stopping one-shot, reverse, sample&hold, bit-crush,
+ * noise, modulated, smoother off, non-finite phase data), and the biquad / the envelope are each used
+ * by all of them or by none.  Anything else runs the generic kernel; both give identical samples. */
+static void classify(skred_bank_t *b) {
+  if (!b->class_dirty) return;
+  int real = 0, filt = 0, env = 0, exotic = 0;
+  for (int v = 0; v < b->n_voices; v++) {
+    const uint8_t c = b->h_class[v];
+    if (!(c & SKC_REAL)) continue;
+    real++;
+    if (c & SKC_FILTER) filt++;
+    if (c & SKC_ENV) env++;
+    if (c & SKC_EXOTIC) exotic++;
+  }
+  uint32_t m = 0;
+  if (real > 0 && !exotic && (filt == 0 || filt == real) && (env == 0 || env == real)) {
+    m = SKM_FAST;
+    if (filt) m |= SKM_FILTER_ALL;
+    if (env) m |= SKM_ENV_ALL;
+  }
+  b->fast_mode = m;
+  b->class_dirty = 0;
+}
+
+int skred_bank_set_option(skred_bank_t *b, int option, int value) {
+  if (!b) return fail(SKRED_E_BAD_ARG, "set_option");
+  switch (option) {
+    case SKRED_OPT_FORCE_GENERIC: b->force_generic = value != 0; return SKRED_OK;
+    default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
+  }
+}
+
+int skred_bank_last_kernel(const skred_bank_t *b) { return b ? b->last_kernel : -1; }
 
 int skred_bank_download(skred_bank_t *b, skred_voice_bank_t *h, int src_first, int dst_first, int count) {
   if (!b || !h || count < 0) return fail(SKRED_E_BAD_ARG, "download: bad arguments");
@@ -343,6 +415,10 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
   a.lds_table_floats = b->table_floats_padded <= SK_LDS_TABLE_MAX_FLOATS ? (int32_t)b->table_floats_padded : 0;
   a.interp = interp;
   a.features = b->features;
+  classify(b);
+  a.fast_mode = (b->force_generic || d_stems) ? 0u : b->fast_mode;
+  b->last_kernel = (a.fast_mode & SKM_FAST) ? SKRED_KERNEL_FAST : SKRED_KERNEL_GENERIC;
+  if ((rc = grow(&b->d_redtmp, &b->redtmp_cap, (size_t)sk_reduce_tmp_floats(2 * num_frames)))) return rc;
 
   const int slot = b->n_timed % SK_TIMING_RING;
   HIP_TRY(hipEventRecord(b->ev0[slot], s));
@@ -350,7 +426,7 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "render launch -> %s", hipGetErrorString(e));
   HIP_TRY(hipEventRecord(b->ev1[slot], s));
   b->n_timed++;
-  e = (hipError_t)sk_launch_reduce(b->d_partial, d_partial, n_wg, 2 * num_frames, s);
+  e = (hipError_t)sk_launch_reduce(b->d_partial, b->d_redtmp, d_partial, n_wg, 2 * num_frames, s);
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "reduce launch -> %s", hipGetErrorString(e));
 
   /* advance the timeline exactly as synth.c:521,525 do: one count and one LCG draw per frame */

@@ -65,6 +65,11 @@ enum {
 #define SKB_ANY_HOLDQ  (1u << 3)   /* sample&hold or bit-crush somewhere */
 #define SKB_ANY_MOD    (1u << 4)
 
+/* fast_mode word (host -> launcher) */
+#define SKM_FAST        (1u << 0)  /* bank qualifies for sk_render_fast_kernel (see skred_bank.c:classify) */
+#define SKM_FILTER_ALL  (1u << 1)  /* every live voice runs the biquad (else: none does) */
+#define SKM_ENV_ALL     (1u << 2)  /* every live voice uses the amp envelope (else: none does) */
+
 #define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */
 #define SK_CHUNK 64                /* frames between two workgroup-level mix flushes */
 #define SK_LDS_TABLE_MAX_FLOATS 12288  /* 48 KiB: pools up to this size are staged in LDS */
@@ -90,6 +95,7 @@ typedef struct {
   int32_t lds_table_floats;/* floats staged in LDS (0 or == table_floats) */
   int32_t interp;
   uint32_t features;       /* SKB_* */
+  uint32_t fast_mode;      /* SKM_* : which specialised kernel the host picked */
 } sk_render_args_t;
 
 #endif

@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "skred_bank_set_globals", "skred_bank_get_globals",
     "skred_bank_render", "skred_bank_master", "skred_bank_render_host",
     "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
+    "skred_bank_set_option", "skred_bank_last_kernel",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -60,6 +61,8 @@ def load() -> C.CDLL:
     L.skred_bank_render_host.argtypes = [vp, vp, i32, i32, i32, vp]
     L.skred_bank_last_render_ms.argtypes = [vp]
     L.skred_bank_last_render_ms.restype = C.c_float
+    L.skred_bank_set_option.argtypes = [vp, i32, i32]
+    L.skred_bank_last_kernel.argtypes = [vp]
     L.skred_bank_timing_reset.argtypes = [vp]
     L.skred_bank_timing_reset.restype = None
     L.skred_bank_timing_summary.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]
@@ -132,6 +135,13 @@ class DeviceBank:
         _check(self.L.skred_bank_render_host(self.h, buf.ctypes.data, frames, channels, interp,
                                              stems.ctypes.data if want_stems else None), "skred_bank_render_host")
         return buf, stems
+
+    def force_generic(self, on: bool = True):
+        _check(self.L.skred_bank_set_option(self.h, 1, int(on)), "skred_bank_set_option")
+
+    def last_kernel(self) -> int:
+        """0 = generic kernel, 1 = specialised fast kernel (SKRED_KERNEL_*)."""
+        return int(self.L.skred_bank_last_kernel(self.h))
 
     def last_render_ms(self) -> float:
         return float(self.L.skred_bank_last_render_ms(self.h))

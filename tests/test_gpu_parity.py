@@ -181,3 +181,101 @@ def test_empty_and_bad_arguments(dev):
     with pytest.raises(dev.SkredAmdError):
         db.upload(b)
     db.close()
+
+
+# ---------------------------------------------------------------- the specialised ("fast") kernel
+
+def _run_scenario(dev, bank, tables, g, interp, segments, force_generic):
+    """Render `segments` = [(frames, event)] where event(bank_host, now) mutates the host bank
+    between launches (host arrays are the source of truth: download -> edit -> upload)."""
+    db = dev.DeviceBank(bank.n)
+    db.set_tables(tables)
+    host = bank.copy()
+    db.upload(host)
+    db.set_globals(g)
+    db.force_generic(force_generic)
+    mixes, kernels = [], []
+    for frames, event in segments:
+        if event is not None:
+            db.download(host)
+            event(host, db.get_globals().synth_sample_count)
+            db.upload(host)
+        m, _ = db.render_host(frames, 2, interp)
+        mixes.append(m)
+        kernels.append(db.last_kernel())
+    db.download(host)
+    db.close()
+    return np.concatenate(mixes), host, kernels
+
+
+def _oracle_scenario(bank, tables, g, interp, segments):
+    host, gl = bank.copy(), g.copy()
+    mixes = []
+    for frames, event in segments:
+        if event is not None:
+            event(host, gl.synth_sample_count)
+        r = cpuref.render(host, gl, tables, frames, interp)
+        mixes.append(cpuref.master(gl, r["sum64"].astype(np.float32)))
+    return np.concatenate(mixes), host
+
+
+def _release_odd_voices(host, now):
+    e = host["voice_amp_envelope"]
+    e["sample_release"][1::2] = now          # == amp_envelope_release, synth.c:391-395
+
+
+@pytest.mark.parametrize("recipe,interp", [("c1", 0), ("c2", 0), ("c2", 1), ("c4", 0), ("c4", 1)])
+def test_fast_kernel_bit_identical_to_generic_and_oracle(dev, recipe, interp):
+    """Attack/decay in flight -> note-off on half the voices -> release runs out (is_active -> 0) ->
+    smoother tail; ragged voice count, frame counts that are not multiples of the 64-frame chunk."""
+    n = 5000
+    bank, tables, g = banks.RECIPES[recipe](n)
+    bank["voice_disconnect"][::7] = 1            # muted voices stay on the fast path
+    bank["voice_amp"][::11] = 0.0                # skipped voices too (state frozen, sample = 0)
+    segs = [(301, None), (333, _release_odd_voices), (12001, None), (64, None)]
+    fast_mix, fast_state, k_fast = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False)
+    gen_mix, gen_state, k_gen = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=True)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert k_fast == [1] * len(segs), "the specialised kernel did not run"
+    assert k_gen == [0] * len(segs)
+    assert not fast_state.rw_equal(ref_state), fast_state.rw_equal(ref_state)
+    assert not gen_state.rw_equal(ref_state), gen_state.rw_equal(ref_state)
+    assert gio.bits_equal(fast_mix, gen_mix), "same per-voice samples + same reduction tree => same bytes"
+    assert rel_rms(fast_mix, ref_mix) <= 1e-5
+
+
+def test_fast_kernel_envelope_clock_beyond_2p24(dev):
+    """Notes held for more than 2^24 frames (5.8 min at 48 kHz): (float)(uint64) stops being an
+    exact +1 ramp; the kernel must fall back to the integer clock.  Crosses 2^24 inside a launch."""
+    n = 1024
+    bank, tables, g = banks.bank_c2(n)
+    e = bank["voice_amp_envelope"]
+    e["sample_start"] = np.arange(n, dtype=np.uint64) * 3
+    g.synth_sample_count = (1 << 24) - 200
+    segs = [(512, None), (300, _release_odd_voices), (700, None)]
+    fast_mix, fast_state, k = _run_scenario(dev, bank, tables, g, 0, segs, force_generic=False)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, 0, segs)
+    assert k == [1, 1, 1]
+    assert not fast_state.rw_equal(ref_state), fast_state.rw_equal(ref_state)
+    assert rel_rms(fast_mix, ref_mix) <= 1e-5
+
+
+def test_fast_kernel_big_increments(dev):
+    """Phase increments beyond one loop length (general fmodf wrap, synth.c:247) on the fast path."""
+    n = 2048
+    bank, tables, g = banks.bank_c2(n)
+    size = bank["voice_table_size"].astype(np.float32)
+    bank["voice_phase_inc"][::3] = size[::3] * np.float32(2.37)
+    bank["voice_phase_inc"][1::3] = size[1::3] * np.float32(0.999)
+    fast_mix, fast_state, k = _run_scenario(dev, bank, tables, g, 0, [(700, None)], force_generic=False)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, 0, [(700, None)])
+    assert k == [1]
+    assert not fast_state.rw_equal(ref_state), fast_state.rw_equal(ref_state)
+    assert rel_rms(fast_mix, ref_mix) <= 1e-5
+
+
+def test_exotic_voice_forces_generic_kernel(dev):
+    bank, tables, g = banks.bank_c2(512)
+    bank["voice_sample_hold_max"][5] = 3
+    _, _, k = _run_scenario(dev, bank, tables, g, 0, [(64, None)], force_generic=False)
+    assert k == [0]

@@ -78,8 +78,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=512, help="frames per launch (reference callback size, skred.h:12)")
     ap.add_argument("--voices", type=int, default=0, help="override the total voice count")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
-                    help="strong: the bank is split over the GPUs; weak: every GPU gets a whole bank")
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
+                    help="weak (default): every GPU gets a whole bank of the workload size; strong: one bank is split over the GPUs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     a = ap.parse_args()
 

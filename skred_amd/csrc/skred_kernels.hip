@@ -462,22 +462,32 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
   out_r = s * r.pan_r;
 }
 
+// (timing experiments only: -DSK_ABLATE_REDUCE drops the cross-lane sum; outputs are then wrong)
+#ifdef SK_ABLATE_REDUCE
+#define SK_REDUCE_AND_STORE(J) asm volatile("" ::"v"(l), "v"(rr));
+#else
+#define SK_REDUCE_AND_STORE(J)       \
+  wave_sum2_to_lane63(l, rr);        \
+  if (lane == 63) wsum[wave * SK_CHUNK + (J)] = make_float2(l, rr);
+#endif
 // one frame of the chunk loop: STEADY_ selects the envelope mode, A/B the delay-line roles
 #define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO)                                                        \
   {                                                                                                      \
     float l, rr;                                                                                         \
     fast_frame<TAB_LDS, FILTER, ENV, STEADY_, INTERP>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
-    wave_sum2_to_lane63(l, rr);                                                                        \
-    if (lane == 63) wsum[wave * SK_CHUNK + (J)] = make_float2(l, rr);                                    \
+    SK_REDUCE_AND_STORE(J)                                                                               \
   }
 #define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2)
 #define SK_FAST_ODD(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1)
 #define SK_FAST_FIX_ODD_TAIL()                                                     \
   { float t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }
 
+#ifndef SK_FAST_MIN_WAVES
+#define SK_FAST_MIN_WAVES 1      /* waves per SIMD the register allocator must leave room for */
+#endif
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
-__global__ __launch_bounds__(SK_GROUP) void sk_render_fast_kernel(const sk_render_args_t a) {
+__global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
   const char *lds_tab = reinterpret_cast<const char *>(lds);

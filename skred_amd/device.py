@@ -14,7 +14,7 @@ import numpy as np
 from .bank import GlobalsC, VoiceBank, VoiceBankC
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libskred_amd.so")
+LIB_PATH = os.environ.get("SKRED_AMD_LIB", os.path.join(_HERE, "libskred_amd.so"))   # override: A/B builds
 
 # every symbol include/skred_amd.h declares
 ABI_SYMBOLS = [

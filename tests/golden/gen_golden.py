@@ -44,11 +44,15 @@ LCG_A, LCG_C, M64 = 6364136223846793005, 1442695040888963407, (1 << 64) - 1
 
 
 class Ref:
-    """The reference process image, driven through ctypes."""
+    """A skred process image driven through ctypes: by default the reference itself
+    (oracle/_ref/libskred_ref.so); tests/test_dropin.py passes oracle/_ref/libskred_dropin_check.so,
+    i.e. the reference's wire/seq/skred objects linked against OUR libskred_synth.so instead of synth.o."""
 
-    def __init__(self):
-        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
-        self.L = C.CDLL(REF_SO)
+    def __init__(self, lib_path=None):
+        if lib_path is None:
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
+            lib_path = REF_SO
+        self.L = C.CDLL(lib_path)
         self.L.ref_boot()
         self.L.ref_stems.restype = C.POINTER(C.c_float)
         self.L.ref_ext_table.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int,
@@ -185,6 +189,8 @@ class Case:
         self.k += 1
 
     def save(self):
+        if self.name == "c0_0sk":
+            assert self.meta["segments"][0]["mix_fnv1a32"] == "4160cd81", self.meta["segments"][0]
         self.out["meta"] = np.array(json.dumps(self.meta))
         path = os.path.join(HERE, self.name + ".npz")
         np.savez_compressed(path, **self.out)
@@ -208,21 +214,26 @@ def lcg_uniform(n, seed):
 
 # ---------------------------------------------------------------- the cases
 
-def case_c0_0sk():
+# the three lines of the reference patch 0.sk (BASELINE config 0), fed through wire() so that the
+# case can also be replayed where the reference tree is absent (GPU box)
+PATCH_0SK = ["S100", "v0 w0 f440 a4 F1,10", "v1 w0 f1 a50 m1"]
+
+
+def case_c0_0sk(ref, Case):
     """BASELINE config 0: 0.sk, 1 s, 512-frame callbacks.  Anchor from SURVEY §8c: FNV-1a 4160cd81."""
-    ref = Ref()
-    ref.load_patch(0)
+    if os.path.isdir(REF_DIR):
+        assert [l.rstrip("\n") for l in open(os.path.join(REF_DIR, "0.sk"))] == PATCH_0SK
+    for line in PATCH_0SK:
+        ref.wire(line)
     c = Case("c0_0sk", "reference patch 0.sk (sine carrier v0, FM by muted v1 > v0: one-frame-delay "
                         "modulator semantics), 44100 frames in 512-frame callbacks")
     c.segment(ref, 44100, 512, keep_stems=(0, 1))
-    assert c.meta["segments"][0]["mix_fnv1a32"] == "4160cd81", c.meta["segments"][0]
     c.save()
 
 
-def case_c1_sine_adsr():
+def case_c1_sine_adsr(ref, Case):
     """BASELINE config 1 shape at N=64: sine + ADSR (+ default amp smoother), note-off mid-way,
     then long enough for the envelope to end and the smoother to decay through the subnormals."""
-    ref = Ref()
     u = (lcg_uniform(192, 0x5EED) + 1.0) * 0.5
     for v in range(64):
         f = 27.5 * 2.0 ** (7.0 * float(u[v]))
@@ -241,9 +252,8 @@ def case_c1_sine_adsr():
     c.save()
 
 
-def case_c2_mixed_filter():
+def case_c2_mixed_filter(ref, Case):
     """BASELINE config 2 shape at N=64: mixed tables + biquad modes 1..5."""
-    ref = Ref()
     u = (lcg_uniform(256, 0xC2) + 1.0) * 0.5
     waves = [0, 4, 1, 2, 3]
     for v in range(64):
@@ -258,10 +268,9 @@ def case_c2_mixed_filter():
     c.save()
 
 
-def case_c2_notamy():
+def case_c2_notamy(ref, Case):
     """Config 2/3 tables: the notamy float LUT pyramids installed into EXT slots (the reference
     itself never loads them: SURVEY D3), voices spread over all pyramid levels, filter on."""
-    ref = Ref()
     luts = np.load(os.path.join(HERE, "notamy_luts.npz"))
     names = json.loads(str(luts["names"]))
     slot = 200
@@ -288,10 +297,9 @@ PCM_GEOM = [(707, 342, 684, 89), (8186, 4282, 7439, 39), (2766, 1377, 2744, 45),
             (1311, 898, 1288, 52), (2276, 1164, 2254, 51)]
 
 
-def case_c4_pcm():
+def case_c4_pcm(ref, Case):
     """BASELINE config 5 shape, truncate mode: one-shot PCM-like tables (synthetic, seeded) with the
     real pcm_map geometry: forward, reverse, looped, finishing mid-block."""
-    ref = Ref()
     for i, (n, ls, le, note) in enumerate(PCM_GEOM):
         data = lcg_uniform(n, 0x9C3 + i)
         data = np.convolve(data, np.ones(5, np.float32) / 5.0, mode="same").astype(np.float32)
@@ -326,9 +334,8 @@ def case_c4_pcm():
     c.save()
 
 
-def case_edge_basic():
+def case_edge_basic(ref, Case):
     """Edge cases without cross-voice modulation."""
-    ref = Ref()
     ref.wire("v0 w0 f440 a0")                              # amp == 0: skipped, state frozen
     ref.wire("v1 w0 f330 a1 h7")                           # sample & hold
     ref.wire("v2 w4 f220 a1 q4")                           # bit crush
@@ -356,9 +363,8 @@ def case_edge_basic():
     c.save()
 
 
-def case_edge_mod():
+def case_edge_mod(ref, Case):
     """Cross-voice modulation (FM/AM/pan/CZ) and phase distortion: SURVEY §8f rank 2."""
-    ref = Ref()
     ref.wire("v0 w0 f440 a1 F1,5")          # FM, modulator index > carrier (previous frame's value)
     ref.wire("v1 w0 f3 a20 m1")
     ref.wire("v2 w0 f2 a10 m1")             # FM, modulator index < carrier (this frame's value)
@@ -400,7 +406,7 @@ def main():
         print("\n".join(CASES))
         return
     if a.case:
-        CASES[a.case]()
+        CASES[a.case](Ref(), Case)
         return
     for name in CASES:   # fresh process per case: synth() has function-static state
         subprocess.run([sys.executable, os.path.abspath(__file__), "--case", name], check=True)

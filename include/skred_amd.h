@@ -207,7 +207,7 @@ int  skred_bank_render_host(skred_bank_t *bank, float *buffer, int num_frames,
  * supports) and a specialised one chosen automatically for "clean" banks; their per-voice results are
  * bit-identical.  FORCE_GENERIC pins the generic kernel (used by the parity tests to cross-check). */
 enum { SKRED_OPT_FORCE_GENERIC = 1 };
-enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1 };
+enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */
 

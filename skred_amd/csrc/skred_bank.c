@@ -22,6 +22,7 @@
 int sk_launch_render(const sk_render_args_t *args, int n_workgroups, hipStream_t stream);
 int sk_launch_reduce(const float *partial, float *tmp, float *out, int W, int ncols, hipStream_t stream);
 int sk_reduce_tmp_floats(int ncols);
+int sk_launch_render_mod(const sk_render_args_t *args, int n_groups64, const int *levels, int max_level, hipStream_t stream);
 int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels,
                      float target, float k, float *gain_state, hipStream_t stream);
 
@@ -43,6 +44,11 @@ struct skred_bank {
   float *d_sum, *d_out, *d_stems; /* scratch of skred_bank_render_host */
   size_t sum_cap, out_cap, stems_cap;
   uint8_t *h_class;           /* per-voice SKC_* bits, shadow used to pick the kernel */
+  int8_t *h_mod;              /* [4][n_padded] modulator lane inside the 64-voice group (fm, am, pm, cz) or -1 */
+  int *h_level;               /* [n_padded] dependency level of each voice (modulated banks) */
+  int *d_level;
+  int max_level;
+  int mod_escapes;            /* some modulator lies outside its carrier's 64-voice group */
   int class_dirty;
   uint32_t fast_mode;         /* SKM_* from classify() */
   int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
@@ -131,7 +137,12 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   free(inert);
   HIP_TRY(e);
   b->h_class = (uint8_t *)calloc((size_t)b->n_padded, 1);
-  if (!b->h_class) return fail(SKRED_E_NO_MEM, "calloc");
+  b->h_mod = (int8_t *)malloc((size_t)b->n_padded * 4);
+  b->h_level = (int *)calloc((size_t)b->n_padded, sizeof(int));
+  if (!b->h_class || !b->h_mod || !b->h_level) return fail(SKRED_E_NO_MEM, "calloc");
+  memset(b->h_mod, -1, (size_t)b->n_padded * 4);
+  HIP_TRY(hipMalloc((void **)&b->d_level, (size_t)b->n_padded * sizeof(int)));
+  HIP_TRY(hipMemset(b->d_level, 0, (size_t)b->n_padded * sizeof(int)));
   b->class_dirty = 1;
   HIP_TRY(hipMalloc((void **)&b->d_gain_state, 4 * sizeof(float)));
   HIP_TRY(hipMemset(b->d_gain_state, 0, 4 * sizeof(float)));
@@ -161,7 +172,8 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_out) hipFree(b->d_out);
   if (b->d_stems) hipFree(b->d_stems);
   if (b->d_redtmp) hipFree(b->d_redtmp);
-  free(b->h_class);
+  free(b->h_class); free(b->h_mod); free(b->h_level);
+  if (b->d_level) hipFree(b->d_level);
   for (int i = 0; i < SK_TIMING_RING; i++) {
     if (b->ev0[i]) hipEventDestroy(b->ev0[i]);
     if (b->ev1[i]) hipEventDestroy(b->ev1[i]);
@@ -201,6 +213,7 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
   sk_plane_t *st = (sk_plane_t *)calloc((size_t)NP * (size_t)count, sizeof(sk_plane_t));
   if (!st) return fail(SKRED_E_NO_MEM, "upload staging");
   uint32_t features = (dst_first == 0 && count == b->n_voices) ? 0u : b->features;
+  if (dst_first == 0 && count == b->n_voices) b->mod_escapes = 0;
   for (int i = 0; i < count; i++) {
     const int v = src_first + i;
     sk_plane_t *ro = st, *rw = st + (size_t)SKP_COUNT * count;
@@ -268,8 +281,24 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
     RO(SKP_GAIN).w[2] = f2u(f->b0);       RO(SKP_GAIN).w[3] = f2u(f->b1);
     RO(SKP_FILT).w[0] = f2u(f->b2); RO(SKP_FILT).w[1] = f2u(f->a1);
     RO(SKP_FILT).w[2] = f2u(f->a2); RO(SKP_FILT).w[3] = f2u(h->voice_cz_distortion[v]);
-    RO(SKP_MODI).w[0] = (uint32_t)h->voice_freq_mod_osc[v]; RO(SKP_MODI).w[1] = (uint32_t)h->voice_amp_mod_osc[v];
-    RO(SKP_MODI).w[2] = (uint32_t)h->voice_pan_mod_osc[v];  RO(SKP_MODI).w[3] = (uint32_t)h->voice_cz_mod_osc[v];
+    {
+      /* modulator indices: host index -> lane inside the carrier's 64-voice device group, -1 = unused
+       * (FM ignores a self reference, synth.c:549; the CZ source only matters with CZ on, synth.c:262) */
+      const int dst = dst_first + i;
+      int src[4] = { h->voice_freq_mod_osc[v], h->voice_amp_mod_osc[v], h->voice_pan_mod_osc[v],
+                     h->voice_cz_mode[v] ? h->voice_cz_mod_osc[v] : -1 };
+      if (src[0] == v) src[0] = -1;
+      for (int k = 0; k < 4; k++) {
+        int lane_k = -1;
+        if (src[k] >= 0) {
+          const int md = src[k] - src_first + dst_first;
+          if (md < 0 || md >= b->n_voices || (md >> 6) != (dst >> 6)) b->mod_escapes = 1;
+          else lane_k = md & 63;
+        }
+        b->h_mod[(size_t)k * b->n_padded + dst] = (int8_t)lane_k;
+        RO(SKP_MODI).w[k] = (uint32_t)(int32_t)lane_k;
+      }
+    }
     RO(SKP_MODF).w[0] = f2u(h->voice_freq_mod_depth[v]); RO(SKP_MODF).w[1] = f2u(h->voice_freq_scale[v]);
     RO(SKP_MODF).w[2] = f2u(h->voice_amp_mod_depth[v]);  RO(SKP_MODF).w[3] = f2u(h->voice_pan_mod_depth[v]);
     RO(SKP_MODX).w[0] = f2u(h->voice_cz_mod_depth[v]); RO(SKP_MODX).w[1] = (uint32_t)h->voice_cz_mode[v];
@@ -320,6 +349,22 @@ static void classify(skred_bank_t *b) {
   }
   b->fast_mode = m;
   b->class_dirty = 0;
+  /* dependency levels for modulated banks (skred_kernels.hip: sk_render_mod_kernel) */
+  b->max_level = 0;
+  if (b->features & SKB_ANY_MOD) {
+    for (int g0 = 0; g0 < b->n_padded; g0 += 64) {
+      for (int l = 0; l < 64; l++) {
+        int lvl = 0;
+        for (int k = 0; k < 4; k++) {
+          const int src = b->h_mod[(size_t)k * b->n_padded + g0 + l];
+          if (src >= 0 && src < l && b->h_level[g0 + src] + 1 > lvl) lvl = b->h_level[g0 + src] + 1;
+        }
+        b->h_level[g0 + l] = lvl;
+        if (lvl > b->max_level) b->max_level = lvl;
+      }
+    }
+    hipMemcpy(b->d_level, b->h_level, (size_t)b->n_padded * sizeof(int), hipMemcpyHostToDevice);
+  }
 }
 
 int skred_bank_set_option(skred_bank_t *b, int option, int value) {
@@ -391,11 +436,13 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
   if (!b || !d_partial || num_frames <= 0) return fail(SKRED_E_BAD_ARG, "render: bad arguments");
   if (interp != SKRED_INTERP_TRUNCATE && interp != SKRED_INTERP_LINEAR) return fail(SKRED_E_BAD_ARG, "render: interp %d", interp);
   if (!b->d_tables) return fail(SKRED_E_BAD_ARG, "render: no table pool set");
-  if (b->features & SKB_ANY_MOD)
-    return fail(SKRED_E_UNSUPPORTED, "bank uses cross-voice modulation / CZ phase distortion: not in this kernel yet");
+  if ((b->features & SKB_ANY_MOD) && b->mod_escapes)
+    return fail(SKRED_E_UNSUPPORTED, "a voice is modulated by a voice outside its aligned 64-voice group: "
+                                     "keep modulator and carrier in the same group (SURVEY 8e)");
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
-  const int n_wg = b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS;
+  const int modulated = (b->features & SKB_ANY_MOD) != 0;
+  const int n_wg = modulated ? b->n_padded / 64 : (b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS);
   int rc = grow(&b->d_partial, &b->partial_cap, (size_t)n_wg * (size_t)num_frames * 2);
   if (rc) return rc;
 
@@ -422,7 +469,13 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
 
   const int slot = b->n_timed % SK_TIMING_RING;
   HIP_TRY(hipEventRecord(b->ev0[slot], s));
-  hipError_t e = (hipError_t)sk_launch_render(&a, n_wg, s);
+  hipError_t e;
+  if (modulated) {
+    b->last_kernel = SKRED_KERNEL_MODULATED;
+    e = (hipError_t)sk_launch_render_mod(&a, n_wg, b->d_level, b->max_level, s);
+  } else {
+    e = (hipError_t)sk_launch_render(&a, n_wg, s);
+  }
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "render launch -> %s", hipGetErrorString(e));
   HIP_TRY(hipEventRecord(b->ev1[slot], s));
   b->n_timed++;

@@ -36,7 +36,7 @@ def dev():
     return device
 
 
-@pytest.mark.parametrize("case", gio.MOD_FREE_CASES)
+@pytest.mark.parametrize("case", gio.CASES)
 def test_golden_case(dev, case):
     """The reference's own output, segment by segment, callback by callback."""
     g = gio.load(case)
@@ -157,15 +157,50 @@ def test_determinism(dev):
     assert gio.bits_equal(res[0], res[1])
 
 
-def test_unsupported_modulation_fails_loudly(dev):
-    g = gio.load("edge_mod")
-    seg = g.segments[0]
-    db = dev.DeviceBank(seg.bank_in.n)
-    db.set_tables(g.tables)
-    db.upload(seg.bank_in)
+def test_modulator_outside_its_group_fails_loudly(dev):
+    """Modulator and carrier must share an aligned 64-voice group (one wavefront exchanges
+    voice_sample through LDS); anything else is refused, never rendered approximately."""
+    bank, tables, g = banks.bank_c2(256)
+    bank["voice_freq_mod_osc"][70] = 3          # carrier in group 1, modulator in group 0
+    bank["voice_freq_mod_depth"][70] = 2.0
+    db = dev.DeviceBank(bank.n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
     with pytest.raises(dev.SkredAmdError):
         db.render_host(64)
     db.close()
+
+
+def test_modulated_bank_of_many_groups_vs_oracle(dev):
+    """The 64-voice modulated patch of the golden case, replicated into a 640-voice bank (10 groups)."""
+    gold = gio.load("edge_mod")
+    seg = gold.segments[0]
+    reps = 10
+    big = VoiceBank(64 * reps)
+    for k in range(reps):
+        sl = slice(64 * k, 64 * (k + 1))
+        for name in big.a:
+            big.a[name][sl] = seg.bank_in.a[name]
+        for key in ("voice_freq_mod_osc", "voice_amp_mod_osc", "voice_pan_mod_osc", "voice_cz_mod_osc"):
+            m = big.a[key][sl]
+            big.a[key][sl] = np.where(m >= 0, m + 64 * k, m)
+        big.a["voice_phase"][sl] += np.float32(k)          # de-correlate the copies
+    ref_bank, ref_g = big.copy(), seg.g_in.copy()
+    r = cpuref.render(ref_bank, ref_g, gold.tables, 700, 0, want_stems=True)
+    ref_mix = cpuref.master(ref_g, r["sum64"].astype(np.float32))
+    db = dev.DeviceBank(big.n)
+    db.set_tables(gold.tables)
+    db.upload(big)
+    db.set_globals(seg.g_in)
+    mix, stems = db.render_host(700, 2, 0, want_stems=True)
+    assert db.last_kernel() == 2
+    got = big.copy()
+    db.download(got)
+    db.close()
+    assert gio.bits_equal(stems, r["stems"])
+    assert not got.rw_equal(ref_bank), got.rw_equal(ref_bank)
+    assert rel_rms(mix, ref_mix) <= 1e-5
 
 
 def test_empty_and_bad_arguments(dev):

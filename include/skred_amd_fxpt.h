@@ -1,0 +1,78 @@
+/*
+ * include/skred_amd_fxpt.h -- C ABI of the FIXED-POINT render path.
+ *
+ * The reference has no fixed-point render path at all (the notamy <name>_lutset_fxpt.h files are
+ * data-only headers nobody includes), so this path is DEFINED by this project: the definition is
+ * oracle/cpu_ref_fxpt.c (scalar C) and the HIP kernel must reproduce it bit for bit, mix included
+ * (integer sums do not depend on the order of addition).  Parity against the reference: unpinned
+ * upstream, by construction.
+ *
+ * Arithmetic (all integer, two's complement, `>>` on signed values is arithmetic):
+ *   LUT      int16 single-cycle tables of 2^L entries (the notamy *_fxpt pyramids), one pool
+ *   phase    uint32, 2^32 = one table cycle; per frame  phase += phase_inc  (mod 2^32), THEN sampled
+ *   index    i = phase >> (32-L);  truncate: s = lut[i]
+ *            linear:   f = (phase << L) >> 17  (Q15),  s = a + (((b - a) * f) >> 15),  b = lut[(i+1) & (2^L-1)]
+ *   ADSR     t = sat32(now - sample_start), linear stages on integer frame counts A, D, R and Q15
+ *            sustain S with reciprocals rX = floor(2^32 / X):
+ *              t < A        e = (t * rA) >> 17
+ *              t < A + D    e = 32768 - ((((t-A) * rD) >> 17) * (32768 - S) >> 15)
+ *              held         e = S                      (sample_release == 0)
+ *              tr < R       e = S - ((((tr * rR) >> 17) * S) >> 15),  tr = sat32(now - sample_release)
+ *              else         e = 0, is_active = 0
+ *   gain     target = (amp_q15 * ((e * velocity_q15) >> 15)) >> 15        (amp_q15 <= 65535)
+ *            smoother (optional): g += ((target - g) * k_q15) >> 15, gain = g
+ *   output   v = (s * gain) >> 15 ; L = (v * pan_left_q15) >> 15 ; R = (v * pan_right_q15) >> 15
+ *   mix      int64 sum of L and of R over all voices, per frame
+ *   skipped  amp_q15 == 0: v = 0, state frozen (as synth.c:537-542 does for the float path)
+ */
+#ifndef SKRED_AMD_FXPT_H
+#define SKRED_AMD_FXPT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct skred_fxpt_bank {
+  int32_t n_voices;
+  uint32_t *phase;              /* rw */
+  uint32_t *phase_inc;
+  int32_t  *table_offset;       /* first entry of the voice's table inside the int16 pool */
+  int32_t  *log2_size;          /* 3..15 */
+  int32_t  *amp_q15;            /* 0..65535 */
+  int32_t  *pan_left_q15, *pan_right_q15;
+  int32_t  *disconnect;
+  int32_t  *use_envelope;
+  uint32_t *attack_frames, *decay_frames, *release_frames;
+  int32_t  *sustain_q15, *velocity_q15;
+  uint64_t *sample_start, *sample_release;
+  int32_t  *is_active;          /* rw */
+  int32_t  *smoother_enable;
+  int32_t  *smoother_k_q15;
+  int32_t  *smoother_gain_q15;  /* rw */
+  int32_t  *voice_sample;       /* rw: v of the last rendered frame */
+} skred_fxpt_bank_t;
+
+typedef struct skred_fxbank skred_fxbank_t;   /* opaque device-side bank */
+
+int  skred_fxbank_create(int device, int n_voices, skred_fxbank_t **out);
+void skred_fxbank_destroy(skred_fxbank_t *fx);
+int  skred_fxbank_set_tables_i16(skred_fxbank_t *fx, const int16_t *pool, size_t n_entries);
+int  skred_fxbank_upload(skred_fxbank_t *fx, const skred_fxpt_bank_t *host, int src_first, int dst_first, int count);
+int  skred_fxbank_download(skred_fxbank_t *fx, skred_fxpt_bank_t *host, int src_first, int dst_first, int count);
+int  skred_fxbank_set_sample_count(skred_fxbank_t *fx, uint64_t synth_sample_count);
+uint64_t skred_fxbank_get_sample_count(const skred_fxbank_t *fx);
+
+/* Render num_frames frames; d_mix = device int64[num_frames][2]; d_stems = device int32
+ * [num_frames][n_voices][2] or NULL.  interp: 0 truncate, 1 linear.  Asynchronous on `stream`. */
+int  skred_fxbank_render(skred_fxbank_t *fx, int num_frames, int interp, int64_t *d_mix, int32_t *d_stems, void *stream);
+/* Same on host buffers (synchronous). */
+int  skred_fxbank_render_host(skred_fxbank_t *fx, int num_frames, int interp, int64_t *mix, int32_t *stems_or_null);
+float skred_fxbank_last_render_ms(skred_fxbank_t *fx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

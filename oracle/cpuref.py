@@ -102,3 +102,20 @@ def lcg_advance(state: int, steps: int) -> int:
     for _ in range(steps):
         state = L.skred_cpuref_lcg_next(state)
     return state
+
+
+def fx_render(bank, pool: np.ndarray, count: int, frames: int, interp: int = 0, want_stems: bool = False, fast: bool = False):
+    """Fixed-point definition (oracle/cpu_ref_fxpt.c).  Returns (mix int64 [F][2], stems int32|None, new count)."""
+    from skred_amd.fxbank import FxBankC
+    L = lib(fast)
+    L.skred_cpuref_fx_render.argtypes = [C.POINTER(FxBankC), C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.skred_cpuref_fx_render.restype = C.c_int
+    pool = np.ascontiguousarray(pool, np.int16)
+    mix = np.zeros((frames, 2), np.int64)
+    stems = np.zeros((frames, bank.n, 2), np.int32) if want_stems else None
+    cnt = C.c_uint64(count)
+    cb = bank.as_c()
+    rc = L.skred_cpuref_fx_render(C.byref(cb), pool.ctypes.data, C.byref(cnt), frames, interp, mix.ctypes.data, _ptr(stems))
+    if rc != 0:
+        raise RuntimeError(f"skred_cpuref_fx_render rc={rc}")
+    return mix, stems, int(cnt.value)

@@ -83,6 +83,15 @@ static int fail(int code, const char *fmt, ...) {
   } while (0)
 
 const char *skred_amd_last_error(void) { return g_err; }
+
+/* shared with skred_fxbank.c */
+int skred_amd_set_error(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
 int skred_amd_abi_version(void) { return SKRED_AMD_ABI_VERSION; }
 
 int skred_amd_device_count(void) {

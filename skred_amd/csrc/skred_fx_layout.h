@@ -1,0 +1,39 @@
+/* skred_fx_layout.h -- device layout of a fixed-point voice bank (see skred_device_layout.h for the
+ * float path; same idea: 16-byte planes, one coalesced dwordx4 per lane per plane). */
+#ifndef SKRED_FX_LAYOUT_H
+#define SKRED_FX_LAYOUT_H
+#include <stdint.h>
+
+enum {
+  SKX_OSC = 0,  /* u32 phase_inc | i32 table_offset | u32 log2_size + (flags << 8) | i32 amp_q15 */
+  SKX_GAIN,     /* i32 pan_left_q15 | i32 pan_right_q15 | i32 smoother_k_q15 | i32 velocity_q15   */
+  SKX_ENV,      /* u32 attack_frames | u32 decay_frames | u32 release_frames | i32 sustain_q15    */
+  SKX_RECIP,    /* u32 floor(2^32/attack) | floor(2^32/decay) | floor(2^32/release) | 0           */
+  SKX_TIME,     /* u32 sample_start lo,hi | u32 sample_release lo,hi                               */
+  SKX_COUNT
+};
+/* read-write plane: u32 phase | i32 smoother_gain_q15 | i32 voice_sample | u32 is_active */
+
+#define SKXF_USE_ENV (1u << 0)
+#define SKXF_SMOOTH  (1u << 1)
+#define SKXF_MUTED   (1u << 2)
+#define SKXF_INERT   (1u << 3)
+
+#define SKX_GROUP 256
+#define SKX_CHUNK 64
+#define SKX_LDS_TABLE_MAX_BYTES 49152
+#define SKX_MAX_WORKGROUPS 2048
+
+typedef struct { uint32_t w[4]; } skx_plane_t;
+
+typedef struct {
+  const skx_plane_t *ro[SKX_COUNT];
+  skx_plane_t *rw;
+  const int16_t *tables;
+  long long *partial;     /* [n_workgroups][num_frames][2] */
+  int32_t *stems;         /* [num_frames][n_voices][2] or NULL */
+  uint64_t count0;
+  int32_t n_voices, n_groups, num_frames, interp;
+  int32_t lds_bytes_tables;   /* bytes of the pool staged in LDS (multiple of 16), 0 = gather from L2/HBM */
+} skx_args_t;
+#endif

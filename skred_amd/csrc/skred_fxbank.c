@@ -1,0 +1,222 @@
+/*
+ * skred_fxbank.c -- C host shim of the fixed-point path (include/skred_amd_fxpt.h).  Mirrors
+ * skred_bank.c: owns the HBM planes, packs the host arrays, sequences sk_fx_render_kernel and the
+ * int64 partial reduction.  No CPU rendering.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "skred_amd.h"
+#include "skred_amd_fxpt.h"
+#include "skred_fx_layout.h"
+
+int skx_launch_render(const skx_args_t *args, int n_workgroups, hipStream_t stream);
+int skx_launch_reduce(const long long *partial, long long *out, int W, int ncols, hipStream_t stream);
+int skred_amd_set_error(int code, const char *fmt, ...);   /* skred_bank.c */
+
+struct skred_fxbank {
+  int device, n_voices, n_padded, n_groups;
+  skx_plane_t *d_ro[SKX_COUNT];
+  skx_plane_t *d_rw;
+  int16_t *d_tables;
+  size_t table_entries, table_bytes_padded;
+  long long *d_partial; size_t partial_cap;
+  long long *d_mix; size_t mix_cap;
+  int32_t *d_stems; size_t stems_cap;
+  uint64_t count;
+  hipEvent_t ev0, ev1;
+  int timed;
+};
+
+#define HIP_TRY(call)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) return skred_amd_set_error(SKRED_E_NO_DEVICE, "%s -> %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+static int grow_bytes(void **buf, size_t *cap, size_t need) {
+  if (*cap >= need) return SKRED_OK;
+  if (*buf) { hipFree(*buf); *buf = NULL; *cap = 0; }
+  HIP_TRY(hipMalloc(buf, need));
+  *cap = need;
+  return SKRED_OK;
+}
+
+int skred_fxbank_create(int device, int n_voices, skred_fxbank_t **out) {
+  if (!out || n_voices <= 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "skred_fxbank_create: bad arguments");
+  *out = NULL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return skred_amd_set_error(SKRED_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return skred_amd_set_error(SKRED_E_BAD_ARG, "device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  skred_fxbank_t *fx = (skred_fxbank_t *)calloc(1, sizeof(*fx));
+  if (!fx) return skred_amd_set_error(SKRED_E_NO_MEM, "calloc");
+  fx->device = device; fx->n_voices = n_voices;
+  fx->n_groups = (n_voices + SKX_GROUP - 1) / SKX_GROUP;
+  fx->n_padded = fx->n_groups * SKX_GROUP;
+  const size_t bytes = (size_t)fx->n_padded * sizeof(skx_plane_t);
+  for (int p = 0; p < SKX_COUNT; p++) { HIP_TRY(hipMalloc((void **)&fx->d_ro[p], bytes)); HIP_TRY(hipMemset(fx->d_ro[p], 0, bytes)); }
+  HIP_TRY(hipMalloc((void **)&fx->d_rw, bytes)); HIP_TRY(hipMemset(fx->d_rw, 0, bytes));
+  skx_plane_t *inert = (skx_plane_t *)calloc((size_t)fx->n_padded, sizeof(skx_plane_t));
+  if (!inert) return skred_amd_set_error(SKRED_E_NO_MEM, "calloc");
+  for (int v = 0; v < fx->n_padded; v++) inert[v].w[2] = 3u | (SKXF_INERT << 8);   /* log2_size 3, amp 0 */
+  hipError_t e = hipMemcpy(fx->d_ro[SKX_OSC], inert, bytes, hipMemcpyHostToDevice);
+  free(inert);
+  HIP_TRY(e);
+  HIP_TRY(hipEventCreate(&fx->ev0)); HIP_TRY(hipEventCreate(&fx->ev1));
+  *out = fx;
+  return SKRED_OK;
+}
+
+void skred_fxbank_destroy(skred_fxbank_t *fx) {
+  if (!fx) return;
+  hipSetDevice(fx->device);
+  for (int p = 0; p < SKX_COUNT; p++) if (fx->d_ro[p]) hipFree(fx->d_ro[p]);
+  if (fx->d_rw) hipFree(fx->d_rw);
+  if (fx->d_tables) hipFree(fx->d_tables);
+  if (fx->d_partial) hipFree(fx->d_partial);
+  if (fx->d_mix) hipFree(fx->d_mix);
+  if (fx->d_stems) hipFree(fx->d_stems);
+  if (fx->ev0) hipEventDestroy(fx->ev0);
+  if (fx->ev1) hipEventDestroy(fx->ev1);
+  free(fx);
+}
+
+int skred_fxbank_set_tables_i16(skred_fxbank_t *fx, const int16_t *pool, size_t n) {
+  if (!fx || !pool || n == 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx set_tables: bad arguments");
+  HIP_TRY(hipSetDevice(fx->device));
+  if (fx->d_tables) { hipFree(fx->d_tables); fx->d_tables = NULL; }
+  fx->table_entries = n;
+  fx->table_bytes_padded = (n * sizeof(int16_t) + 15) & ~(size_t)15;
+  HIP_TRY(hipMalloc((void **)&fx->d_tables, fx->table_bytes_padded));
+  HIP_TRY(hipMemset(fx->d_tables, 0, fx->table_bytes_padded));
+  HIP_TRY(hipMemcpy(fx->d_tables, pool, n * sizeof(int16_t), hipMemcpyHostToDevice));
+  return SKRED_OK;
+}
+
+static uint32_t recip32(uint32_t x) { return x ? (uint32_t)(0x100000000ull / x) : 0u; }
+
+int skred_fxbank_upload(skred_fxbank_t *fx, const skred_fxpt_bank_t *h, int src_first, int dst_first, int count) {
+  if (!fx || !h || count < 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx upload: bad arguments");
+  if (src_first < 0 || src_first + count > h->n_voices || dst_first < 0 || dst_first + count > fx->n_voices)
+    return skred_amd_set_error(SKRED_E_RANGE, "fx upload window outside bank");
+  if (count == 0) return SKRED_OK;
+  HIP_TRY(hipSetDevice(fx->device));
+  skx_plane_t *st = (skx_plane_t *)calloc((size_t)(SKX_COUNT + 1) * (size_t)count, sizeof(skx_plane_t));
+  if (!st) return skred_amd_set_error(SKRED_E_NO_MEM, "fx upload staging");
+  for (int i = 0; i < count; i++) {
+    const int v = src_first + i;
+    const int L = h->log2_size[v];
+    if (L < 3 || L > 15 || h->table_offset[v] < 0 ||
+        (size_t)h->table_offset[v] + ((size_t)1 << L) > fx->table_entries) {
+      free(st);
+      return skred_amd_set_error(SKRED_E_RANGE, "fx voice %d: table [%d,+2^%d) outside pool of %zu entries", v, h->table_offset[v], L, fx->table_entries);
+    }
+    if (h->amp_q15[v] < 0 || h->amp_q15[v] > 65535) { free(st); return skred_amd_set_error(SKRED_E_RANGE, "fx voice %d: amp_q15 %d outside 0..65535", v, h->amp_q15[v]); }
+    uint32_t flags = 0;
+    if (h->use_envelope[v]) flags |= SKXF_USE_ENV;
+    if (h->smoother_enable[v]) flags |= SKXF_SMOOTH;
+    if (h->disconnect[v]) flags |= SKXF_MUTED;
+#define P(p) st[(size_t)(p) * count + i]
+    P(SKX_OSC).w[0] = h->phase_inc[v]; P(SKX_OSC).w[1] = (uint32_t)h->table_offset[v];
+    P(SKX_OSC).w[2] = (uint32_t)L | (flags << 8); P(SKX_OSC).w[3] = (uint32_t)h->amp_q15[v];
+    P(SKX_GAIN).w[0] = (uint32_t)h->pan_left_q15[v]; P(SKX_GAIN).w[1] = (uint32_t)h->pan_right_q15[v];
+    P(SKX_GAIN).w[2] = (uint32_t)h->smoother_k_q15[v]; P(SKX_GAIN).w[3] = (uint32_t)h->velocity_q15[v];
+    P(SKX_ENV).w[0] = h->attack_frames[v]; P(SKX_ENV).w[1] = h->decay_frames[v];
+    P(SKX_ENV).w[2] = h->release_frames[v]; P(SKX_ENV).w[3] = (uint32_t)h->sustain_q15[v];
+    P(SKX_RECIP).w[0] = recip32(h->attack_frames[v]); P(SKX_RECIP).w[1] = recip32(h->decay_frames[v]);
+    P(SKX_RECIP).w[2] = recip32(h->release_frames[v]);
+    P(SKX_TIME).w[0] = (uint32_t)h->sample_start[v]; P(SKX_TIME).w[1] = (uint32_t)(h->sample_start[v] >> 32);
+    P(SKX_TIME).w[2] = (uint32_t)h->sample_release[v]; P(SKX_TIME).w[3] = (uint32_t)(h->sample_release[v] >> 32);
+    P(SKX_COUNT).w[0] = h->phase[v]; P(SKX_COUNT).w[1] = (uint32_t)h->smoother_gain_q15[v];
+    P(SKX_COUNT).w[2] = (uint32_t)h->voice_sample[v]; P(SKX_COUNT).w[3] = h->is_active[v] ? 1u : 0u;
+#undef P
+  }
+  const size_t bytes = (size_t)count * sizeof(skx_plane_t);
+  hipError_t e = hipSuccess;
+  for (int p = 0; p < SKX_COUNT && e == hipSuccess; p++)
+    e = hipMemcpy(fx->d_ro[p] + dst_first, st + (size_t)p * count, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(fx->d_rw + dst_first, st + (size_t)SKX_COUNT * count, bytes, hipMemcpyHostToDevice);
+  free(st);
+  HIP_TRY(e);
+  return SKRED_OK;
+}
+
+int skred_fxbank_download(skred_fxbank_t *fx, skred_fxpt_bank_t *h, int src_first, int dst_first, int count) {
+  if (!fx || !h || count < 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx download: bad arguments");
+  if (src_first < 0 || src_first + count > fx->n_voices || dst_first < 0 || dst_first + count > h->n_voices)
+    return skred_amd_set_error(SKRED_E_RANGE, "fx download window outside bank");
+  if (count == 0) return SKRED_OK;
+  HIP_TRY(hipSetDevice(fx->device));
+  skx_plane_t *st = (skx_plane_t *)malloc((size_t)count * sizeof(skx_plane_t));
+  if (!st) return skred_amd_set_error(SKRED_E_NO_MEM, "fx download staging");
+  HIP_TRY(hipDeviceSynchronize());
+  hipError_t e = hipMemcpy(st, fx->d_rw + src_first, (size_t)count * sizeof(skx_plane_t), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { free(st); HIP_TRY(e); }
+  for (int i = 0; i < count; i++) {
+    const int v = dst_first + i;
+    h->phase[v] = st[i].w[0];
+    h->smoother_gain_q15[v] = (int32_t)st[i].w[1];
+    h->voice_sample[v] = (int32_t)st[i].w[2];
+    h->is_active[v] = (int32_t)(st[i].w[3] & 1u);
+  }
+  free(st);
+  return SKRED_OK;
+}
+
+int skred_fxbank_set_sample_count(skred_fxbank_t *fx, uint64_t c) { if (!fx) return SKRED_E_BAD_ARG; fx->count = c; return SKRED_OK; }
+uint64_t skred_fxbank_get_sample_count(const skred_fxbank_t *fx) { return fx ? fx->count : 0; }
+
+int skred_fxbank_render(skred_fxbank_t *fx, int num_frames, int interp, int64_t *d_mix, int32_t *d_stems, void *stream) {
+  if (!fx || !d_mix || num_frames <= 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx render: bad arguments");
+  if (!fx->d_tables) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx render: no table pool set");
+  HIP_TRY(hipSetDevice(fx->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int n_wg = fx->n_groups < SKX_MAX_WORKGROUPS ? fx->n_groups : SKX_MAX_WORKGROUPS;
+  int rc = grow_bytes((void **)&fx->d_partial, &fx->partial_cap, (size_t)n_wg * (size_t)num_frames * 2 * sizeof(long long));
+  if (rc) return rc;
+  skx_args_t a;
+  memset(&a, 0, sizeof(a));
+  for (int p = 0; p < SKX_COUNT; p++) a.ro[p] = fx->d_ro[p];
+  a.rw = fx->d_rw; a.tables = fx->d_tables; a.partial = fx->d_partial; a.stems = d_stems;
+  a.count0 = fx->count; a.n_voices = fx->n_voices; a.n_groups = fx->n_groups;
+  a.num_frames = num_frames; a.interp = interp ? 1 : 0;
+  a.lds_bytes_tables = fx->table_bytes_padded <= SKX_LDS_TABLE_MAX_BYTES ? (int32_t)fx->table_bytes_padded : 0;
+  HIP_TRY(hipEventRecord(fx->ev0, s));
+  hipError_t e = (hipError_t)skx_launch_render(&a, n_wg, s);
+  if (e != hipSuccess) return skred_amd_set_error(SKRED_E_NO_DEVICE, "fx render launch -> %s", hipGetErrorString(e));
+  HIP_TRY(hipEventRecord(fx->ev1, s));
+  fx->timed = 1;
+  e = (hipError_t)skx_launch_reduce(fx->d_partial, (long long *)d_mix, n_wg, 2 * num_frames, s);
+  if (e != hipSuccess) return skred_amd_set_error(SKRED_E_NO_DEVICE, "fx reduce launch -> %s", hipGetErrorString(e));
+  fx->count += (uint64_t)num_frames;
+  return SKRED_OK;
+}
+
+int skred_fxbank_render_host(skred_fxbank_t *fx, int num_frames, int interp, int64_t *mix, int32_t *stems) {
+  if (!fx || !mix || num_frames <= 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx render_host: bad arguments");
+  HIP_TRY(hipSetDevice(fx->device));
+  int rc;
+  const size_t mix_bytes = (size_t)num_frames * 2 * sizeof(int64_t);
+  const size_t stem_bytes = (size_t)num_frames * (size_t)fx->n_voices * 2 * sizeof(int32_t);
+  if ((rc = grow_bytes((void **)&fx->d_mix, &fx->mix_cap, mix_bytes))) return rc;
+  if (stems && (rc = grow_bytes((void **)&fx->d_stems, &fx->stems_cap, stem_bytes))) return rc;
+  if ((rc = skred_fxbank_render(fx, num_frames, interp, (int64_t *)fx->d_mix, stems ? fx->d_stems : NULL, NULL))) return rc;
+  HIP_TRY(hipMemcpy(mix, fx->d_mix, mix_bytes, hipMemcpyDeviceToHost));
+  if (stems) HIP_TRY(hipMemcpy(stems, fx->d_stems, stem_bytes, hipMemcpyDeviceToHost));
+  return SKRED_OK;
+}
+
+float skred_fxbank_last_render_ms(skred_fxbank_t *fx) {
+  if (!fx || !fx->timed) return -1.0f;
+  float ms = -1.0f;
+  if (hipSetDevice(fx->device) != hipSuccess) return -1.0f;
+  if (hipEventSynchronize(fx->ev1) != hipSuccess) return -1.0f;
+  if (hipEventElapsedTime(&ms, fx->ev0, fx->ev1) != hipSuccess) return -1.0f;
+  return ms;
+}

@@ -22,6 +22,13 @@ def test_header_and_binding_agree():
     assert declared_symbols() == sorted(device.ABI_SYMBOLS)
 
 
+def test_fxpt_header_and_binding_agree():
+    from skred_amd import fxbank
+    text = open(os.path.join(ROOT, "include", "skred_amd_fxpt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert sorted(set(re.findall(r"\b(skred_fxbank_\w+)\s*\(", text))) == sorted(fxbank.FX_ABI_SYMBOLS)
+
+
 def test_library_exports_every_declared_symbol():
     L = device.load()
     for s in declared_symbols():

@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
                     help="weak (default): every GPU gets a whole bank of the workload size; strong: one bank is split over the GPUs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--fast2-min-voices", type=int, default=-1,
+                    help="override the bank size from which the two-voices-per-lane kernel is used (-1: library default)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +122,8 @@ def main():
     db.set_tables(tables)
     db.upload(shard)
     db.set_globals(g)
+    if a.fast2_min_voices >= 0:
+        db.fast2_min_voices(a.fast2_min_voices)
 
     partial = torch.zeros(F, 2, device=dev, dtype=torch.float32)
     out = torch.zeros(F, 2, device=dev, dtype=torch.float32)
@@ -174,7 +178,8 @@ def main():
             "output_finite": finite,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": "sk_render_kernel", "kernel_ms_mean": k_mean_ms, "kernel_ms_min": k_min_ms,
+                         "kernel": {0: "sk_render_kernel", 1: "sk_render_fast_kernel", 2: "sk_render_mod_kernel",
+                                    3: "sk_render_fast2_kernel"}.get(db.last_kernel(), "?"), "kernel_ms_mean": k_mean_ms, "kernel_ms_min": k_min_ms,
                          "launches_timed": k_cnt, "algorithmic_bytes_per_voice_sample": B,
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "kernel_voice_samples_per_s": shard.n * F / (k_mean_ms * 1e-3),

@@ -206,8 +206,8 @@ int  skred_bank_render_host(skred_bank_t *bank, float *buffer, int num_frames,
 /* Options.  Two kernels implement the render loop: a generic one (every synth() feature the path
  * supports) and a specialised one chosen automatically for "clean" banks; their per-voice results are
  * bit-identical.  FORCE_GENERIC pins the generic kernel (used by the parity tests to cross-check). */
-enum { SKRED_OPT_FORCE_GENERIC = 1 };
-enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2 };
+enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size from which the two-voices-per-lane kernel is used */ };
+enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */
 

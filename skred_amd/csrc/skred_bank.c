@@ -27,6 +27,7 @@ int sk_launch_master(const float *sum, float *out, int num_frames, int num_chann
                      float target, float k, float *gain_state, hipStream_t stream);
 
 #define SK_TIMING_RING 256
+#define SK_FAST2_MIN_VOICES 262144   /* banks at least this large use two voices per lane (measured crossover) */
 
 struct skred_bank {
   int device;
@@ -52,6 +53,7 @@ struct skred_bank {
   int class_dirty;
   uint32_t fast_mode;         /* SKM_* from classify() */
   int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
+  int fast2_min_voices;       /* SKRED_OPT_FAST2_MIN_VOICES */
   int last_kernel;            /* SKRED_KERNEL_* used by the most recent render */
   skred_globals_t g;
   uint32_t features;
@@ -122,7 +124,8 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   if (!b) return fail(SKRED_E_NO_MEM, "calloc");
   b->device = device;
   b->n_voices = n_voices;
-  b->n_groups = (n_voices + SK_GROUP - 1) / SK_GROUP;
+  b->n_groups = ((n_voices + 2 * SK_GROUP - 1) / (2 * SK_GROUP)) * 2;   /* even: the two-per-lane kernel takes 512 voices per pass */
+  b->fast2_min_voices = SK_FAST2_MIN_VOICES;
   b->n_padded = b->n_groups * SK_GROUP;
   const size_t plane_bytes = (size_t)b->n_padded * sizeof(sk_plane_t);
   for (int p = 0; p < SKP_COUNT; p++) {
@@ -380,6 +383,7 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
   if (!b) return fail(SKRED_E_BAD_ARG, "set_option");
   switch (option) {
     case SKRED_OPT_FORCE_GENERIC: b->force_generic = value != 0; return SKRED_OK;
+    case SKRED_OPT_FAST2_MIN_VOICES: b->fast2_min_voices = value; return SKRED_OK;
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
 }
@@ -451,7 +455,7 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
   HIP_TRY(hipSetDevice(b->device));
   hipStream_t s = (hipStream_t)stream;
   const int modulated = (b->features & SKB_ANY_MOD) != 0;
-  const int n_wg = modulated ? b->n_padded / 64 : (b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS);
+  int n_wg = modulated ? b->n_padded / 64 : (b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS);
   int rc = grow(&b->d_partial, &b->partial_cap, (size_t)n_wg * (size_t)num_frames * 2);
   if (rc) return rc;
 
@@ -473,10 +477,15 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
   a.features = b->features;
   classify(b);
   a.fast_mode = (b->force_generic || d_stems) ? 0u : b->fast_mode;
-  b->last_kernel = (a.fast_mode & SKM_FAST) ? SKRED_KERNEL_FAST : SKRED_KERNEL_GENERIC;
+  if ((a.fast_mode & SKM_FAST) && b->n_voices >= b->fast2_min_voices) a.fast_mode |= SKM_TWO_PER_LANE;
+  b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
+                   : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
   if ((rc = grow(&b->d_redtmp, &b->redtmp_cap, (size_t)sk_reduce_tmp_floats(2 * num_frames)))) return rc;
 
   const int slot = b->n_timed % SK_TIMING_RING;
+  if (!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) {
+    n_wg = b->n_groups / 2 < SK_MAX_WORKGROUPS ? b->n_groups / 2 : SK_MAX_WORKGROUPS;
+  }
   HIP_TRY(hipEventRecord(b->ev0[slot], s));
   hipError_t e;
   if (modulated) {

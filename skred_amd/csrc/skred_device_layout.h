@@ -69,6 +69,7 @@ enum {
 #define SKM_FAST        (1u << 0)  /* bank qualifies for sk_render_fast_kernel (see skred_bank.c:classify) */
 #define SKM_FILTER_ALL  (1u << 1)  /* every live voice runs the biquad (else: none does) */
 #define SKM_ENV_ALL     (1u << 2)  /* every live voice uses the amp envelope (else: none does) */
+#define SKM_TWO_PER_LANE (1u << 3) /* large bank: sk_render_fast2_kernel (two voices per lane, packed fp32) */
 
 #define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */
 #define SK_CHUNK 64                /* frames between two workgroup-level mix flushes */

@@ -851,6 +851,281 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_ke
   }
 }
 
+// ---------------------------------------------------------------- fast kernel, two voices per lane
+//
+// Same per-voice arithmetic as sk_render_fast_kernel, but every lane carries TWO voices (v and v+64
+// of a 128-voice wave slice) as 2-vectors, so that
+//   * the mul/add backbone (phase add, wrap, biquad, smoother, gain, pan) issues as packed fp32
+//     (v_pk_add_f32 / v_pk_mul_f32: two voices per instruction, each lane-op still IEEE fp32,
+//     unfused, hence bit-identical), and
+//   * the 12-instruction cross-lane DPP reduction is paid once per 128 voices instead of per 64.
+// Compares, selects, float->int conversion and the LDS gathers stay per voice.  Used for large
+// clean banks (the host decides, skred_bank.c); per-voice results equal the other two kernels'.
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct Fast2Regs {
+  v2f inc, lo, hi, span, span2;
+  int toff4[2], tsize_m1[2];
+  v2f k, b0, b1, b2, a1, a2, pan_l, pan_r, gain_const;   // gain_const: amp (no envelope) or amp*(sus*vel)
+  v2f phase, sgain, x1, x2, y1, y2, sample;
+  // envelope (per voice, scalar code)
+  float amp[2], att[2], attdec[2], dec[2], sus[2], one_m_sus[2], rel[2], vel[2], tf[2], trf[2];
+  uint32_t rw[2];
+};
+
+template <bool TAB_LDS, int INTERP>
+__device__ __forceinline__ float fast2_fetch(const char *lds_tab, const char *__restrict__ glb_tab,
+                                             int toff4, int tsize_m1, float lo, float hi, float pos) {
+  int idx = (int)pos;
+  idx = max(min(idx, tsize_m1), 0);
+  const char *tab = TAB_LDS ? lds_tab : glb_tab;
+  const float a = *reinterpret_cast<const float *>(tab + (toff4 + (idx << 2)));
+  if (INTERP == 0) return a;
+  int nxt = idx + 1;
+  if ((float)nxt >= hi) nxt = (int)lo;
+  nxt = max(min(nxt, tsize_m1), 0);
+  const float b = *reinterpret_cast<const float *>(tab + (toff4 + (nxt << 2)));
+  const float frac = pos - (float)idx;
+  return a + frac * (b - a);
+}
+
+__device__ __forceinline__ float fast2_env(Fast2Regs &r, int c, bool released) {
+  float e = 0.0f;
+  if (r.rw[c] & SKR_ENV_ACTIVE) {
+    if (r.tf[c] < r.att[c]) {
+      e = r.tf[c] / r.att[c];
+    } else if (r.tf[c] < r.attdec[c]) {
+      const float prog = (r.tf[c] - r.att[c]) / r.dec[c];
+      e = 1.0f - prog * r.one_m_sus[c];
+    } else if (!released) {
+      e = r.sus[c];
+    } else if (r.trf[c] < r.rel[c]) {
+      const float prog = r.trf[c] / r.rel[c];
+      e = r.sus[c] * (1.0f - prog);
+    } else {
+      r.rw[c] &= ~SKR_ENV_ACTIVE;
+    }
+  }
+  return r.amp[c] * (e * r.vel[c]);
+}
+
+template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, int INTERP>
+__device__ __forceinline__ void fast2_frame(Fast2Regs &r, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
+                                            const bool rel0, const bool rel1, const bool silent0,
+                                            const bool silent1, const char *lds_tab,
+                                            const char *__restrict__ glb_tab, float &out_l, float &out_r) {
+  // ---- oscillator: packed add / wrap candidate, per-voice range tests ----
+  const v2f ph0 = r.phase + r.inc;
+  const v2f x = ph0 - r.lo;
+  const v2f phw = r.lo + (x - r.span);
+  v2f ph;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const bool over = ph0[c] >= r.hi[c];
+    const bool simple = over && (x[c] < r.span2[c]);
+    const bool in_range = (ph0[c] >= r.lo[c]) && !over;
+    float p = simple ? phw[c] : ph0[c];
+    if (!(in_range || simple)) p = slow_wrap(ph0[c], r.lo[c], r.hi[c], r.span[c]);
+    ph[c] = p;
+  }
+  r.phase = ph;
+  v2f s;
+  s.x = fast2_fetch<TAB_LDS, INTERP>(lds_tab, glb_tab, r.toff4[0], r.tsize_m1[0], r.lo.x, r.hi.x, ph.x);
+  s.y = fast2_fetch<TAB_LDS, INTERP>(lds_tab, glb_tab, r.toff4[1], r.tsize_m1[1], r.lo.y, r.hi.y, ph.y);
+  // ---- biquad, packed ----
+  if (FILTER) {
+    v2f y = r.b0 * s;
+    y = y + r.b1 * xn;
+    y = y + r.b2 * xo;
+    y = y - r.a1 * yn;
+    y = y - r.a2 * yo;
+    xo = s;
+    yo = y;
+    s = y;
+  }
+  // ---- gain ----
+  v2f gain;
+  if (!ENV || STEADY) {
+    gain = r.gain_const;
+  } else {
+    gain.x = fast2_env(r, 0, rel0);
+    gain.y = fast2_env(r, 1, rel1);
+  }
+  r.sgain = r.sgain + r.k * (gain - r.sgain);
+  s = s * r.sgain;
+  r.sample = s;
+  // ---- pan, lane-local sum of the two voices ----
+  v2f so;
+  so.x = silent0 ? 0.0f : s.x;
+  so.y = silent1 ? 0.0f : s.y;
+  const v2f l2 = so * r.pan_l;
+  const v2f r2 = so * r.pan_r;
+  out_l = l2.x + l2.y;
+  out_r = r2.x + r2.y;
+}
+
+#define SK_FAST2_FRAME(J, STEADY_, XN, XO, YN, YO)                                                       \
+  {                                                                                                      \
+    float l, rr;                                                                                         \
+    fast2_frame<TAB_LDS, FILTER, ENV, STEADY_, INTERP>(r, XN, XO, YN, YO, released[0], released[1],      \
+                                                       silent[0], silent[1], lds_tab, glb_tab, l, rr);   \
+    SK_REDUCE_AND_STORE(J)                                                                               \
+  }
+#define SK_FAST2_EVEN(J, STEADY_) SK_FAST2_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2)
+#define SK_FAST2_ODD(J, STEADY_) SK_FAST2_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1)
+#define SK_FAST2_FIX_ODD_TAIL() { v2f t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }
+
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
+__global__ __launch_bounds__(SK_GROUP) void sk_render_fast2_kernel(const sk_render_args_t a) {
+  extern __shared__ float lds[];
+  float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
+  const char *lds_tab = reinterpret_cast<const char *>(lds);
+  const char *glb_tab = reinterpret_cast<const char *>(a.tables);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  if (TAB_LDS) {
+    const int n4 = a.lds_table_floats >> 2;
+    const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);
+    float4 *dst4 = reinterpret_cast<float4 *>(lds);
+    for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];
+    __syncthreads();
+  }
+  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;
+  bool first_pass = true;
+  const int n_groups2 = a.n_groups >> 1;                 // 512 voices per workgroup pass (host pads to 512)
+
+  for (int g = blockIdx.x; g < n_groups2; g += gridDim.x) {
+    Fast2Regs r;
+    bool dead[2], silent[2], released[2];
+    uint64_t t_start[2], t_release[2];
+    int vidx[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int v = g * (2 * SK_GROUP) + wave * 128 + c * 64 + lane;
+      vidx[c] = v;
+      const uint4 osc = *reinterpret_cast<const uint4 *>(&a.ro[SKP_OSC][v]);
+      const uint4 tab = *reinterpret_cast<const uint4 *>(&a.ro[SKP_TAB][v]);
+      const uint4 gn = *reinterpret_cast<const uint4 *>(&a.ro[SKP_GAIN][v]);
+      const uint4 s0 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_OSC][v]);
+      const uint4 s1 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_FILT][v]);
+      const uint4 s2 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_MISC][v]);
+      r.inc[c] = __uint_as_float(osc.x); r.lo[c] = __uint_as_float(osc.y);
+      r.hi[c] = __uint_as_float(osc.z);  r.amp[c] = __uint_as_float(osc.w);
+      r.toff4[c] = (int)tab.x << 2; r.tsize_m1[c] = (int)tab.y - 1;
+      const uint32_t flags = tab.z;
+      r.vel[c] = __uint_as_float(gn.x); r.k[c] = __uint_as_float(gn.y);
+      r.b0[c] = __uint_as_float(gn.z);  r.b1[c] = __uint_as_float(gn.w);
+      r.phase[c] = __uint_as_float(s0.x); r.sgain[c] = __uint_as_float(s0.y);
+      r.x1[c] = __uint_as_float(s0.z);    r.x2[c] = __uint_as_float(s0.w);
+      r.y1[c] = __uint_as_float(s1.x);    r.y2[c] = __uint_as_float(s1.y);
+      r.sample[c] = __uint_as_float(s1.z); r.rw[c] = s1.w;
+      r.pan_l[c] = __uint_as_float(s2.z); r.pan_r[c] = __uint_as_float(s2.w);
+      r.tf[c] = 0.0f; r.trf[c] = 0.0f;
+      r.b2[c] = 0.0f; r.a1[c] = 0.0f; r.a2[c] = 0.0f;
+      if (FILTER) {
+        const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
+        r.b2[c] = __uint_as_float(fl.x); r.a1[c] = __uint_as_float(fl.y); r.a2[c] = __uint_as_float(fl.z);
+      }
+      released[c] = false; t_start[c] = 0; t_release[c] = 0;
+      r.gain_const[c] = r.amp[c];
+      if (ENV) {
+        const uint4 et = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_T][v]);
+        const uint4 es = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_S][v]);
+        r.att[c] = __uint_as_float(et.x); r.dec[c] = __uint_as_float(et.y);
+        r.sus[c] = __uint_as_float(et.z); r.rel[c] = __uint_as_float(et.w);
+        r.attdec[c] = r.att[c] + r.dec[c];
+        r.one_m_sus[c] = 1.0f - r.sus[c];
+        r.gain_const[c] = r.amp[c] * (r.sus[c] * r.vel[c]);
+        t_start[c] = ((uint64_t)es.y << 32) | es.x;
+        t_release[c] = ((uint64_t)es.w << 32) | es.z;
+        released[c] = t_release[c] != 0;
+      }
+      dead[c] = (r.rw[c] & SKR_FINISHED) || r.amp[c] == 0.0f || (flags & SKF_INERT);
+      silent[c] = dead[c] || (flags & SKF_MUTED);
+    }
+    r.span = r.hi - r.lo;
+    r.span2 = r.span + r.span;
+
+    for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
+      const int cn = min(SK_CHUNK, a.num_frames - c0);
+      bool steady = true, exact = true;
+      if (ENV) {
+        const uint64_t base = a.count0 + (uint64_t)c0;
+        const uint64_t lim = (1ull << 24) - (uint64_t)SK_CHUNK - 2;
+        bool ex = true, st = true;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint64_t d_on = base - t_start[c], d_off = base - t_release[c];
+          ex = ex && (dead[c] || ((d_on < lim) && (!released[c] || d_off < lim)));
+          r.tf[c] = (float)d_on;
+          r.trf[c] = released[c] ? (float)d_off : 0.0f;
+          const float tf_first = (float)(d_on + 1);
+          st = st && (dead[c] || ((r.rw[c] & SKR_ENV_ACTIVE) && !released[c] && !(tf_first < r.attdec[c])));
+        }
+        exact = __all(ex);
+        steady = __all(st);
+      }
+      if (!ENV || steady) {
+        int j = 0;
+        for (; j + 1 < cn; j += 2) {
+          SK_FAST2_EVEN(j, true)
+          SK_FAST2_ODD(j + 1, true)
+        }
+        if (j < cn) { SK_FAST2_EVEN(j, true) SK_FAST2_FIX_ODD_TAIL() }
+      } else if (exact) {
+        int j = 0;
+        for (; j + 1 < cn; j += 2) {
+          r.tf[0] += 1.0f; r.trf[0] += 1.0f; r.tf[1] += 1.0f; r.trf[1] += 1.0f;
+          SK_FAST2_EVEN(j, false)
+          r.tf[0] += 1.0f; r.trf[0] += 1.0f; r.tf[1] += 1.0f; r.trf[1] += 1.0f;
+          SK_FAST2_ODD(j + 1, false)
+        }
+        if (j < cn) {
+          r.tf[0] += 1.0f; r.trf[0] += 1.0f; r.tf[1] += 1.0f; r.trf[1] += 1.0f;
+          SK_FAST2_EVEN(j, false)
+          SK_FAST2_FIX_ODD_TAIL()
+        }
+      } else {
+        for (int j = 0; j < cn; ++j) {
+          const uint64_t now = a.count0 + (uint64_t)(c0 + j) + 1;
+          r.tf[0] = (float)(now - t_start[0]); r.trf[0] = (float)(now - t_release[0]);
+          r.tf[1] = (float)(now - t_start[1]); r.trf[1] = (float)(now - t_release[1]);
+          SK_FAST2_EVEN(j, false)
+          SK_FAST2_FIX_ODD_TAIL()
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * cn) {
+        const float *w = reinterpret_cast<const float *>(wsum);
+        float s = w[0 * 2 * SK_CHUNK + tid];
+        s += w[1 * 2 * SK_CHUNK + tid];
+        s += w[2 * 2 * SK_CHUNK + tid];
+        s += w[3 * 2 * SK_CHUNK + tid];
+        float *p = a.partial + part_base + (size_t)c0 * 2 + tid;
+        if (first_pass) *p = s; else *p += s;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int v = vidx[c];
+      if (!dead[c]) {
+        uint4 s0, s1;
+        s0.x = __float_as_uint(r.phase[c]); s0.y = __float_as_uint(r.sgain[c]);
+        s0.z = __float_as_uint(r.x1[c]);    s0.w = __float_as_uint(r.x2[c]);
+        s1.x = __float_as_uint(r.y1[c]);    s1.y = __float_as_uint(r.y2[c]);
+        s1.z = __float_as_uint(r.sample[c]); s1.w = r.rw[c];
+        *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
+        *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;
+      } else {
+        reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][v])[2] = 0u;
+      }
+    }
+    first_pass = false;
+  }
+}
+
 // ---------------------------------------------------------------- partial-mix reduction
 
 // Stage 1: partial[W][ncols] -> tmp[SK_RED_SLABS][ncols]; stage 2: tmp -> out[ncols].
@@ -916,6 +1191,24 @@ extern "C" int sk_launch_render(const sk_render_args_t *args, int n_workgroups, 
   const size_t lds_bytes = (size_t)(tab_lds ? args->lds_table_floats : 0) * sizeof(float) +
                            (size_t)4 * SK_CHUNK * sizeof(float2);
   dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
+  if ((args->fast_mode & SKM_FAST) && (args->fast_mode & SKM_TWO_PER_LANE) && !stems) {
+    const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
+                    ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
+#define SK_FAST2_CASE(K, T, F, E, I)                                                                     \
+  case K: hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I>), grid, block, lds_bytes, stream, *args); break;
+    switch (key) {
+      SK_FAST2_CASE(0, false, false, false, 0) SK_FAST2_CASE(1, false, false, false, 1)
+      SK_FAST2_CASE(2, false, false, true, 0)  SK_FAST2_CASE(3, false, false, true, 1)
+      SK_FAST2_CASE(4, false, true, false, 0)  SK_FAST2_CASE(5, false, true, false, 1)
+      SK_FAST2_CASE(6, false, true, true, 0)   SK_FAST2_CASE(7, false, true, true, 1)
+      SK_FAST2_CASE(8, true, false, false, 0)  SK_FAST2_CASE(9, true, false, false, 1)
+      SK_FAST2_CASE(10, true, false, true, 0)  SK_FAST2_CASE(11, true, false, true, 1)
+      SK_FAST2_CASE(12, true, true, false, 0)  SK_FAST2_CASE(13, true, true, false, 1)
+      SK_FAST2_CASE(14, true, true, true, 0)   SK_FAST2_CASE(15, true, true, true, 1)
+    }
+#undef SK_FAST2_CASE
+    return (int)hipGetLastError();
+  }
   if ((args->fast_mode & SKM_FAST) && !stems) {
     // clean bank: specialised kernel (table residency x filter x envelope x interpolation)
     const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |

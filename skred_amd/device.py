@@ -139,6 +139,10 @@ class DeviceBank:
     def force_generic(self, on: bool = True):
         _check(self.L.skred_bank_set_option(self.h, 1, int(on)), "skred_bank_set_option")
 
+    def fast2_min_voices(self, n: int):
+        """Bank size from which the two-voices-per-lane kernel is chosen (0 = always when eligible)."""
+        _check(self.L.skred_bank_set_option(self.h, 2, int(n)), "skred_bank_set_option")
+
     def last_kernel(self) -> int:
         """0 = generic kernel, 1 = specialised fast kernel (SKRED_KERNEL_*)."""
         return int(self.L.skred_bank_last_kernel(self.h))

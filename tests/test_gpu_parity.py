@@ -314,3 +314,55 @@ def test_exotic_voice_forces_generic_kernel(dev):
     bank["voice_sample_hold_max"][5] = 3
     _, _, k = _run_scenario(dev, bank, tables, g, 0, [(64, None)], force_generic=False)
     assert k == [0]
+
+
+@pytest.mark.parametrize("recipe,interp", [("c1", 0), ("c2", 0), ("c2", 1), ("c4", 1)])
+def test_two_per_lane_kernel_matches_oracle(dev, recipe, interp):
+    """sk_render_fast2_kernel (two voices per lane, packed fp32): per-voice state bit-exact against the
+    oracle through attack/decay, note-off, release end and the smoother tail; mix within tolerance
+    (its reduction tree adds the lane's two voices first, so mix bits differ from the other kernels)."""
+    n = 5000
+    bank, tables, g = banks.RECIPES[recipe](n)
+    bank["voice_disconnect"][::7] = 1
+    bank["voice_amp"][::11] = 0.0
+    segs = [(301, None), (333, _release_odd_voices), (12001, None), (64, None)]
+    db = dev.DeviceBank(bank.n)
+    db.set_tables(tables)
+    host = bank.copy()
+    db.upload(host)
+    db.set_globals(g)
+    db.fast2_min_voices(0)
+    mixes, kernels = [], []
+    for frames, event in segs:
+        if event is not None:
+            db.download(host)
+            event(host, db.get_globals().synth_sample_count)
+            db.upload(host)
+        mixes.append(db.render_host(frames, 2, interp)[0])
+        kernels.append(db.last_kernel())
+    db.download(host)
+    db.close()
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert kernels == [3] * len(segs), kernels
+    assert not host.rw_equal(ref_state), host.rw_equal(ref_state)
+    assert rel_rms(np.concatenate(mixes), ref_mix) <= 1e-5
+
+
+def test_two_per_lane_kernel_full_size_c3(dev):
+    """BASELINE config-3 bank (2^20 voices) on the kernel bench.py uses for it, 64 frames vs the oracle."""
+    n = 1 << 20
+    bank, tables, g = banks.bank_c2(n)
+    ref_bank, ref_g = bank.copy(), g.copy()
+    r = cpuref.render(ref_bank, ref_g, tables, 64, 0)
+    ref_mix = cpuref.master(ref_g, r["sum64"].astype(np.float32))
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    mix, _ = db.render_host(64)
+    assert db.last_kernel() == 3
+    got = bank.copy()
+    db.download(got)
+    db.close()
+    assert not got.rw_equal(ref_bank), got.rw_equal(ref_bank)
+    assert rel_rms(mix, ref_mix) <= 1e-5

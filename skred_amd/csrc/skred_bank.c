@@ -27,7 +27,7 @@ int sk_launch_master(const float *sum, float *out, int num_frames, int num_chann
                      float target, float k, float *gain_state, hipStream_t stream);
 
 #define SK_TIMING_RING 256
-#define SK_FAST2_MIN_VOICES 262144   /* banks at least this large use two voices per lane (measured crossover) */
+#define SK_FAST2_MIN_VOICES 131072   /* banks at least this large use two voices per lane (measured crossover) */
 
 struct skred_bank {
   int device;

@@ -80,6 +80,26 @@ __device__ __forceinline__ void wave_sum2_to_lane63(float &l, float &r) {
       : "+v"(l), "+v"(r));
 }
 
+// Two frames at once: four independent chains (L0, R0, L1, R1), so every DPP read already sits three
+// instructions behind the write of its source and no s_nop padding is needed between the stages.
+__device__ __forceinline__ void wave_sum4_to_lane63(float &l0, float &r0, float &l1, float &r1) {
+#define SK_DPP4(CTRL)                                                \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"              \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"              \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " bank_mask:0xf\n\t"              \
+  "v_add_f32_dpp %3, %3, %3 " CTRL " bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t"
+               SK_DPP4("quad_perm:[1,0,3,2] row_mask:0xf")
+               SK_DPP4("quad_perm:[2,3,0,1] row_mask:0xf")
+               SK_DPP4("row_half_mirror row_mask:0xf")
+               SK_DPP4("row_mirror row_mask:0xf")
+               SK_DPP4("row_bcast:15 row_mask:0xa")
+               SK_DPP4("row_bcast:31 row_mask:0xc")
+               "s_nop 1"
+               : "+v"(l0), "+v"(r0), "+v"(l1), "+v"(r1));
+#undef SK_DPP4
+}
+
 // ---------------------------------------------------------------- small exact helpers
 
 // fmodf for x >= 0, y > 0, exact.  x - y is exact for y <= x < 2y (Sterbenz), which is the
@@ -627,7 +647,9 @@ __device__ __forceinline__ float slow_wrap(float ph, float lo, float hi, float s
 
 // One voice, one frame.  STEADY: every lane of the wave sits in its sustain stage.  When !STEADY the
 // caller has set r.tf / r.trf to this frame's envelope clocks.
-template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, int INTERP>
+// TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
+// by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
+template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP>
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r) {
@@ -635,10 +657,15 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
   const float ph0 = r.phase + r.inc;
   const float x = ph0 - r.lo;
   const bool over = ph0 >= r.hi;
-  const bool simple = over && (x < r.span2);            // one loop length past the end: x - span exact
-  const bool in_range = (ph0 >= r.lo) && !over;
-  float ph = simple ? r.lo + (x - r.span) : ph0;
-  if (!(in_range || simple)) ph = slow_wrap(ph0, r.lo, r.hi, r.span);
+  float ph;
+  if (TAME) {
+    ph = over ? r.lo + (x - r.span) : ph0;
+  } else {
+    const bool simple = over && (x < r.span2);          // one loop length past the end: x - span exact
+    const bool in_range = (ph0 >= r.lo) && !over;
+    ph = simple ? r.lo + (x - r.span) : ph0;
+    if (!(in_range || simple)) ph = slow_wrap(ph0, r.lo, r.hi, r.span);
+  }
   r.phase = ph;
   float s = fast_fetch<TAB_LDS, INTERP>(lds_tab, glb_tab, r, ph);
   // ---- biquad (mmf_process, synth.c:349-364) ----
@@ -696,13 +723,29 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
   wave_sum2_to_lane63(l, rr);        \
   if (lane == 63) wsum[wave * SK_CHUNK + (J)] = make_float2(l, rr);
 #endif
+#ifdef SK_ABLATE_REDUCE
+#define SK_REDUCE4_AND_STORE(J) asm volatile("" ::"v"(l0), "v"(r0), "v"(l1), "v"(r1));
+#else
+#define SK_REDUCE4_AND_STORE(J)                      \
+  wave_sum4_to_lane63(l0, r0, l1, r1);               \
+  if (lane == 63) *reinterpret_cast<float4 *>(&wsum[wave * SK_CHUNK + (J)]) = make_float4(l0, r0, l1, r1);
+#endif
 // one frame of the chunk loop: STEADY_ selects the envelope mode, A/B the delay-line roles
 #define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO)                                                        \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, INTERP>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr); \
+    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
     SK_REDUCE_AND_STORE(J)                                                                               \
+  }
+// two steady frames (J even, J+1): delay-line roles swap in between, one 4-chain reduction, one 16-byte store
+#define SK_FAST_PAIR_STEADY(J, TAME_)                                                                    \
+  {                                                                                                      \
+    float l0, r0, l1, r1;                                                                                \
+    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x1, r.x2, r.y1, r.y2, released, lds_tab, glb_tab, l0, r0); \
+    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x2, r.x1, r.y2, r.y1, released, lds_tab, glb_tab, l1, r1); \
+    l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; \
+    SK_REDUCE4_AND_STORE(J)                                                                              \
   }
 #define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2)
 #define SK_FAST_ODD(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1)
@@ -710,7 +753,7 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
   { float t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }
 
 #ifndef SK_FAST_MIN_WAVES
-#define SK_FAST_MIN_WAVES 1      /* waves per SIMD the register allocator must leave room for */
+#define SK_FAST_MIN_WAVES 6      /* waves per SIMD the register allocator must leave room for */
 #endif
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
 __global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
@@ -779,7 +822,8 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_ke
       dead = (r.rw & SKR_FINISHED) || r.amp == 0.0f || (flags & SKF_INERT);
       silent = dead || (flags & SKF_MUTED);
     }
-    const bool any_silent = __any(silent);
+    // wrap can only ever be the simple one (see fast_frame<TAME>): decided once per pass
+    const bool tame = __all(dead || (r.inc >= 0.0f && r.inc <= 0.5f * r.span && r.phase >= r.lo && r.phase <= r.hi));
 
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
@@ -798,12 +842,13 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_ke
         const float tf_first = (float)(d_on + 1);
         steady = __all(dead || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
       }
-      if (!ENV || steady) {
+      if ((!ENV || steady) && tame) {
         int j = 0;
-        for (; j + 1 < cn; j += 2) {
-          SK_FAST_EVEN(j, true)
-          SK_FAST_ODD(j + 1, true)
-        }
+        for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
+        if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
+      } else if (!ENV || steady) {
+        int j = 0;
+        for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, false)
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (exact) {
         int j = 0;
@@ -910,7 +955,7 @@ __device__ __forceinline__ float fast2_env(Fast2Regs &r, int c, bool released) {
   return r.amp[c] * (e * r.vel[c]);
 }
 
-template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, int INTERP>
+template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP>
 __device__ __forceinline__ void fast2_frame(Fast2Regs &r, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
                                             const bool rel0, const bool rel1, const bool silent0,
                                             const bool silent1, const char *lds_tab,
@@ -923,10 +968,15 @@ __device__ __forceinline__ void fast2_frame(Fast2Regs &r, v2f &xn, v2f &xo, v2f 
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const bool over = ph0[c] >= r.hi[c];
-    const bool simple = over && (x[c] < r.span2[c]);
-    const bool in_range = (ph0[c] >= r.lo[c]) && !over;
-    float p = simple ? phw[c] : ph0[c];
-    if (!(in_range || simple)) p = slow_wrap(ph0[c], r.lo[c], r.hi[c], r.span[c]);
+    float p;
+    if (TAME) {
+      p = over ? phw[c] : ph0[c];
+    } else {
+      const bool simple = over && (x[c] < r.span2[c]);
+      const bool in_range = (ph0[c] >= r.lo[c]) && !over;
+      p = simple ? phw[c] : ph0[c];
+      if (!(in_range || simple)) p = slow_wrap(ph0[c], r.lo[c], r.hi[c], r.span[c]);
+    }
     ph[c] = p;
   }
   r.phase = ph;
@@ -968,16 +1018,28 @@ __device__ __forceinline__ void fast2_frame(Fast2Regs &r, v2f &xn, v2f &xo, v2f 
 #define SK_FAST2_FRAME(J, STEADY_, XN, XO, YN, YO)                                                       \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast2_frame<TAB_LDS, FILTER, ENV, STEADY_, INTERP>(r, XN, XO, YN, YO, released[0], released[1],      \
+    fast2_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP>(r, XN, XO, YN, YO, released[0], released[1], \
                                                        silent[0], silent[1], lds_tab, glb_tab, l, rr);   \
     SK_REDUCE_AND_STORE(J)                                                                               \
+  }
+#define SK_FAST2_PAIR_STEADY(J, TAME_)                                                                   \
+  {                                                                                                      \
+    float l0, r0, l1, r1;                                                                                \
+    fast2_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x1, r.x2, r.y1, r.y2, released[0], released[1], \
+                                                           silent[0], silent[1], lds_tab, glb_tab, l0, r0);      \
+    fast2_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x2, r.x1, r.y2, r.y1, released[0], released[1], \
+                                                           silent[0], silent[1], lds_tab, glb_tab, l1, r1);      \
+    SK_REDUCE4_AND_STORE(J)                                                                              \
   }
 #define SK_FAST2_EVEN(J, STEADY_) SK_FAST2_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2)
 #define SK_FAST2_ODD(J, STEADY_) SK_FAST2_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1)
 #define SK_FAST2_FIX_ODD_TAIL() { v2f t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }
 
+#ifndef SK_FAST2_MIN_WAVES
+#define SK_FAST2_MIN_WAVES 4     /* <= 128 VGPRs */
+#endif
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
-__global__ __launch_bounds__(SK_GROUP) void sk_render_fast2_kernel(const sk_render_args_t a) {
+__global__ __launch_bounds__(SK_GROUP, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
   const char *lds_tab = reinterpret_cast<const char *>(lds);
@@ -1046,6 +1108,12 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_fast2_kernel(const sk_rend
     }
     r.span = r.hi - r.lo;
     r.span2 = r.span + r.span;
+    bool tame_lane = true;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      tame_lane = tame_lane && (dead[c] || (r.inc[c] >= 0.0f && r.inc[c] <= 0.5f * r.span[c] &&
+                                            r.phase[c] >= r.lo[c] && r.phase[c] <= r.hi[c]));
+    const bool tame = __all(tame_lane);
 
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
@@ -1066,12 +1134,13 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_fast2_kernel(const sk_rend
         exact = __all(ex);
         steady = __all(st);
       }
-      if (!ENV || steady) {
+      if ((!ENV || steady) && tame) {
         int j = 0;
-        for (; j + 1 < cn; j += 2) {
-          SK_FAST2_EVEN(j, true)
-          SK_FAST2_ODD(j + 1, true)
-        }
+        for (; j + 1 < cn; j += 2) SK_FAST2_PAIR_STEADY(j, true)
+        if (j < cn) { SK_FAST2_EVEN(j, true) SK_FAST2_FIX_ODD_TAIL() }
+      } else if (!ENV || steady) {
+        int j = 0;
+        for (; j + 1 < cn; j += 2) SK_FAST2_PAIR_STEADY(j, false)
         if (j < cn) { SK_FAST2_EVEN(j, true) SK_FAST2_FIX_ODD_TAIL() }
       } else if (exact) {
         int j = 0;

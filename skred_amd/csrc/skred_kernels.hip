@@ -620,18 +620,20 @@ struct FastRegs {
   uint32_t rw;
 };
 
-template <bool TAB_LDS, int INTERP>
+// NOCLAMP: the caller guarantees 0 <= lo <= pos < hi <= table_size (TAME loops), so the reference's
+// index clamps (synth.c:271-272) can never act and are dropped.
+template <bool TAB_LDS, int INTERP, bool NOCLAMP>
 __device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__restrict__ glb_tab,
                                             const FastRegs &r, float pos) {
   int idx = (int)pos;
-  idx = max(min(idx, r.tsize_m1), 0);                        // clamp, synth.c:271-272 (one v_med3_i32)
+  if (!NOCLAMP) idx = max(min(idx, r.tsize_m1), 0);          // clamp, synth.c:271-272
   const char *tab = TAB_LDS ? lds_tab : glb_tab;
   const float a = *reinterpret_cast<const float *>(tab + (r.toff4 + (idx << 2)));
   if (INTERP == 0) return a;
   // linear: oracle/cpu_ref.c:table_fetch.  Every voice of a fast bank wraps (no stopping one-shots).
   int nxt = idx + 1;
   if ((float)nxt >= r.hi) nxt = (int)r.lo;
-  nxt = max(min(nxt, r.tsize_m1), 0);
+  if (!NOCLAMP) nxt = max(min(nxt, r.tsize_m1), 0);
   const float b = *reinterpret_cast<const float *>(tab + (r.toff4 + (nxt << 2)));
   const float frac = pos - (float)idx;
   return a + frac * (b - a);
@@ -667,7 +669,7 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     if (!(in_range || simple)) ph = slow_wrap(ph0, r.lo, r.hi, r.span);
   }
   r.phase = ph;
-  float s = fast_fetch<TAB_LDS, INTERP>(lds_tab, glb_tab, r, ph);
+  float s = fast_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r, ph);
   // ---- biquad (mmf_process, synth.c:349-364) ----
   if (FILTER) {
     // xn/yn: newest delay-line entries, xo/yo: the older ones.  The new values overwrite the OLD
@@ -739,12 +741,12 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     SK_REDUCE_AND_STORE(J)                                                                               \
   }
 // two steady frames (J even, J+1): delay-line roles swap in between, one 4-chain reduction, one 16-byte store
-#define SK_FAST_PAIR_STEADY(J, TAME_)                                                                    \
+#define SK_FAST_PAIR_STEADY(J, TAME_) /* TAME_ loops run only when no live lane is muted: no output select */ \
   {                                                                                                      \
     float l0, r0, l1, r1;                                                                                \
     fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x1, r.x2, r.y1, r.y2, released, lds_tab, glb_tab, l0, r0); \
     fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x2, r.x1, r.y2, r.y1, released, lds_tab, glb_tab, l1, r1); \
-    l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; \
+    if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
 #define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2)
@@ -823,7 +825,19 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_ke
       silent = dead || (flags & SKF_MUTED);
     }
     // wrap can only ever be the simple one (see fast_frame<TAME>): decided once per pass
-    const bool tame = __all(dead || (r.inc >= 0.0f && r.inc <= 0.5f * r.span && r.phase >= r.lo && r.phase <= r.hi));
+    if (dead) {
+      // a skipped voice is never stored back (see the end of the pass): give its lane inert numbers
+      // so that it contributes exact zeros and its table index stays at 0, whatever its real state is
+      r.inc = 0.0f; r.lo = 0.0f; r.hi = 1.0f; r.span = 1.0f; r.span2 = 2.0f; r.phase = 0.0f;
+      r.toff4 = 0; r.tsize_m1 = 0;
+      r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
+      r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
+      r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
+    }
+    // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
+    // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>
+    const bool tame = __all(dead || (r.inc >= 0.0f && r.inc <= 0.5f * r.span && r.phase >= r.lo && r.phase <= r.hi &&
+                                     r.lo >= 0.0f && r.hi <= (float)(r.tsize_m1 + 1))) && !__any(silent && !dead);
 
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
@@ -919,17 +933,17 @@ struct Fast2Regs {
   uint32_t rw[2];
 };
 
-template <bool TAB_LDS, int INTERP>
+template <bool TAB_LDS, int INTERP, bool NOCLAMP>
 __device__ __forceinline__ float fast2_fetch(const char *lds_tab, const char *__restrict__ glb_tab,
                                              int toff4, int tsize_m1, float lo, float hi, float pos) {
   int idx = (int)pos;
-  idx = max(min(idx, tsize_m1), 0);
+  if (!NOCLAMP) idx = max(min(idx, tsize_m1), 0);
   const char *tab = TAB_LDS ? lds_tab : glb_tab;
   const float a = *reinterpret_cast<const float *>(tab + (toff4 + (idx << 2)));
   if (INTERP == 0) return a;
   int nxt = idx + 1;
   if ((float)nxt >= hi) nxt = (int)lo;
-  nxt = max(min(nxt, tsize_m1), 0);
+  if (!NOCLAMP) nxt = max(min(nxt, tsize_m1), 0);
   const float b = *reinterpret_cast<const float *>(tab + (toff4 + (nxt << 2)));
   const float frac = pos - (float)idx;
   return a + frac * (b - a);
@@ -981,8 +995,8 @@ __device__ __forceinline__ void fast2_frame(Fast2Regs &r, v2f &xn, v2f &xo, v2f 
   }
   r.phase = ph;
   v2f s;
-  s.x = fast2_fetch<TAB_LDS, INTERP>(lds_tab, glb_tab, r.toff4[0], r.tsize_m1[0], r.lo.x, r.hi.x, ph.x);
-  s.y = fast2_fetch<TAB_LDS, INTERP>(lds_tab, glb_tab, r.toff4[1], r.tsize_m1[1], r.lo.y, r.hi.y, ph.y);
+  s.x = fast2_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r.toff4[0], r.tsize_m1[0], r.lo.x, r.hi.x, ph.x);
+  s.y = fast2_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r.toff4[1], r.tsize_m1[1], r.lo.y, r.hi.y, ph.y);
   // ---- biquad, packed ----
   if (FILTER) {
     v2f y = r.b0 * s;
@@ -1006,9 +1020,11 @@ __device__ __forceinline__ void fast2_frame(Fast2Regs &r, v2f &xn, v2f &xo, v2f 
   s = s * r.sgain;
   r.sample = s;
   // ---- pan, lane-local sum of the two voices ----
-  v2f so;
-  so.x = silent0 ? 0.0f : s.x;
-  so.y = silent1 ? 0.0f : s.y;
+  v2f so = s;
+  if (!TAME) {          // TAME loops run only when no live lane is muted (dead lanes already yield exact zeros)
+    so.x = silent0 ? 0.0f : s.x;
+    so.y = silent1 ? 0.0f : s.y;
+  }
   const v2f l2 = so * r.pan_l;
   const v2f r2 = so * r.pan_r;
   out_l = l2.x + l2.y;
@@ -1105,14 +1121,23 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST2_MIN_WAVES) void sk_render_fast2_
       }
       dead[c] = (r.rw[c] & SKR_FINISHED) || r.amp[c] == 0.0f || (flags & SKF_INERT);
       silent[c] = dead[c] || (flags & SKF_MUTED);
+      if (dead[c]) {   // never stored back: inert numbers -> exact zeros, table index 0 (see sk_render_fast_kernel)
+        r.inc[c] = 0.0f; r.lo[c] = 0.0f; r.hi[c] = 1.0f; r.phase[c] = 0.0f;
+        r.toff4[c] = 0; r.tsize_m1[c] = 0;
+        r.k[c] = 0.0f; r.sgain[c] = 0.0f; r.amp[c] = 0.0f; r.gain_const[c] = 0.0f;
+        r.b0[c] = r.b1[c] = r.b2[c] = r.a1[c] = r.a2[c] = 0.0f;
+        r.x1[c] = r.x2[c] = r.y1[c] = r.y2[c] = 0.0f;
+        r.pan_l[c] = r.pan_r[c] = 0.0f; r.rw[c] &= ~SKR_ENV_ACTIVE;
+      }
     }
     r.span = r.hi - r.lo;
     r.span2 = r.span + r.span;
     bool tame_lane = true;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
-      tame_lane = tame_lane && (dead[c] || (r.inc[c] >= 0.0f && r.inc[c] <= 0.5f * r.span[c] &&
-                                            r.phase[c] >= r.lo[c] && r.phase[c] <= r.hi[c]));
+      tame_lane = tame_lane && !(silent[c] && !dead[c]) &&
+                  (dead[c] || (r.inc[c] >= 0.0f && r.inc[c] <= 0.5f * r.span[c] && r.phase[c] >= r.lo[c] &&
+                               r.phase[c] <= r.hi[c] && r.lo[c] >= 0.0f && r.hi[c] <= (float)(r.tsize_m1[c] + 1)));
     const bool tame = __all(tame_lane);
 
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {

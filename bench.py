@@ -9,8 +9,11 @@ timed region starts; the output frames stay in HBM (a real-time host would copy 
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3|c4] [--frames F]
 
-N>1 is launched by the driver through torch.distributed.run, one rank per GPU; voices are
-block-partitioned over ranks, the only collective is one reduce of float[F][2].
+Default workload: the BASELINE config-3 bank -- 2^20 voices (mixed notamy LUTs + biquad + ADSR) per
+GPU, F = 512 frames per launch (the reference's callback size, skred.h:12), 48 kHz.  N>1 is
+launched by the driver through torch.distributed.run, one rank per GPU; every GPU holds a bank of
+that size (weak scaling), voices never cross GPUs, the only collective is one reduce of float[F][2].
+`--scaling strong` splits ONE 2^20-voice bank over the GPUs instead (the literal config 3).
 """
 from __future__ import annotations
 
@@ -28,7 +31,7 @@ HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s sp
 STATE_READ, STATE_WRITE = 240, 52   # bytes per voice per launch, SURVEY §8(d)
 
 WORKLOADS = {
-    #        recipe  total voices  interp  table bytes gathered from HBM-resident tables / voice-sample
+    #        recipe  voices   interp  table bytes gathered from HBM-resident tables per voice-sample
     "c1": ("c1", 4096, 0, 0.0),
     "c2": ("c2", 65536, 0, 0.0),
     "c3": ("c2", 1048576, 0, 0.0),
@@ -37,14 +40,16 @@ WORKLOADS = {
 DESCR = {
     "c1": "C1: 4096 voices, sine LUT + ADSR + amp smoother, 48 kHz, fp32",
     "c2": "C2: 65536 voices, mixed notamy sine/triangle/impulse LUTs + per-voice biquad + ADSR, 48 kHz, fp32",
-    "c3": "C3 bank: 1048576 voices (C2 recipe: mixed notamy LUTs + biquad + ADSR), block-partitioned over the GPUs, 48 kHz, fp32",
+    "c3": "C3 bank: 1048576 voices, mixed notamy sine/triangle/impulse LUTs + per-voice biquad + ADSR + amp smoother, 48 kHz, fp32",
     "c4": "C4: 262144 PCM voices (pcm_map geometry, synthetic samples), linear interpolation, 48 kHz, fp32",
 }
+KERNELS = {0: "sk_render_kernel", 1: "sk_render_fast_kernel", 2: "sk_render_mod_kernel", 3: "sk_render_fast2_kernel"}
 
 
 def cpu_baseline(recipe, interp, seconds_per_leg=8.0):
     """The oracle (oracle/cpu_ref.c, bit-pinned to the reference) timed on this box's host cores,
-    compiled with the reference's own flags (-O3 -march=native, reference Makefile:23-28)."""
+    compiled with the reference's own flags (-O3 -march=native, reference Makefile:23-28).  It is the
+    CHECKER being timed as a baseline, never the thing measured above."""
     from oracle import cpuref
     from skred_amd import banks
     cores = os.cpu_count() or 1
@@ -66,8 +71,20 @@ def cpu_baseline(recipe, interp, seconds_per_leg=8.0):
     many = nm * frames / (time.perf_counter() - t)
     return {"value": many, "unit": "voice-samples/s", "cores": cores, "kind": "port",
             "value_1thread": one,
-            "sample": f"oracle/cpu_ref.c -O3 -march=native on the same recipe: {n1} voices x {frames} frames on 1 thread, "
-                      f"{nm} voices x {frames} frames on {cores} threads (static voice partition)"}
+            "sample": f"oracle/cpu_ref.c -O3 -march=native on the same recipe: {n1} voices x {frames} frames on 1 thread "
+                      f"(the reference is single-threaded), {nm} voices x {frames} frames on {cores} threads (static voice partition)"}
+
+
+def pmc_traffic(workload, voices, frames):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), when
+    one exists for exactly this workload shape; bench.py itself cannot collect PMC counters."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
+        if d["frames_per_launch"] == frames and d["voices"] == voices:
+            return d["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -77,10 +94,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=512, help="frames per launch (reference callback size, skred.h:12)")
-    ap.add_argument("--voices", type=int, default=0, help="override the total voice count")
+    ap.add_argument("--voices", type=int, default=0, help="override the per-bank voice count")
     ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
                     help="weak (default): every GPU gets a whole bank of the workload size; strong: one bank is split over the GPUs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-low-latency", action="store_true", help="skip the secondary F=64 measurement")
     ap.add_argument("--fast2-min-voices", type=int, default=-1,
                     help="override the bank size from which the two-voices-per-lane kernel is used (-1: library default)")
     a = ap.parse_args()
@@ -91,7 +109,6 @@ def main():
     if world != a.gpus and world > 1:
         a.gpus = world
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -106,18 +123,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    recipe, total, interp, gather_bytes = WORKLOADS[a.workload]
+    recipe, bank_voices, interp, gather_bytes = WORKLOADS[a.workload]
     if a.voices:
-        total = a.voices
-    if a.scaling == "weak":
-        total *= world
+        bank_voices = a.voices
+    total = bank_voices * world if a.scaling == "weak" else bank_voices
     sh = ShardedRender(total, rank, world)
-    lo, hi = sh.lo, sh.hi
     F = a.frames
 
-    full, tables, g = banks.RECIPES[recipe](total)
-    shard = full.take(slice(lo, hi)) if world > 1 else full
-    del full
+    # seeded banks: weak scaling gives every rank its own bank of the workload size (seed + rank);
+    # strong scaling generates the one global bank on every rank and keeps this rank's block
+    if a.scaling == "weak":
+        shard, tables, g = banks.RECIPES[recipe](bank_voices, seed=banks.SEED + rank)
+    else:
+        full, tables, g = banks.RECIPES[recipe](total)
+        shard = full.take(slice(sh.lo, sh.hi)) if world > 1 else full
+        del full
+    assert shard.n == sh.n_local
     db = device.DeviceBank(shard.n, local)
     db.set_tables(tables)
     db.upload(shard)
@@ -125,18 +146,7 @@ def main():
     if a.fast2_min_voices >= 0:
         db.fast2_min_voices(a.fast2_min_voices)
 
-    partial = torch.zeros(F, 2, device=dev, dtype=torch.float32)
-    out = torch.zeros(F, 2, device=dev, dtype=torch.float32)
     stream = torch.cuda.current_stream().cuda_stream
-
-    def render_partial(p):
-        db.render(F, p.data_ptr(), 0, interp, stream)
-
-    def master(p, o):
-        db.master(p.data_ptr(), F, o.data_ptr(), 2, stream)
-
-    def step():   # render -> (RCCL reduce of 8*F bytes over xGMI when world > 1) -> master on rank 0
-        sh.step(render_partial, master, partial, out)
 
     def fence():
         torch.cuda.synchronize()
@@ -144,48 +154,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    db.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    k_mean_ms, k_min_ms, k_cnt = db.timing_summary()
-    finite = bool(torch.isfinite(out).all().item()) if rank == 0 else True
+    def timed(frames, steps, warmup):
+        partial = torch.zeros(frames, 2, device=dev, dtype=torch.float32)
+        out = torch.zeros(frames, 2, device=dev, dtype=torch.float32)
 
+        def render_partial(p):
+            db.render(frames, p.data_ptr(), 0, interp, stream)
+
+        def master(p, o):
+            db.master(p.data_ptr(), frames, o.data_ptr(), 2, stream)
+
+        for _ in range(warmup):
+            sh.step(render_partial, master, partial, out)   # render -> (RCCL reduce, N>1) -> master on rank 0
+        fence()
+        db.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sh.step(render_partial, master, partial, out)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        k_mean, k_min, k_cnt = db.timing_summary()
+        finite = bool(torch.isfinite(out).all().item()) if rank == 0 else True
+        return dt, k_mean, k_min, k_cnt, finite
+
+    def roofline(frames, k_mean, k_min, k_cnt):
+        B = gather_bytes + (STATE_READ + STATE_WRITE) / frames       # algorithmic bytes / voice-sample
+        launch_bytes = B * shard.n * frames
+        achieved = launch_bytes / (k_mean * 1e-3)
+        return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(a.workload, shard.n, frames),
+                "kernel": KERNELS.get(db.last_kernel(), "?"), "frames_per_launch": frames,
+                "kernel_ms_mean": k_mean, "kernel_ms_min": k_min, "launches_timed": k_cnt,
+                "algorithmic_bytes_per_voice_sample": B, "algorithmic_bytes_per_launch": launch_bytes,
+                "kernel_voice_samples_per_s": shard.n * frames / (k_mean * 1e-3)}
+
+    dt, k_mean, k_min, k_cnt, finite = timed(F, a.steps, a.warmup)
+
+    res = None
     if rank == 0:
         value = total * F * a.steps / dt
-        B = gather_bytes + (STATE_READ + STATE_WRITE) / F          # algorithmic bytes / voice-sample
-        launch_bytes = B * shard.n * F
-        achieved = launch_bytes / (k_mean_ms * 1e-3)
+        rl = roofline(F, k_mean, k_min, k_cnt)
+        rl["note"] = ("LUTs are LDS-resident and the recurrences live in registers, so compulsory HBM traffic is one "
+                      "state sweep per launch: at F=512 the kernel is bound by fp32 VALU issue (91% VALU-busy, "
+                      "profiles/r01_v3_c3_pmc_summary.json), not by HBM; the HBM fraction grows as F shrinks (low_latency)")
+        where = ""
+        if world > 1:
+            where = f"; one such bank per GPU ({world} GPUs)" if a.scaling == "weak" else f"; split over {world} GPUs"
         res = {
             "metric": "voice-samples/s", "value": value, "unit": "voice-samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": DESCR[a.workload], "voices_total": total, "voices_per_gpu": shard.n,
+            "config": {"workload": DESCR[a.workload] + where,
+                       "voices_total": total, "voices_per_gpu": shard.n,
                        "frames_per_launch": F, "sample_rate": 48000, "interp": "linear" if interp else "truncate",
-                       "parallelism": f"voices block-partitioned over {world} GPU(s)" + ("; RCCL reduce(sum) of float[F][2] per launch" if world > 1 else ""),
+                       "parallelism": f"voices block-partitioned over {world} GPU(s)" + ("; one RCCL reduce(sum) of float[F][2] per launch" if world > 1 else ""),
                        "seed": "0x5EED"},
             "realtime_factor_48k": value / (total * 48000.0),
             "output_finite": finite,
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": {0: "sk_render_kernel", 1: "sk_render_fast_kernel", 2: "sk_render_mod_kernel",
-                                    3: "sk_render_fast2_kernel"}.get(db.last_kernel(), "?"), "kernel_ms_mean": k_mean_ms, "kernel_ms_min": k_min_ms,
-                         "launches_timed": k_cnt, "algorithmic_bytes_per_voice_sample": B,
-                         "algorithmic_bytes_per_launch": launch_bytes,
-                         "kernel_voice_samples_per_s": shard.n * F / (k_mean_ms * 1e-3),
-                         "note": "LUTs are LDS-resident and the recurrences live in registers, so compulsory HBM traffic is "
-                                 "only the per-launch state sweep: the kernel is bound by fp32 VALU issue, not HBM (SURVEY §8d)"},
+            "roofline": rl,
         }
+    # secondary operating point: short callbacks (F = 64 frames = 1.33 ms at 48 kHz), where the per-launch
+    # state sweep dominates and the kernel approaches the HBM roofline (single GPU only)
+    if world == 1 and not a.no_low_latency and F != 64:
+        k2 = max(50, a.steps)
+        dt2, km2, kn2, kc2, _ = timed(64, k2, 20)
+        ll = roofline(64, km2, kn2, kc2)
+        ll["value"] = total * 64 * k2 / dt2
+        ll["realtime_factor_48k"] = ll["value"] / (total * 48000.0)
+        res["low_latency"] = ll
+    if rank == 0:
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(recipe, interp)
         print(json.dumps(res), flush=True)

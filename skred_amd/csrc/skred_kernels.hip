@@ -607,6 +607,10 @@ __global__ __launch_bounds__(64) void sk_render_mod_kernel(const sk_render_args_
 // What remains per frame is ~45 VALU instructions instead of ~107, with almost no scalar
 // branch bookkeeping.
 
+// two adjacent table samples, fetched with one 4-byte-aligned 8-byte access (global_load_dwordx2 /
+// ds_read2_b32).  The pool is padded by the host so that reading one float past any table is in bounds.
+struct __attribute__((packed, aligned(4))) tap_pair_t { float a, b; };
+
 struct FastRegs {
   // launch constants
   float inc, lo, hi, span, span2, amp;
@@ -628,13 +632,18 @@ __device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__r
   int idx = (int)pos;
   if (!NOCLAMP) idx = max(min(idx, r.tsize_m1), 0);          // clamp, synth.c:271-272
   const char *tab = TAB_LDS ? lds_tab : glb_tab;
-  const float a = *reinterpret_cast<const float *>(tab + (r.toff4 + (idx << 2)));
-  if (INTERP == 0) return a;
+  if (INTERP == 0) return *reinterpret_cast<const float *>(tab + (r.toff4 + (idx << 2)));
   // linear: oracle/cpu_ref.c:table_fetch.  Every voice of a fast bank wraps (no stopping one-shots).
+  // Both taps come from ONE 8-byte gather (4-byte aligned pair) -- the neighbour is idx+1 except on
+  // the last sample before the loop end, where a second (rare) gather fetches the loop start.
+  const tap_pair_t pr = *reinterpret_cast<const tap_pair_t *>(tab + (r.toff4 + (idx << 2)));
+  const float a = pr.a;
+  float b = pr.b;
   int nxt = idx + 1;
-  if ((float)nxt >= r.hi) nxt = (int)r.lo;
-  if (!NOCLAMP) nxt = max(min(nxt, r.tsize_m1), 0);
-  const float b = *reinterpret_cast<const float *>(tab + (r.toff4 + (nxt << 2)));
+  bool special = (float)nxt >= r.hi;
+  if (special) nxt = (int)r.lo;
+  if (!NOCLAMP) { const int c = max(min(nxt, r.tsize_m1), 0); special = special || (c != nxt); nxt = c; }
+  if (special) b = *reinterpret_cast<const float *>(tab + (r.toff4 + (nxt << 2)));
   const float frac = pos - (float)idx;
   return a + frac * (b - a);
 }
@@ -939,12 +948,15 @@ __device__ __forceinline__ float fast2_fetch(const char *lds_tab, const char *__
   int idx = (int)pos;
   if (!NOCLAMP) idx = max(min(idx, tsize_m1), 0);
   const char *tab = TAB_LDS ? lds_tab : glb_tab;
-  const float a = *reinterpret_cast<const float *>(tab + (toff4 + (idx << 2)));
-  if (INTERP == 0) return a;
+  if (INTERP == 0) return *reinterpret_cast<const float *>(tab + (toff4 + (idx << 2)));
+  const tap_pair_t pr = *reinterpret_cast<const tap_pair_t *>(tab + (toff4 + (idx << 2)));   // see fast_fetch
+  const float a = pr.a;
+  float b = pr.b;
   int nxt = idx + 1;
-  if ((float)nxt >= hi) nxt = (int)lo;
-  if (!NOCLAMP) nxt = max(min(nxt, tsize_m1), 0);
-  const float b = *reinterpret_cast<const float *>(tab + (toff4 + (nxt << 2)));
+  bool special = (float)nxt >= hi;
+  if (special) nxt = (int)lo;
+  if (!NOCLAMP) { const int c = max(min(nxt, tsize_m1), 0); special = special || (c != nxt); nxt = c; }
+  if (special) b = *reinterpret_cast<const float *>(tab + (toff4 + (nxt << 2)));
   const float frac = pos - (float)idx;
   return a + frac * (b - a);
 }

@@ -52,7 +52,8 @@ def cpu_baseline(recipe, interp, seconds_per_leg=8.0):
     CHECKER being timed as a baseline, never the thing measured above."""
     from oracle import cpuref
     from skred_amd import banks
-    cores = os.cpu_count() or 1
+    # a 1-GPU box grants a CPU share of 16 cores whatever os.cpu_count() says: use at most that many threads
+    cores = max(1, min(os.cpu_count() or 1, int(os.environ.get("SKRED_CPU_THREADS", "16"))))
     n1 = 4096
     bank, tables, g = banks.RECIPES[recipe](n1)
     cpuref.lib(fast=True)

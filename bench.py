@@ -100,6 +100,9 @@ def main():
                     help="weak (default): every GPU gets a whole bank of the workload size; strong: one bank is split over the GPUs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-low-latency", action="store_true", help="skip the secondary F=64 measurement")
+    ap.add_argument("--backend", default=os.environ.get("SKRED_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, default).  gloo is only for rehearsing the N>1 code path on a box with fewer "
+                         "GPUs than ranks (ranks then share devices and the partial mix is reduced through host memory)")
     ap.add_argument("--fast2-min-voices", type=int, default=-1,
                     help="override the bank size from which the two-voices-per-lane kernel is used (-1: library default)")
     a = ap.parse_args()
@@ -118,11 +121,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and local >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
+    local = local % ndev                       # gloo rehearsal: ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     recipe, bank_voices, interp, gather_bytes = WORKLOADS[a.workload]
     if a.voices:
@@ -165,17 +175,35 @@ def main():
         def master(p, o):
             db.master(p.data_ptr(), frames, o.data_ptr(), 2, stream)
 
+        if world > 1 and a.backend == "gloo":     # rehearsal only: reduce through host memory
+            host = torch.zeros(frames, 2, dtype=torch.float32)
+            dev_render = render_partial
+
+            def render_partial(p):                 # noqa: F811
+                dev_render(partial)
+                torch.cuda.synchronize()
+                p.copy_(partial)
+
+            dev_master = master
+
+            def master(p, o):                      # noqa: F811
+                partial.copy_(p)
+                dev_master(partial, o)
+
+            red = host
+        else:
+            red = partial
         for _ in range(warmup):
-            sh.step(render_partial, master, partial, out)   # render -> (RCCL reduce, N>1) -> master on rank 0
+            sh.step(render_partial, master, red, out)       # render -> (RCCL reduce, N>1) -> master on rank 0
         fence()
         db.timing_reset()
         t0 = time.perf_counter()
         for _ in range(steps):
-            sh.step(render_partial, master, partial, out)
+            sh.step(render_partial, master, red, out)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         k_mean, k_min, k_cnt = db.timing_summary()
@@ -210,7 +238,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": DESCR[a.workload] + where,
+            "config": {"workload": DESCR[a.workload] + (f" [voices overridden: {bank_voices} per bank]" if a.voices else "") + where,
                        "voices_total": total, "voices_per_gpu": shard.n,
                        "frames_per_launch": F, "sample_rate": 48000, "interp": "linear" if interp else "truncate",
                        "parallelism": f"voices block-partitioned over {world} GPU(s)" + ("; one RCCL reduce(sum) of float[F][2] per launch" if world > 1 else ""),

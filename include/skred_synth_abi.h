@@ -184,6 +184,12 @@ int   voice_show_all(int voice, int verbose);
 char *synth_stats(void);
 void  synth_voice_bench(int voice);
 
+/* ---- `.sk` patch subset -> voice state (skred_patch.c; SURVEY 8f "next" #1) ---- */
+typedef struct { int voice; int unsupported; int errors; } skred_patch_t;
+void skred_patch_init(skred_patch_t *p);
+int  skred_patch_line(skred_patch_t *p, const char *line);  /* returns unsupported tokens met in this line */
+int  skred_patch_load(const char *path, skred_patch_t *p);  /* -1: cannot open; else total unsupported tokens */
+
 /* ---- additions of this build (no counterpart in the reference) ---- */
 int         skred_synth_last_rc(void);          /* SKRED_E_* of the most recent synth() call */
 const char *skred_synth_last_error(void);

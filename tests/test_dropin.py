@@ -82,3 +82,21 @@ def test_dropin_render_matches_reference(case):
         assert s["state_out"] == {}, s
         assert s["mix_rms_err"] <= 1e-5, s
         assert s["count_out_equal"], s
+
+
+@pytest.mark.gpu
+def test_sk_render_config0_wav_matches_reference(tmp_path):
+    """BASELINE config 0 end to end on the GPU: the C harness loads 0.sk with our patch reader, calls
+    synth() in 512-frame callbacks and writes a float WAV; its samples equal the reference's 1 s render
+    (one audible voice, so even the mix is bit-exact)."""
+    import numpy as np
+    exe = os.path.join(ROOT, "skred_amd", "sk_render")
+    wav = str(tmp_path / "c0.wav")
+    out = subprocess.run([exe, "--patch-0sk", "--seconds", "1", wav], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    raw = open(wav, "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE"
+    frames = np.frombuffer(raw[44:], dtype="<f4").reshape(-1, 2)
+    gold = gio.load("c0_0sk").segments[0].mix
+    assert frames.shape == gold.shape
+    assert gio.bits_equal(frames, gold)

@@ -1,0 +1,64 @@
+"""`.sk` subset loader (skred_amd/csrc/skred_patch.c) against the reference's own
+wire(): every reference patch that stays inside the voice subset must leave all 64 voices in
+bit-identical state.  Needs the reference tree (patch files + compiled oracle/_ref); skipped elsewhere."""
+import ctypes as C
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("SKRED_REFERENCE", "/root/reference")
+
+
+def run(n, mode):
+    out = subprocess.run([sys.executable, os.path.join(HERE, "patch_replay.py"), str(n), mode],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+def test_inline_patch_lines():
+    """The three lines of 0.sk through our loader: voices 0 and 1 as BASELINE config 0 describes them."""
+    L = C.CDLL(os.path.join(ROOT, "skred_amd", "libskred_synth.so"))
+    L.wave_table_init()
+    L.voice_init()
+
+    class Patch(C.Structure):
+        _fields_ = [("voice", C.c_int), ("unsupported", C.c_int), ("errors", C.c_int)]
+    p = Patch()
+    L.skred_patch_init(C.byref(p))
+    for line in (b"S100", b"v0 w0 f440 a4 F1,10", b"v1 w0 f1 a50 m1  # modulator, muted", b"x0 {v1 l1}"):
+        L.skred_patch_line(C.byref(p), line)
+    amp = (C.c_float * 64).in_dll(L, "voice_amp")
+    fm = (C.c_int * 64).in_dll(L, "voice_freq_mod_osc")
+    mute = (C.c_int * 64).in_dll(L, "voice_disconnect")
+    assert (amp[0], amp[1], fm[0], mute[1]) == (4.0, 50.0, 1, 1)
+    assert p.unsupported == 2 and p.voice == 1          # the sequencer atom and its {string}
+
+
+def test_reference_patches_in_subset_match_reference_wire():
+    if not (os.path.isdir(REF) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libskred_ref.so"))):
+        pytest.skip("needs the reference tree")
+    patches = sorted(int(os.path.basename(f)[:-3]) for f in glob.glob(os.path.join(REF, "*.sk")))
+    checked, skipped = [], []
+    import re
+    for n in patches:
+        text = open(os.path.join(REF, f"{n}.sk")).read()
+        if any(32 <= int(w) <= 63 for w in re.findall(r"(?<![A-Za-z])w(\d+)", text)):
+            skipped.append((n, "Korg table data (retro/korg.h) is not bundled with this build"))
+            continue
+        mine = run(n, "mine")
+        if mine["unsupported"] != 0:
+            skipped.append((n, "outside the voice subset"))
+            continue
+        ref = run(n, "ref")
+        diff = {k: (mine["digest"][k], ref["digest"][k]) for k in ref["digest"] if mine["digest"][k] != ref["digest"][k]}
+        assert not diff, f"patch {n}.sk: state differs in {sorted(diff)}"
+        checked.append(n)
+    assert len(checked) >= 8, (checked, skipped)
+    print(f"patches identical to reference wire(): {checked}; outside the subset: {skipped}")

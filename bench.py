@@ -100,6 +100,8 @@ def main():
                     help="weak (default): every GPU gets a whole bank of the workload size; strong: one bank is split over the GPUs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-low-latency", action="store_true", help="skip the secondary F=64 measurement")
+    ap.add_argument("--no-recipe-warmup", action="store_true",
+                    help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
     ap.add_argument("--backend", default=os.environ.get("SKRED_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default).  gloo is only for rehearsing the N>1 code path on a box with fewer "
                          "GPUs than ranks (ranks then share devices and the partial mix is reduced through host memory)")
@@ -221,6 +223,17 @@ def main():
                 "algorithmic_bytes_per_voice_sample": B, "algorithmic_bytes_per_launch": launch_bytes,
                 "kernel_voice_samples_per_s": shard.n * frames / (k_mean * 1e-3)}
 
+    # BASELINE.md §4 / SURVEY §8(d): "render 1 s after 0.1 s warm-up".  The recipe's note-ons are staggered over
+    # the last second and attack+decay last 0.11 s, so those first 5280 frames are rendered here, untimed and
+    # independent of --warmup: the timed region then starts with every voice in its sustain stage, as the
+    # recipe intends (launches with voices still in attack/decay are ~3.5x slower: DESIGN.md §4).
+    recipe_warmup_frames = 0
+    if not a.no_recipe_warmup:
+        scratch = torch.zeros(F, 2, device=dev, dtype=torch.float32)
+        while recipe_warmup_frames < int(0.11 * 48000):
+            db.render(F, scratch.data_ptr(), 0, interp, stream)
+            recipe_warmup_frames += F
+        fence()
     dt, k_mean, k_min, k_cnt, finite = timed(F, a.steps, a.warmup)
 
     res = None
@@ -242,7 +255,7 @@ def main():
                        "voices_total": total, "voices_per_gpu": shard.n,
                        "frames_per_launch": F, "sample_rate": 48000, "interp": "linear" if interp else "truncate",
                        "parallelism": f"voices block-partitioned over {world} GPU(s)" + ("; one RCCL reduce(sum) of float[F][2] per launch" if world > 1 else ""),
-                       "seed": "0x5EED"},
+                       "seed": "0x5EED", "recipe_warmup_frames": recipe_warmup_frames},
             "realtime_factor_48k": value / (total * 48000.0),
             "output_finite": finite,
             "roofline": rl,

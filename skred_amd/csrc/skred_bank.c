@@ -48,6 +48,7 @@ struct skred_bank {
   int8_t *h_mod;              /* [4][n_padded] modulator lane inside the 64-voice group (fm, am, pm, cz) or -1 */
   int *h_level;               /* [n_padded] dependency level of each voice (modulated banks) */
   int *d_level;
+  int32_t *d_group_flag;      /* per 512-voice group: deferred to sk_render_env2_kernel */
   int max_level;
   int mod_escapes;            /* some modulator lies outside its carrier's 64-voice group */
   int class_dirty;
@@ -155,6 +156,8 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   memset(b->h_mod, -1, (size_t)b->n_padded * 4);
   HIP_TRY(hipMalloc((void **)&b->d_level, (size_t)b->n_padded * sizeof(int)));
   HIP_TRY(hipMemset(b->d_level, 0, (size_t)b->n_padded * sizeof(int)));
+  HIP_TRY(hipMalloc((void **)&b->d_group_flag, (size_t)(b->n_groups / 2 + 1) * sizeof(int32_t)));
+  HIP_TRY(hipMemset(b->d_group_flag, 0, (size_t)(b->n_groups / 2 + 1) * sizeof(int32_t)));
   b->class_dirty = 1;
   HIP_TRY(hipMalloc((void **)&b->d_gain_state, 4 * sizeof(float)));
   HIP_TRY(hipMemset(b->d_gain_state, 0, 4 * sizeof(float)));
@@ -186,6 +189,7 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_redtmp) hipFree(b->d_redtmp);
   free(b->h_class); free(b->h_mod); free(b->h_level);
   if (b->d_level) hipFree(b->d_level);
+  if (b->d_group_flag) hipFree(b->d_group_flag);
   for (int i = 0; i < SK_TIMING_RING; i++) {
     if (b->ev0[i]) hipEventDestroy(b->ev0[i]);
     if (b->ev1[i]) hipEventDestroy(b->ev1[i]);
@@ -466,6 +470,7 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
   a.tables = b->d_tables;
   a.partial = b->d_partial;
   a.stems = d_stems;
+  a.group_flag = b->d_group_flag;
   a.count0 = b->g.synth_sample_count;
   a.rng0 = b->g.noise_rng;
   a.n_voices = b->n_voices;

@@ -87,6 +87,7 @@ typedef struct {
   const float *tables;     /* HBM pool */
   float *partial;          /* [n_workgroups][num_frames][2] pre-master partial sums */
   float *stems;            /* [num_frames][n_voices][2] or NULL */
+  int32_t *group_flag;     /* [n_groups/2]: 1 = this 512-voice group has envelopes in motion (fast2 -> env2 hand-over) */
   uint64_t count0;         /* synth_sample_count before the first frame */
   uint64_t rng0;           /* noise LCG state before the first frame */
   int32_t n_voices;        /* real voices (stems indexing) */

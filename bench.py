@@ -70,10 +70,46 @@ def cpu_baseline(recipe, interp, seconds_per_leg=8.0):
     t = time.perf_counter()
     cpuref.render_mt(bank_m, g_m, tables_m, frames, cores, interp, fast=True)
     many = nm * frames / (time.perf_counter() - t)
+    ref = reference_rate()
     return {"value": many, "unit": "voice-samples/s", "cores": cores, "kind": "port",
-            "value_1thread": one,
+            "value_1thread": one, "reference_1thread": ref,
             "sample": f"oracle/cpu_ref.c -O3 -march=native on the same recipe: {n1} voices x {frames} frames on 1 thread "
                       f"(the reference is single-threaded), {nm} voices x {frames} frames on {cores} threads (static voice partition)"}
+
+
+def reference_rate(seconds=3.0):
+    """The UNMODIFIED reference synth() (oracle/_ref/libskred_ref.so, compiled from /root/reference by
+    oracle/Makefile with -O2 -ffp-contract=off; the .so travels to the GPU box, the sources do not) on its
+    own maximum of 64 voices: sine/triangle/square tables + biquad + ADSR, one thread, 512-frame callbacks.
+    Runs in a child process (the library prints and keeps static state).  None when the .so is absent."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libskred_ref.so")
+    if not os.path.exists(so):
+        return None
+    code = r"""
+import ctypes, time, sys
+import numpy as np
+L = ctypes.CDLL(sys.argv[1]); L.ref_boot()
+for v in range(64):
+    f = 55.0 * 2 ** (v / 12.0)
+    L.ref_wire(("v%d w%d f%.3f a1 p%.2f J%d K%.1f Q1.2 t0.01,0.1,0.7,0.2 l1" % (v, [0, 4, 1][v % 3], f, (v % 9) / 4.0 - 1.0, 1 + v % 4, 300.0 + 40 * v)).encode())
+out = np.zeros((512, 2), np.float32)
+p = out.ctypes.data_as(ctypes.c_void_p)
+for _ in range(200): L.ref_callback(p, 512)
+n, t0 = 0, time.perf_counter()
+while time.perf_counter() - t0 < float(sys.argv[2]):
+    for _ in range(100): L.ref_callback(p, 512)
+    n += 100
+print("RATE", 64 * 512 * n / (time.perf_counter() - t0))
+"""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", code, so, str(seconds)], capture_output=True, text=True, timeout=60)
+        rate = [float(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("RATE ")]
+        return {"value": rate[-1], "unit": "voice-samples/s", "cores": 1,
+                "what": "unmodified reference synth()+seq() via its own synth_callback, 64 voices (VOICE_MAX), "
+                        "oracle/_ref/libskred_ref.so (-O2 -ffp-contract=off)"} if rate else None
+    except Exception:
+        return None
 
 
 def pmc_traffic(workload, voices, frames):

@@ -1045,12 +1045,9 @@ __device__ __forceinline__ float fast2_env_general(Fast2Regs &r, Env2Regs &e, in
 
 // EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
 // with the short exact division; 2 general.  TAME: see fast_frame.
-template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP>
-__device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
-                                            const bool rel0, const bool rel1, const bool silent0,
-                                            const bool silent1, const char *lds_tab,
-                                            const char *__restrict__ glb_tab, float &out_l, float &out_r) {
-  // ---- oscillator: packed add / wrap candidate, per-voice range tests ----
+// Oscillator half of a frame: advance both phases, wrap, fetch the two table samples.
+template <bool TAB_LDS, bool TAME, int INTERP>
+__device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, const char *__restrict__ glb_tab) {
   const v2f ph0 = r.phase + r.inc;
   const v2f x = ph0 - r.lo;
   const v2f phw = r.lo + (x - r.span);
@@ -1073,6 +1070,16 @@ __device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, 
   v2f s;
   s.x = fast2_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r.toff4[0], r.tsize_m1[0], r.lo.x, r.hi.x, ph.x);
   s.y = fast2_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r.toff4[1], r.tsize_m1[1], r.lo.y, r.hi.y, ph.y);
+  return s;
+}
+
+// The rest of the frame: biquad, envelope/gain, smoother, pan, lane-local sum of the two voices.
+// EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
+// with the short exact division; 2 general.  TAME: see fast_frame.
+template <bool FILTER, int EM, bool TAME>
+__device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
+                                           const bool rel0, const bool rel1, const bool silent0,
+                                           const bool silent1, float &out_l, float &out_r) {
   // ---- biquad, packed ----
   if (FILTER) {
     v2f y = r.b0 * s;
@@ -1120,6 +1127,15 @@ __device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, 
   out_r = r2.x + r2.y;
 }
 
+template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP>
+__device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
+                                            const bool rel0, const bool rel1, const bool silent0,
+                                            const bool silent1, const char *lds_tab,
+                                            const char *__restrict__ glb_tab, float &out_l, float &out_r) {
+  const v2f s = fast2_osc<TAB_LDS, TAME, INTERP>(r, lds_tab, glb_tab);
+  fast2_post<FILTER, EM, TAME>(r, e, s, xn, xo, yn, yo, rel0, rel1, silent0, silent1, out_l, out_r);
+}
+
 #define SK_F2_ARGS released[0], released[1], silent[0], silent[1], lds_tab, glb_tab
 // one frame (J) / two frames (J, J+1; delay-line roles swap in between, one 4-chain DPP reduction)
 #define SK_FAST2_ONE(J, EM_, TAME_)                                                                      \
@@ -1148,10 +1164,15 @@ __device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #define SK_FAST2_LDS_BLOCK(J, EM_)                                                                       \
   {                                                                                                      \
+    /* software pipeline: the table gather of the NEXT frame is issued before the biquad/gain chain of the   \
+       current one (the source order matters: the compiler may not move an LDS read above the tile write) */  \
+    v2f s0_ = fast2_osc<TAB_LDS, true, INTERP>(r, lds_tab, glb_tab);                                      \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
-      fast2_frame<TAB_LDS, FILTER, EM_, true, INTERP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0); \
-      fast2_frame<TAB_LDS, FILTER, EM_, true, INTERP>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1); \
+      const v2f s1_ = fast2_osc<TAB_LDS, true, INTERP>(r, lds_tab, glb_tab);                              \
+      fast2_post<FILTER, EM_, true>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
+      if (q_ < 6) s0_ = fast2_osc<TAB_LDS, true, INTERP>(r, lds_tab, glb_tab);                            \
+      fast2_post<FILTER, EM_, true>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
       xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
       xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
     }                                                                                                    \

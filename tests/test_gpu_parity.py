@@ -452,3 +452,56 @@ def test_random_feature_mix_vs_oracle(dev, seed):
     assert gl.noise_rng == ref_g.noise_rng
     if np.isfinite(ref_mix).all():
         assert rel_rms(mix, ref_mix) <= 1e-5
+
+
+def test_non_finite_phase_increments(dev):
+    """osc_next's !isfinite() branch (synth.c:228-232): phase resets to 0, a one-shot voice finishes, the frame
+    outputs table-independent 0 -- NaN / +-inf increments and a NaN phase, on cyclic and one-shot voices."""
+    gold = gio.load("c4_pcm_oneshot")
+    seg = gold.segments[0]
+    b = seg.bank_in.copy()
+    b["voice_amp"] = 1.0
+    b["voice_finished"] = 0
+    b["voice_phase_inc"][0] = np.inf
+    b["voice_phase_inc"][1] = -np.inf
+    b["voice_phase_inc"][2] = np.nan
+    b["voice_phase"][3] = np.nan
+    b["voice_phase_inc"][20] = np.inf          # voices 20+ sit on the cyclic sine table (voice_reset default)
+    b["voice_phase_inc"][21] = np.nan
+    b["voice_phase_inc"][22] = 3.0e38          # finite but overflows to inf after a few adds
+    ref_bank, ref_g = b.copy(), seg.g_in.copy()
+    r = cpuref.render(ref_bank, ref_g, gold.tables, 200, 0, want_stems=True)
+    db = dev.DeviceBank(b.n)
+    db.set_tables(gold.tables)
+    db.upload(b)
+    db.set_globals(seg.g_in)
+    mix, stems = db.render_host(200, 2, 0, want_stems=True)
+    got = b.copy()
+    db.download(got)
+    db.close()
+    fin = np.isfinite(r["stems"])
+    assert (np.isfinite(stems) == fin).all()
+    assert gio.bits_equal(np.where(fin, stems, 0), np.where(fin, r["stems"], 0))
+    for k in ("voice_finished", "voice_sample_hold_count"):
+        assert (got[k] == ref_bank[k]).all(), k
+    ph_g, ph_r = got["voice_phase"], ref_bank["voice_phase"]
+    assert ((ph_g.view(np.uint32) == ph_r.view(np.uint32)) | (np.isnan(ph_g) & np.isnan(ph_r))).all()
+
+
+def test_four_million_voices(dev):
+    """Maximum-size edge: 2^22 voices (0.8 GB of device state), 16 frames, against the oracle."""
+    n, frames = 1 << 22, 16
+    bank, tables, g = banks.bank_c2(n)
+    ref_bank, ref_g = bank.copy(), g.copy()
+    r = cpuref.render(ref_bank, ref_g, tables, frames, 0)     # parity build (-ffp-contract=off), not the timing build
+    ref_mix = cpuref.master(ref_g, r["sum64"].astype(np.float32))
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    mix, _ = db.render_host(frames)
+    got = bank.copy()
+    db.download(got)
+    db.close()
+    assert not got.rw_equal(ref_bank), got.rw_equal(ref_bank)
+    assert rel_rms(mix, ref_mix) <= 1e-5

@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--no-low-latency", action="store_true", help="skip the secondary F=64 measurement")
     ap.add_argument("--no-recipe-warmup", action="store_true",
                     help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: wait for each launch's reduce before rendering the next block (default: double-buffered, "
+                         "reduce k overlaps render k+1)")
     ap.add_argument("--backend", default=os.environ.get("SKRED_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default).  gloo is only for rehearsing the N>1 code path on a box with fewer "
                          "GPUs than ranks (ranks then share devices and the partial mix is reduced through host memory)")
@@ -231,13 +234,24 @@ def main():
             red = host
         else:
             red = partial
-        for _ in range(warmup):
-            sh.step(render_partial, master, red, out)       # render -> (RCCL reduce, N>1) -> master on rank 0
+        if world > 1 and not a.no_overlap:
+            # double-buffered: the reduce of block k (RCCL, its own stream) overlaps the render of block k+1;
+            # every block is still rendered, reduced and mastered inside the region it is counted in (drain)
+            sh.begin([red, torch.zeros_like(red)])
+
+            def run(n):
+                for _ in range(n):
+                    sh.step_overlapped(render_partial, master, out)
+                sh.drain(master, out)                       # leaves the pair of buffers in place
+        else:
+            def run(n):
+                for _ in range(n):
+                    sh.step(render_partial, master, red, out)   # render -> (RCCL reduce, N>1) -> master on rank 0
+        run(warmup)
         fence()
         db.timing_reset()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            sh.step(render_partial, master, red, out)
+        run(steps)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -290,7 +304,7 @@ def main():
             "config": {"workload": DESCR[a.workload] + (f" [voices overridden: {bank_voices} per bank]" if a.voices else "") + where,
                        "voices_total": total, "voices_per_gpu": shard.n,
                        "frames_per_launch": F, "sample_rate": 48000, "interp": "linear" if interp else "truncate",
-                       "parallelism": f"voices block-partitioned over {world} GPU(s)" + ("; one RCCL reduce(sum) of float[F][2] per launch" if world > 1 else ""),
+                       "parallelism": f"voices block-partitioned over {world} GPU(s)" + ("; one RCCL reduce(sum) of float[F][2] per launch" + ("" if a.no_overlap else ", overlapped with the next launch's render") if world > 1 else ""),
                        "seed": "0x5EED", "recipe_warmup_frames": recipe_warmup_frames},
             "realtime_factor_48k": value / (total * 48000.0),
             "output_finite": finite,

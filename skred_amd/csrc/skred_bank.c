@@ -4,8 +4,9 @@
  * Plain C on purpose (the reference's host code is C, north_star: "Host code stays in C and
  * reaches the HIP kernels through a thin C-ABI shim").  It owns the HBM copy of a voice bank,
  * packs the reference-named host arrays (synth.def:12-89) into the 16-byte device planes of
- * skred_device_layout.h, and sequences the kernels of skred_kernels.hip.  There is no CPU
- * rendering here: every failure to reach the GPU is reported, never papered over.
+ * skred_device_layout.h, and sequences the kernels of skred_render_*.hip and
+ * skred_mix_kernels.hip (through skred_launch.h).  There is no CPU rendering here: every failure
+ * to reach the GPU is reported, never papered over.
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -17,14 +18,7 @@
 
 #include "skred_amd.h"
 #include "skred_device_layout.h"
-
-/* launchers in skred_kernels.hip */
-int sk_launch_render(const sk_render_args_t *args, int n_workgroups, hipStream_t stream);
-int sk_launch_reduce(const float *partial, float *tmp, float *out, int W, int ncols, hipStream_t stream);
-int sk_reduce_tmp_floats(int ncols);
-int sk_launch_render_mod(const sk_render_args_t *args, int n_groups64, const int *levels, int max_level, hipStream_t stream);
-int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels,
-                     float target, float k, float *gain_state, hipStream_t stream);
+#include "skred_launch.h"
 
 #define SK_TIMING_RING 256
 #define SK_FAST2_MIN_VOICES 131072   /* banks at least this large use two voices per lane (measured crossover) */
@@ -342,7 +336,7 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
   return SKRED_OK;
 }
 
-/* Pick the kernel.  The fast kernel (skred_kernels.hip: sk_render_fast_kernel) is valid when, over
+/* Pick the kernel.  The fast kernel (skred_render_fast.hip: sk_render_fast_kernel) is valid when, over
  * all voices that can sound: none is "exotic" (stopping one-shot, reverse, sample&hold, bit-crush,
  * noise, modulated, smoother off, non-finite phase data), and the biquad / the envelope are each used
  * by all of them or by none.  Anything else runs the generic kernel; both give identical samples. */
@@ -365,7 +359,7 @@ static void classify(skred_bank_t *b) {
   }
   b->fast_mode = m;
   b->class_dirty = 0;
-  /* dependency levels for modulated banks (skred_kernels.hip: sk_render_mod_kernel) */
+  /* dependency levels for modulated banks (skred_render_generic.hip: sk_render_mod_kernel) */
   b->max_level = 0;
   if (b->features & SKB_ANY_MOD) {
     for (int g0 = 0; g0 < b->n_padded; g0 += 64) {

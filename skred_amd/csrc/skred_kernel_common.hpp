@@ -1,0 +1,294 @@
+// skred_kernel_common.hpp -- device helpers shared by the render kernels (gfx950 / CDNA4).
+//
+// Included by skred_render_generic.hip, skred_render_fast.hip and skred_render_fast2.hip; each is its
+// own translation unit (no relocatable device code), so everything here is __forceinline__.
+//
+// Arithmetic contract (must match oracle/cpu_ref.c bit for bit per voice): compiled with
+// -ffp-contract=off (no FMA fusion), fp32 subnormals kept (hipcc default), IEEE-rounded
+// divide (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), exact fmod.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "skred_device_layout.h"
+
+#define LCG_A 6364136223846793005ULL
+#define LCG_C 1442695040888963407ULL
+
+// ---------------------------------------------------------------- wave reduction (DPP)
+//
+// Sum over the 64 lanes of a wavefront, total in lane 63, fixed association order:
+//   quad_perm [1,0,3,2]; quad_perm [2,3,0,1]; row_half_mirror; row_mirror (every lane now holds its
+//   16-lane row sum); row_bcast:15 into rows 1,3; row_bcast:31 into rows 2,3.
+//
+// The same two reductions (L and R) as 12 v_add_f32 with the lane permutation folded into the
+// add's DPP operand.  Written as one asm block because hipcc otherwise SLP-packs L/R into
+// v_pk_add_f32, which cannot take a DPP operand, and then spends 5 instructions per stage
+// (2 x v_mov 0, 2 x v_mov_dpp, v_pk_add) = 30 per frame.  The two chains are interleaved and padded
+// with s_nop so that every DPP read sits >= 2 wait states behind the VALU write of its source
+// (hipcc pads nothing inside an asm statement).  Rows masked off by row_mask keep their value.
+__device__ __forceinline__ void wave_sum2_to_lane63(float &l, float &r) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(l), "+v"(r));
+}
+
+// Two frames at once: four independent chains (L0, R0, L1, R1), so every DPP read already sits three
+// instructions behind the write of its source and no s_nop padding is needed between the stages.
+__device__ __forceinline__ void wave_sum4_to_lane63(float &l0, float &r0, float &l1, float &r1) {
+#define SK_DPP4(CTRL)                                                \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"              \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"              \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " bank_mask:0xf\n\t"              \
+  "v_add_f32_dpp %3, %3, %3 " CTRL " bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t"
+               SK_DPP4("quad_perm:[1,0,3,2] row_mask:0xf")
+               SK_DPP4("quad_perm:[2,3,0,1] row_mask:0xf")
+               SK_DPP4("row_half_mirror row_mask:0xf")
+               SK_DPP4("row_mirror row_mask:0xf")
+               SK_DPP4("row_bcast:15 row_mask:0xa")
+               SK_DPP4("row_bcast:31 row_mask:0xc")
+               "s_nop 1"
+               : "+v"(l0), "+v"(r0), "+v"(l1), "+v"(r1));
+#undef SK_DPP4
+}
+
+// ---------------------------------------------------------------- small exact helpers
+
+// fmodf for x >= 0, y > 0, exact.  x - y is exact for y <= x < 2y (Sterbenz), which is the
+// case whenever the phase increment is below one loop length.
+__device__ __forceinline__ float fmod_pos(float x, float y) {
+  if (x < y) return x;
+  if (x < y + y) return x - y;
+  return fmodf(x, y);
+}
+
+// == quantize_bits_int, synth.c:341-345 (the +0.5 is a double add there)
+__device__ __forceinline__ float crush(float v, int bits) {
+  const int levels = (1 << bits) - 1;
+  const int q = (int)((double)(v * (float)levels) + 0.5);
+  return (float)q * (1.0f / (float)levels);
+}
+
+// ---------------------------------------------------------------- per-voice registers
+
+struct VoiceRegs {
+  // read-only
+  float inc, lo, hi, amp;
+  int toff, tsize;
+  uint32_t flags;
+  int quant, hold_max;
+  float att, dec, sus, rel;
+  uint64_t t_start, t_release;
+  float vel, smooth_k, b0, b1, b2, a1, a2;
+  // read-write
+  float phase, sgain, x1, x2, y1, y2, sample, hold, pan_l, pan_r;
+  int hold_count;
+  uint32_t rw;
+};
+
+__device__ __forceinline__ void load_voice(const sk_render_args_t &a, int v, VoiceRegs &r) {
+  const uint4 osc = *reinterpret_cast<const uint4 *>(&a.ro[SKP_OSC][v]);
+  const uint4 tab = *reinterpret_cast<const uint4 *>(&a.ro[SKP_TAB][v]);
+  const uint4 et = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_T][v]);
+  const uint4 es = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_S][v]);
+  const uint4 gn = *reinterpret_cast<const uint4 *>(&a.ro[SKP_GAIN][v]);
+  const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
+  const uint4 s0 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_OSC][v]);
+  const uint4 s1 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_FILT][v]);
+  const uint4 s2 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_MISC][v]);
+  r.inc = __uint_as_float(osc.x); r.lo = __uint_as_float(osc.y);
+  r.hi = __uint_as_float(osc.z);  r.amp = __uint_as_float(osc.w);
+  r.toff = (int)tab.x; r.tsize = (int)tab.y; r.flags = tab.z;
+  r.quant = (int)(tab.w & 0xFFu); r.hold_max = (int)(tab.w >> 8);
+  r.att = __uint_as_float(et.x); r.dec = __uint_as_float(et.y);
+  r.sus = __uint_as_float(et.z); r.rel = __uint_as_float(et.w);
+  r.t_start = ((uint64_t)es.y << 32) | es.x;
+  r.t_release = ((uint64_t)es.w << 32) | es.z;
+  r.vel = __uint_as_float(gn.x); r.smooth_k = __uint_as_float(gn.y);
+  r.b0 = __uint_as_float(gn.z);  r.b1 = __uint_as_float(gn.w);
+  r.b2 = __uint_as_float(fl.x);  r.a1 = __uint_as_float(fl.y); r.a2 = __uint_as_float(fl.z);
+  r.phase = __uint_as_float(s0.x); r.sgain = __uint_as_float(s0.y);
+  r.x1 = __uint_as_float(s0.z);    r.x2 = __uint_as_float(s0.w);
+  r.y1 = __uint_as_float(s1.x);    r.y2 = __uint_as_float(s1.y);
+  r.sample = __uint_as_float(s1.z); r.rw = s1.w;
+  r.hold = __uint_as_float(s2.x);  r.hold_count = (int)s2.y;
+  r.pan_l = __uint_as_float(s2.z); r.pan_r = __uint_as_float(s2.w);
+  if (r.flags & SKF_REVERSE) r.inc = -r.inc;   // synth.c:224
+}
+
+__device__ __forceinline__ void store_voice(const sk_render_args_t &a, int v, const VoiceRegs &r) {
+  uint4 s0, s1, s2;
+  s0.x = __float_as_uint(r.phase); s0.y = __float_as_uint(r.sgain);
+  s0.z = __float_as_uint(r.x1);    s0.w = __float_as_uint(r.x2);
+  s1.x = __float_as_uint(r.y1);    s1.y = __float_as_uint(r.y2);
+  s1.z = __float_as_uint(r.sample); s1.w = r.rw;
+  s2.x = __float_as_uint(r.hold);  s2.y = (uint32_t)r.hold_count;
+  s2.z = __float_as_uint(r.pan_l); s2.w = __float_as_uint(r.pan_r);
+  *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
+  *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;
+  *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = s2;
+}
+
+// ---------------------------------------------------------------- one voice, one frame
+
+// Table fetch at table-domain position `pos` (>= 0).  truncate == synth.c:261-274;
+// linear == oracle/cpu_ref.c:table_fetch (defined by this project, not by the reference).
+template <bool TAB_LDS>
+__device__ __forceinline__ float table_fetch(const float *lds_tab, const float *__restrict__ glb_tab,
+                                             const VoiceRegs &r, float pos, int interp, bool wraps) {
+  int idx = (int)pos;
+  if (idx >= r.tsize) idx = r.tsize - 1;
+  if (idx < 0) idx = 0;
+  const float *tab = TAB_LDS ? lds_tab : glb_tab;
+  const float a = tab[r.toff + idx];
+  if (interp != 1) return a;
+  int nxt = idx + 1;
+  if (wraps && (float)nxt >= r.hi) nxt = (int)r.lo;
+  if (nxt >= r.tsize) nxt = r.tsize - 1;
+  if (nxt < 0) nxt = 0;
+  const float frac = pos - (float)idx;
+  return a + frac * (tab[r.toff + nxt] - a);
+}
+
+// Everything synth.c:531-612 does for one voice in one frame.  Returns this voice's L/R
+// contribution to the mix (0,0 when skipped or muted).
+template <bool TAB_LDS>
+__device__ __forceinline__ void voice_frame(VoiceRegs &r, const float *lds_tab,
+                                            const float *__restrict__ glb_tab, uint64_t now,
+                                            float white, int interp, float &out_l, float &out_r) {
+  out_l = 0.0f; out_r = 0.0f;
+  // skip tests, synth.c:531-542: finished or silent voices keep their state frozen
+  if ((r.rw & SKR_FINISHED) || r.amp == 0.0f || (r.flags & SKF_INERT)) {
+    r.sample = 0.0f;
+    return;
+  }
+  float raw;
+  if (r.flags & SKF_NOISE) {
+    raw = white;                                            // synth.c:543-546
+  } else {
+    // osc_next, synth.c:217-275
+    float ph = r.phase + r.inc;
+    if (!__builtin_isfinite(ph)) {
+      r.phase = 0.0f;
+      if (r.flags & SKF_ONE_SHOT) r.rw |= SKR_FINISHED;
+      raw = 0.0f;
+    } else {
+      const bool stops = (r.flags & SKF_ONE_SHOT) && !(r.flags & SKF_LOOPING);
+      const float span = r.hi - r.lo;
+      if (ph >= r.hi) {
+        if (stops) { ph = r.hi - 1e-6f; r.rw |= SKR_FINISHED; }
+        else ph = r.lo + fmod_pos(ph - r.lo, span);
+      } else if (ph < r.lo) {
+        if (stops) { ph = r.lo; r.rw |= SKR_FINISHED; }
+        else ph = r.hi - fmod_pos(r.lo - ph, span);
+      }
+      r.phase = ph;
+      raw = table_fetch<TAB_LDS>(lds_tab, glb_tab, r, ph, interp, !stops);
+    }
+  }
+  // sample & hold, synth.c:560-571
+  if (r.hold_max) {
+    if (r.hold_count == 0) r.hold = raw;
+    raw = r.hold;
+    if (++r.hold_count >= r.hold_max) r.hold_count = 0;
+  }
+  float s = raw;
+  if (r.quant) s = crush(s, r.quant);                        // synth.c:574
+  if (r.flags & SKF_FILTER) {                                // mmf_process, synth.c:349-364
+    float y = r.b0 * s;
+    y = y + r.b1 * r.x1;
+    y = y + r.b2 * r.x2;
+    y = y - r.a1 * r.y1;
+    y = y - r.a2 * r.y2;
+    r.x2 = r.x1; r.x1 = s;
+    r.y2 = r.y1; r.y1 = y;
+    s = y;
+  }
+  // amp_envelope_step, synth.c:398-431
+  float env = 1.0f;
+  if (r.flags & SKF_USE_ENV) {
+    float e = 0.0f;
+    if (r.rw & SKR_ENV_ACTIVE) {
+      const float t = (float)(now - r.t_start);
+      if (t < r.att) {
+        e = t / r.att;
+      } else if (t < r.att + r.dec) {
+        const float prog = (t - r.att) / r.dec;
+        e = 1.0f - prog * (1.0f - r.sus);
+      } else if (r.t_release == 0) {
+        e = r.sus;
+      } else {
+        const float tr = (float)(now - r.t_release);
+        if (tr < r.rel) {
+          const float prog = tr / r.rel;
+          e = r.sus * (1.0f - prog);
+        } else {
+          r.rw &= ~SKR_ENV_ACTIVE;
+        }
+      }
+    }
+    env = e * r.vel;
+  }
+  // amp, smoother, apply: synth.c:580-593 (no amplitude modulator in this kernel: mod == 1)
+  float gain = r.amp * env;
+  if (r.flags & SKF_SMOOTH) {
+    r.sgain += r.smooth_k * (gain - r.sgain);
+    gain = r.sgain;
+  }
+  s *= gain;
+  r.sample = s;
+  // pan + mix, synth.c:595-612
+  if (!(r.flags & SKF_MUTED)) {
+    out_l = s * r.pan_l;
+    out_r = s * r.pan_r;
+  }
+}
+
+// ---------------------------------------------------------------- shared by the fast kernels
+
+// two adjacent table samples, fetched with one 4-byte-aligned 8-byte access (global_load_dwordx2 /
+// ds_read2_b32).  The pool is padded by the host so that reading one float past any table is in bounds.
+struct __attribute__((packed, aligned(4))) tap_pair_t { float a, b; };
+
+// exact wrap for the cases the straight-line code does not cover (synth.c:241-256, looping voice)
+__device__ __forceinline__ float slow_wrap(float ph, float lo, float hi, float span) {
+  if (!__builtin_isfinite(ph)) return 0.0f;     // unreachable for a fast bank; kept total
+  if (ph >= hi) return lo + fmod_pos(ph - lo, span);
+  if (ph < lo) return hi - fmod_pos(lo - ph, span);
+  return ph;
+}
+
+// (timing experiments only: -DSK_ABLATE_REDUCE drops the cross-lane sum; outputs are then wrong)
+#ifdef SK_ABLATE_REDUCE
+#define SK_REDUCE_AND_STORE(J) asm volatile("" ::"v"(l), "v"(rr));
+#else
+#define SK_REDUCE_AND_STORE(J)       \
+  wave_sum2_to_lane63(l, rr);        \
+  if (lane == 63) wsum[wave * SK_CHUNK + (J)] = make_float2(l, rr);
+#endif
+#ifdef SK_ABLATE_REDUCE
+#define SK_REDUCE4_AND_STORE(J) asm volatile("" ::"v"(l0), "v"(r0), "v"(l1), "v"(r1));
+#else
+#define SK_REDUCE4_AND_STORE(J)                      \
+  wave_sum4_to_lane63(l0, r0, l1, r1);               \
+  if (lane == 63) *reinterpret_cast<float4 *>(&wsum[wave * SK_CHUNK + (J)]) = make_float4(l0, r0, l1, r1);
+#endif

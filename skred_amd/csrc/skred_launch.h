@@ -1,0 +1,41 @@
+/*
+ * skred_launch.h -- C-linkage launch entry points of the HIP translation units (internal to
+ * libskred_amd.so; the public ABI is include/skred_amd.h).
+ *
+ *   skred_render_generic.hip  sk_launch_render (dispatcher), sk_launch_render_mod
+ *   skred_render_fast.hip     sk_launch_render_fast
+ *   skred_render_fast2.hip    sk_launch_render_fast2
+ *   skred_mix_kernels.hip     sk_launch_reduce, sk_reduce_tmp_floats, sk_launch_master
+ *
+ * Every launcher returns the hipError_t of the launch as an int.
+ */
+#ifndef SKRED_LAUNCH_H
+#define SKRED_LAUNCH_H
+
+#include <hip/hip_runtime_api.h>
+
+#include "skred_device_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* picks the kernel family from args->fast_mode / args->stems and launches it on `stream` */
+int sk_launch_render(const sk_render_args_t *args, int n_workgroups, hipStream_t stream);
+/* banks with modulators: one 64-voice group per workgroup, dependency levels in `levels` */
+int sk_launch_render_mod(const sk_render_args_t *args, int n_groups64, const int *levels, int max_level,
+                         hipStream_t stream);
+/* the two specialised families (called by sk_launch_render only) */
+int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+
+/* partial[W][ncols] -> out[ncols], fixed order; `tmp` holds sk_reduce_tmp_floats(ncols) floats */
+int sk_launch_reduce(const float *partial, float *tmp, float *out, int W, int ncols, hipStream_t stream);
+int sk_reduce_tmp_floats(int ncols);
+int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels, float target, float k,
+                     float *gain_state, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,334 @@
+// skred_render_fast.hip -- sk_render_fast_kernel: one voice per lane, clean banks.
+#include "skred_kernel_common.hpp"
+#include "skred_launch.h"
+
+// ---------------------------------------------------------------- fast render kernel
+//
+// Same arithmetic, per voice bit-identical to the generic kernel above, for "clean" banks -- the
+// host only selects it when (bank-wide, skred_bank.c:classify): no one-shot voice that stops at
+// its table end, no reverse playback, no sample&hold / bit-crush / noise voices, no modulators,
+// smoother on everywhere, filter on for ALL voices or for none, envelope for ALL or none, and
+// every phase / increment / loop bound finite (so the !isfinite() branch of osc_next can never
+// fire and `voice_finished` cannot change inside a launch).  Under those conditions:
+//   * which lanes are skipped (synth.c:531-542) is a launch constant -> one mask, no per-frame
+//     branch; their state is left untouched in HBM and their output is select-masked to 0;
+//   * the wrap is straight-line: for span <= x < 2*span, fmodf(x, span) == x - span exactly
+//     (Sterbenz), anything else (huge increments, NaN) drops into the exact generic path;
+//   * envelope time is carried as a float that gains 1.0f per frame: exact below 2^24 frames
+//     and then equal to the reference's (float)(uint64) conversion; once every lane of the wave is
+//     in its sustain stage (monotone within a launch) the envelope costs nothing per frame and
+//     amp*env is a per-lane constant.
+// What remains per frame is ~45 VALU instructions instead of ~107, with almost no scalar
+// branch bookkeeping.
+
+
+struct FastRegs {
+  // launch constants
+  float inc, lo, hi, span, span2, amp;
+  int toff4, tsize_m1;          // byte offset of the table in the pool, table_size - 1
+  float att, attdec, dec, sus, one_m_sus, rel, vel;
+  float k, b0, b1, b2, a1, a2, pan_l, pan_r;
+  float gain_sustain;           // amp * (sustain_level * velocity)
+  // recurrences
+  float phase, sgain, x1, x2, y1, y2, sample;
+  float tf, trf;                // frames since note-on / note-off for the CURRENT frame
+  uint32_t rw;
+};
+
+// NOCLAMP: the caller guarantees 0 <= lo <= pos < hi <= table_size (TAME loops), so the reference's
+// index clamps (synth.c:271-272) can never act and are dropped.
+template <bool TAB_LDS, int INTERP, bool NOCLAMP>
+__device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__restrict__ glb_tab,
+                                            const FastRegs &r, float pos) {
+  int idx = (int)pos;
+  if (!NOCLAMP) idx = max(min(idx, r.tsize_m1), 0);          // clamp, synth.c:271-272
+  const char *tab = TAB_LDS ? lds_tab : glb_tab;
+  if (INTERP == 0) return *reinterpret_cast<const float *>(tab + (r.toff4 + (idx << 2)));
+  // linear: oracle/cpu_ref.c:table_fetch.  Every voice of a fast bank wraps (no stopping one-shots).
+  // Both taps come from ONE 8-byte gather (4-byte aligned pair) -- the neighbour is idx+1 except on
+  // the last sample before the loop end, where a second (rare) gather fetches the loop start.
+  const tap_pair_t pr = *reinterpret_cast<const tap_pair_t *>(tab + (r.toff4 + (idx << 2)));
+  const float a = pr.a;
+  float b = pr.b;
+  int nxt = idx + 1;
+  bool special = (float)nxt >= r.hi;
+  if (special) nxt = (int)r.lo;
+  if (!NOCLAMP) { const int c = max(min(nxt, r.tsize_m1), 0); special = special || (c != nxt); nxt = c; }
+  if (special) b = *reinterpret_cast<const float *>(tab + (r.toff4 + (nxt << 2)));
+  const float frac = pos - (float)idx;
+  return a + frac * (b - a);
+}
+
+
+// One voice, one frame.  STEADY: every lane of the wave sits in its sustain stage.  When !STEADY the
+// caller has set r.tf / r.trf to this frame's envelope clocks.
+// TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
+// by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
+template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP>
+__device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
+                                           const bool released, const char *lds_tab,
+                                           const char *__restrict__ glb_tab, float &out_l, float &out_r) {
+  // ---- oscillator (osc_next, synth.c:217-275) ----
+  const float ph0 = r.phase + r.inc;
+  const float x = ph0 - r.lo;
+  const bool over = ph0 >= r.hi;
+  float ph;
+  if (TAME) {
+    ph = over ? r.lo + (x - r.span) : ph0;
+  } else {
+    const bool simple = over && (x < r.span2);          // one loop length past the end: x - span exact
+    const bool in_range = (ph0 >= r.lo) && !over;
+    ph = simple ? r.lo + (x - r.span) : ph0;
+    if (!(in_range || simple)) ph = slow_wrap(ph0, r.lo, r.hi, r.span);
+  }
+  r.phase = ph;
+  float s = fast_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r, ph);
+  // ---- biquad (mmf_process, synth.c:349-364) ----
+  if (FILTER) {
+    // xn/yn: newest delay-line entries, xo/yo: the older ones.  The new values overwrite the OLD
+    // slots, so the caller alternates the argument order frame by frame instead of shifting
+    // registers (x2 = x1; x1 = s costs four v_mov per frame).
+    float y = r.b0 * s;
+    y = y + r.b1 * xn;
+    y = y + r.b2 * xo;
+    y = y - r.a1 * yn;
+    y = y - r.a2 * yo;
+    xo = s;
+    yo = y;
+    s = y;
+  }
+  // ---- envelope (amp_envelope_step, synth.c:398-431) and gain (synth.c:580-588) ----
+  float gain;
+  if (!ENV) {
+    gain = r.amp;                                   // amp * 1.0f * 1.0f
+  } else if (STEADY) {
+    gain = r.gain_sustain;                          // e = sustain_level on every lane
+  } else {
+    float e = 0.0f;
+    if (r.rw & SKR_ENV_ACTIVE) {
+      if (r.tf < r.att) {
+        e = r.tf / r.att;
+      } else if (r.tf < r.attdec) {
+        const float prog = (r.tf - r.att) / r.dec;
+        e = 1.0f - prog * r.one_m_sus;
+      } else if (!released) {
+        e = r.sus;
+      } else if (r.trf < r.rel) {
+        const float prog = r.trf / r.rel;
+        e = r.sus * (1.0f - prog);
+      } else {
+        r.rw &= ~SKR_ENV_ACTIVE;
+      }
+    }
+    gain = r.amp * (e * r.vel);
+  }
+  // ---- smoother + apply (synth.c:589-593), pan (synth.c:603-604) ----
+  r.sgain += r.k * (gain - r.sgain);
+  s *= r.sgain;
+  r.sample = s;
+  out_l = s * r.pan_l;
+  out_r = s * r.pan_r;
+}
+
+// one frame of the chunk loop: STEADY_ selects the envelope mode, A/B the delay-line roles
+#define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO)                                                        \
+  {                                                                                                      \
+    float l, rr;                                                                                         \
+    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr); \
+    l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
+    SK_REDUCE_AND_STORE(J)                                                                               \
+  }
+// two steady frames (J even, J+1): delay-line roles swap in between, one 4-chain reduction, one 16-byte store
+#define SK_FAST_PAIR_STEADY(J, TAME_) /* TAME_ loops run only when no live lane is muted: no output select */ \
+  {                                                                                                      \
+    float l0, r0, l1, r1;                                                                                \
+    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x1, r.x2, r.y1, r.y2, released, lds_tab, glb_tab, l0, r0); \
+    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x2, r.x1, r.y2, r.y1, released, lds_tab, glb_tab, l1, r1); \
+    if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
+    SK_REDUCE4_AND_STORE(J)                                                                              \
+  }
+#define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2)
+#define SK_FAST_ODD(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1)
+#define SK_FAST_FIX_ODD_TAIL()                                                     \
+  { float t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }
+
+#ifndef SK_FAST_MIN_WAVES
+#define SK_FAST_MIN_WAVES 6      /* waves per SIMD the register allocator must leave room for */
+#endif
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
+__global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
+  extern __shared__ float lds[];
+  float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
+  const char *lds_tab = reinterpret_cast<const char *>(lds);
+  const char *glb_tab = reinterpret_cast<const char *>(a.tables);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  if (TAB_LDS) {
+    const int n4 = a.lds_table_floats >> 2;           // padded to a multiple of 4 by the host
+    const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);
+    float4 *dst4 = reinterpret_cast<float4 *>(lds);
+    for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];
+    __syncthreads();
+  }
+
+  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;
+  bool first_pass = true;
+
+  for (int g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+    const int v = g * SK_GROUP + tid;
+    FastRegs r;
+    bool dead, silent;            // dead: skipped by synth.c:531-542; silent: dead or muted
+    bool released = false;
+    uint64_t t_start = 0, t_release = 0;
+    {
+      const uint4 osc = *reinterpret_cast<const uint4 *>(&a.ro[SKP_OSC][v]);
+      const uint4 tab = *reinterpret_cast<const uint4 *>(&a.ro[SKP_TAB][v]);
+      const uint4 gn = *reinterpret_cast<const uint4 *>(&a.ro[SKP_GAIN][v]);
+      const uint4 s0 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_OSC][v]);
+      const uint4 s1 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_FILT][v]);
+      const uint4 s2 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_MISC][v]);
+      r.inc = __uint_as_float(osc.x); r.lo = __uint_as_float(osc.y);
+      r.hi = __uint_as_float(osc.z);  r.amp = __uint_as_float(osc.w);
+      r.span = r.hi - r.lo; r.span2 = r.span + r.span;
+      r.toff4 = (int)tab.x << 2; r.tsize_m1 = (int)tab.y - 1;
+      const uint32_t flags = tab.z;
+      r.vel = __uint_as_float(gn.x); r.k = __uint_as_float(gn.y);
+      r.b0 = __uint_as_float(gn.z);  r.b1 = __uint_as_float(gn.w);
+      r.phase = __uint_as_float(s0.x); r.sgain = __uint_as_float(s0.y);
+      r.x1 = __uint_as_float(s0.z);    r.x2 = __uint_as_float(s0.w);
+      r.y1 = __uint_as_float(s1.x);    r.y2 = __uint_as_float(s1.y);
+      r.sample = __uint_as_float(s1.z); r.rw = s1.w;
+      r.pan_l = __uint_as_float(s2.z); r.pan_r = __uint_as_float(s2.w);
+      r.tf = 0.0f; r.trf = 0.0f;
+      if (FILTER) {
+        const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
+        r.b2 = __uint_as_float(fl.x); r.a1 = __uint_as_float(fl.y); r.a2 = __uint_as_float(fl.z);
+      }
+      if (ENV) {
+        const uint4 et = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_T][v]);
+        const uint4 es = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_S][v]);
+        r.att = __uint_as_float(et.x); r.dec = __uint_as_float(et.y);
+        r.sus = __uint_as_float(et.z); r.rel = __uint_as_float(et.w);
+        r.attdec = r.att + r.dec;                    // synth.c:410: decay_start + decay_time
+        r.one_m_sus = 1.0f - r.sus;                  // synth.c:413
+        r.gain_sustain = r.amp * (r.sus * r.vel);    // synth.c:582,588 in the sustain stage
+        t_start = ((uint64_t)es.y << 32) | es.x;
+        t_release = ((uint64_t)es.w << 32) | es.z;
+        released = t_release != 0;                   // synth.c:417
+      }
+      dead = (r.rw & SKR_FINISHED) || r.amp == 0.0f || (flags & SKF_INERT);
+      silent = dead || (flags & SKF_MUTED);
+    }
+    // wrap can only ever be the simple one (see fast_frame<TAME>): decided once per pass
+    if (dead) {
+      // a skipped voice is never stored back (see the end of the pass): give its lane inert numbers
+      // so that it contributes exact zeros and its table index stays at 0, whatever its real state is
+      r.inc = 0.0f; r.lo = 0.0f; r.hi = 1.0f; r.span = 1.0f; r.span2 = 2.0f; r.phase = 0.0f;
+      r.toff4 = 0; r.tsize_m1 = 0;
+      r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
+      r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
+      r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
+    }
+    // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
+    // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>
+    const bool tame = __all(dead || (r.inc >= 0.0f && r.inc <= 0.5f * r.span && r.phase >= r.lo && r.phase <= r.hi &&
+                                     r.lo >= 0.0f && r.hi <= (float)(r.tsize_m1 + 1))) && !__any(silent && !dead);
+
+    for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
+      const int cn = min(SK_CHUNK, a.num_frames - c0);
+      bool steady = true, exact = true;
+      if (ENV) {
+        // Envelope clocks for this chunk from the integer timeline: frame c0+j has
+        // now = count0 + c0 + j + 1 (synth.c:521).  d_* are the clocks of "frame c0 - 1".
+        const uint64_t base = a.count0 + (uint64_t)c0;
+        const uint64_t d_on = base - t_start;
+        const uint64_t d_off = base - t_release;
+        const uint64_t lim = (1ull << 24) - (uint64_t)SK_CHUNK - 2;   // x + 1.0f stays exact below 2^24
+        exact = __all(dead || ((d_on < lim) && (!released || d_off < lim)));
+        r.tf = (float)d_on;
+        r.trf = released ? (float)d_off : 0.0f;
+        // sustain is absorbing within a launch: the clock only grows and note-off arrives between launches
+        const float tf_first = (float)(d_on + 1);
+        steady = __all(dead || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
+      }
+      if ((!ENV || steady) && tame) {
+        int j = 0;
+        for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
+        if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
+      } else if (!ENV || steady) {
+        int j = 0;
+        for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, false)
+        if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
+      } else if (exact) {
+        int j = 0;
+        for (; j + 1 < cn; j += 2) {                 // clocks == (float)(now - sample_start), exact below 2^24
+          r.tf += 1.0f; r.trf += 1.0f;
+          SK_FAST_EVEN(j, false)
+          r.tf += 1.0f; r.trf += 1.0f;
+          SK_FAST_ODD(j + 1, false)
+        }
+        if (j < cn) { r.tf += 1.0f; r.trf += 1.0f; SK_FAST_EVEN(j, false) SK_FAST_FIX_ODD_TAIL() }
+      } else {
+        for (int j = 0; j < cn; ++j) {               // clocks past 2^24 frames: integer path, synth.c:401,422
+          const uint64_t now = a.count0 + (uint64_t)(c0 + j) + 1;
+          r.tf = (float)(now - t_start); r.trf = (float)(now - t_release);
+          SK_FAST_EVEN(j, false)
+          SK_FAST_FIX_ODD_TAIL()
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * cn) {
+        const float *w = reinterpret_cast<const float *>(wsum);
+        float s = w[0 * 2 * SK_CHUNK + tid];
+        s += w[1 * 2 * SK_CHUNK + tid];
+        s += w[2 * 2 * SK_CHUNK + tid];
+        s += w[3 * 2 * SK_CHUNK + tid];
+        float *p = a.partial + part_base + (size_t)c0 * 2 + tid;
+        if (first_pass) *p = s; else *p += s;
+      }
+      __syncthreads();
+    }
+
+    // store the recurrences; skipped voices keep their state and get voice_sample = 0 (synth.c:532,538)
+    if (!dead) {
+      uint4 s0, s1;
+      s0.x = __float_as_uint(r.phase); s0.y = __float_as_uint(r.sgain);
+      s0.z = __float_as_uint(r.x1);    s0.w = __float_as_uint(r.x2);
+      s1.x = __float_as_uint(r.y1);    s1.y = __float_as_uint(r.y2);
+      s1.z = __float_as_uint(r.sample); s1.w = r.rw;
+      *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
+      *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;
+    } else {
+      reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][v])[2] = 0u;
+    }
+    first_pass = false;
+  }
+}
+
+// ---------------------------------------------------------------- launcher (C linkage)
+
+// specialisation key: table residency x filter x envelope x interpolation
+extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
+                                     hipStream_t stream) {
+  const bool tab_lds = args->lds_table_floats > 0;
+  dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
+  const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
+                  ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
+#define SK_FAST_CASE(K, T, F, E, I) \
+  case K: hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I>), grid, block, lds_bytes, stream, *args); break;
+  switch (key) {
+    SK_FAST_CASE(0, false, false, false, 0) SK_FAST_CASE(1, false, false, false, 1)
+    SK_FAST_CASE(2, false, false, true, 0)  SK_FAST_CASE(3, false, false, true, 1)
+    SK_FAST_CASE(4, false, true, false, 0)  SK_FAST_CASE(5, false, true, false, 1)
+    SK_FAST_CASE(6, false, true, true, 0)   SK_FAST_CASE(7, false, true, true, 1)
+    SK_FAST_CASE(8, true, false, false, 0)  SK_FAST_CASE(9, true, false, false, 1)
+    SK_FAST_CASE(10, true, false, true, 0)  SK_FAST_CASE(11, true, false, true, 1)
+    SK_FAST_CASE(12, true, true, false, 0)  SK_FAST_CASE(13, true, true, false, 1)
+    SK_FAST_CASE(14, true, true, true, 0)   SK_FAST_CASE(15, true, true, true, 1)
+  }
+#undef SK_FAST_CASE
+  return (int)hipGetLastError();
+}

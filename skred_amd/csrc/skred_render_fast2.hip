@@ -1,0 +1,580 @@
+// skred_render_fast2.hip -- sk_render_fast2_kernel / sk_render_env2_kernel: two voices per lane, large clean banks.
+#include "skred_kernel_common.hpp"
+#include "skred_launch.h"
+
+// ---------------------------------------------------------------- fast kernel, two voices per lane
+//
+// Same per-voice arithmetic as sk_render_fast_kernel, but every lane carries TWO voices (v and v+64
+// of a 128-voice wave slice) as 2-vectors, so that
+//   * the mul/add backbone (phase add, wrap, biquad, smoother, gain, pan) issues as packed fp32
+//     (v_pk_add_f32 / v_pk_mul_f32: two voices per instruction, each lane-op still IEEE fp32,
+//     unfused, hence bit-identical), and
+//   * the 12-instruction cross-lane DPP reduction is paid once per 128 voices instead of per 64.
+// Compares, selects, float->int conversion and the LDS gathers stay per voice.  Used for large
+// clean banks (the host decides, skred_bank.c); per-voice results equal the other two kernels'.
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#ifndef SK_LDS_REDUCE
+#define SK_LDS_REDUCE 1     /* 1: tame chunks of LDS-table banks sum across lanes through an LDS transposition tile
+                               (+11 % measured at 2^20 voices; global-gather banks keep the DPP butterfly: the
+                               8-frame block costs them 30 %); 0: always the DPP butterfly */
+#endif
+
+// Two kernels share this machinery.  sk_render_fast2_kernel renders the 512-voice groups in which every
+// voice holds a CONSTANT envelope level for the whole launch (sustain, inactive, finished release, or no
+// envelope at all): its loop has no envelope code and a small register footprint.  Groups with any voice
+// in attack / decay / release are only flagged by it and rendered right afterwards by
+// sk_render_env2_kernel, which carries the envelope machinery (and its registers) alone.
+struct Fast2Regs {
+  v2f inc, lo, hi, span, span2;
+  int toff4[2], tsize_m1[2];
+  v2f k, b0, b1, b2, a1, a2, pan_l, pan_r, gain_const;   // gain_const: gain of a constant-level lane
+  v2f phase, sgain, x1, x2, y1, y2, sample;
+  uint32_t rw[2];
+};
+
+struct Env2Regs {                 // sk_render_env2_kernel only
+  float att[2], attdec[2], dec[2], rel[2];
+  v2f ampv, velv, susv, omsv;     // amp, velocity, sustain_level, 1 - sustain_level
+  v2f clk, ebase, eden, erinv, eA, eB, eC;   // "ramp" spans: see fast2_env_span
+  float tf[2], trf[2];            // general frames: this frame's clocks
+};
+
+template <bool TAB_LDS, int INTERP, bool NOCLAMP>
+__device__ __forceinline__ float fast2_fetch(const char *lds_tab, const char *__restrict__ glb_tab,
+                                             int toff4, int tsize_m1, float lo, float hi, float pos) {
+  int idx = (int)pos;
+  if (!NOCLAMP) idx = max(min(idx, tsize_m1), 0);
+  const char *tab = TAB_LDS ? lds_tab : glb_tab;
+  if (INTERP == 0) return *reinterpret_cast<const float *>(tab + (toff4 + (idx << 2)));
+  const tap_pair_t pr = *reinterpret_cast<const tap_pair_t *>(tab + (toff4 + (idx << 2)));   // see fast_fetch
+  const float a = pr.a;
+  float b = pr.b;
+  int nxt = idx + 1;
+  bool special = (float)nxt >= hi;
+  if (special) nxt = (int)lo;
+  if (!NOCLAMP) { const int c = max(min(nxt, tsize_m1), 0); special = special || (c != nxt); nxt = c; }
+  if (special) b = *reinterpret_cast<const float *>(tab + (toff4 + (nxt << 2)));
+  const float frac = pos - (float)idx;
+  return a + frac * (b - a);
+}
+
+// Which branch of amp_envelope_step (synth.c:398-431) a voice takes at envelope clocks (t, tr):
+// 0 inactive, 1 attack, 2 decay, 3 sustain (held), 4 release, 5 release finished (is_active -> 0).
+// The code is monotone in time within a launch (note-off only arrives between launches), so a voice
+// whose code is the same on the first and the last frame of a span keeps it for the whole span, and
+// codes 0 / 3 / 5 (constant level) are absorbing.
+__device__ __forceinline__ int env_stage_code(bool active, bool released, float t, float tr, float att,
+                                              float attdec, float rel) {
+  if (!active) return 0;
+  if (t < att) return 1;
+  if (t < attdec) return 2;
+  if (!released) return 3;
+  return (tr < rel) ? 4 : 5;
+}
+
+// Per-lane envelope constants for a span of frames whose first / last frame have clocks (t1,tr1) / (tN,trN)
+// and whose preceding frame has (t0,tr0).  Constant lanes get gain_const; moving lanes get the "ramp" form
+//     q = (clk - ebase) / eden,  e = eC * (eA + eB * q)
+// which is bit-identical to the reference's stage expressions:
+//     attack  q               = 1*(0 + 1*q)            (synth.c:405)
+//     decay   1 - q*(1-sus)   = 1*(1 + (-(1-sus))*q)   (synth.c:413)
+//     release sus*(1 - q)     = sus*(1 + (-1)*q)       (synth.c:425)
+// `st` stays true while every lane sits on a constant level; `same` while no lane changes stage in the span
+// (and the denominators are in the range where the short division below equals the full IEEE expansion).
+__device__ __forceinline__ void fast2_env_span(Fast2Regs &r, Env2Regs &e, int c, bool dead, bool released,
+                                               float t1, float tr1, float tN, float trN, float t0, float tr0,
+                                               bool &st, bool &same) {
+  const bool act = (r.rw[c] & SKR_ENV_ACTIVE) != 0;
+  const int code0 = env_stage_code(act, released, t1, tr1, e.att[c], e.attdec[c], e.rel[c]);
+  const int code1 = env_stage_code(act, released, tN, trN, e.att[c], e.attdec[c], e.rel[c]);
+  st = st && (dead || code0 == 0 || code0 == 3 || code0 == 5);
+  const float level = code0 == 3 ? e.susv[c] : 0.0f;
+  e.eA[c] = code0 == 1 ? 0.0f : 1.0f;
+  e.eB[c] = code0 == 1 ? 1.0f : (code0 == 2 ? -e.omsv[c] : (code0 == 4 ? -1.0f : 0.0f));
+  e.eC[c] = code0 == 4 ? e.susv[c] : ((code0 == 1 || code0 == 2) ? 1.0f : level);
+  e.clk[c] = code0 == 4 ? tr0 : t0;
+  e.ebase[c] = code0 == 2 ? e.att[c] : 0.0f;
+  const float d = code0 == 1 ? e.att[c] : (code0 == 2 ? e.dec[c] : (code0 == 4 ? e.rel[c] : 1.0f));
+  e.eden[c] = d;
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  e.erinv[c] = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);   // refined reciprocal, as v_rcp + one fma step
+  r.gain_const[c] = e.ampv[c] * (level * e.velv[c]);                   // amp * (e * velocity), synth.c:582,588
+  same = same && (dead || (code0 == code1 && d >= 0x1p-40f && d <= 0x1p40f));
+  // a release that has run out: the reference clears is_active on the first frame it notices (synth.c:429)
+  if (!dead && code0 == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;
+}
+
+// General frames (a lane changes stage inside the block): amp_envelope_step as the reference writes it.
+__device__ __forceinline__ float fast2_env_general(Fast2Regs &r, Env2Regs &e, int c, bool released) {
+  float lvl = 0.0f;
+  if (r.rw[c] & SKR_ENV_ACTIVE) {
+    if (e.tf[c] < e.att[c]) {
+      lvl = e.tf[c] / e.att[c];
+    } else if (e.tf[c] < e.attdec[c]) {
+      const float prog = (e.tf[c] - e.att[c]) / e.dec[c];
+      lvl = 1.0f - prog * e.omsv[c];
+    } else if (!released) {
+      lvl = e.susv[c];
+    } else if (e.trf[c] < e.rel[c]) {
+      const float prog = e.trf[c] / e.rel[c];
+      lvl = e.susv[c] * (1.0f - prog);
+    } else {
+      r.rw[c] &= ~SKR_ENV_ACTIVE;
+    }
+  }
+  return e.ampv[c] * (lvl * e.velv[c]);
+}
+
+// EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
+// with the short exact division; 2 general.  TAME: see fast_frame.
+// Oscillator half of a frame: advance both phases, wrap, fetch the two table samples.
+template <bool TAB_LDS, bool TAME, int INTERP>
+__device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, const char *__restrict__ glb_tab) {
+  const v2f ph0 = r.phase + r.inc;
+  const v2f x = ph0 - r.lo;
+  const v2f phw = r.lo + (x - r.span);
+  v2f ph;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const bool over = ph0[c] >= r.hi[c];
+    float p;
+    if (TAME) {
+      p = over ? phw[c] : ph0[c];
+    } else {
+      const bool simple = over && (x[c] < r.span2[c]);
+      const bool in_range = (ph0[c] >= r.lo[c]) && !over;
+      p = simple ? phw[c] : ph0[c];
+      if (!(in_range || simple)) p = slow_wrap(ph0[c], r.lo[c], r.hi[c], r.span[c]);
+    }
+    ph[c] = p;
+  }
+  r.phase = ph;
+  v2f s;
+  s.x = fast2_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r.toff4[0], r.tsize_m1[0], r.lo.x, r.hi.x, ph.x);
+  s.y = fast2_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r.toff4[1], r.tsize_m1[1], r.lo.y, r.hi.y, ph.y);
+  return s;
+}
+
+// The rest of the frame: biquad, envelope/gain, smoother, pan, lane-local sum of the two voices.
+// EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
+// with the short exact division; 2 general.  TAME: see fast_frame.
+template <bool FILTER, int EM, bool TAME>
+__device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
+                                           const bool rel0, const bool rel1, const bool silent0,
+                                           const bool silent1, float &out_l, float &out_r) {
+  // ---- biquad, packed ----
+  if (FILTER) {
+    v2f y = r.b0 * s;
+    y = y + r.b1 * xn;
+    y = y + r.b2 * xo;
+    y = y - r.a1 * yn;
+    y = y - r.a2 * yo;
+    xo = s;
+    yo = y;
+    s = y;
+  }
+  // ---- gain ----
+  v2f gain;
+  if (EM == 0) {
+    gain = r.gain_const;
+  } else if (EM == 1) {
+    e.clk = e.clk + 1.0f;                              // exact: clocks stay below 2^24 in this mode
+    const v2f num = e.clk - e.ebase;                   // t | t - attack_time | t_release
+    // q = num / den correctly rounded: the FMA tail of the IEEE fp32 division expansion hipcc itself emits
+    // (v_div_scale / v_rcp / fma.. / v_div_fmas / v_div_fixup) with the refined reciprocal prepared once per
+    // span; fast2_env_span admits only denominators for which div_scale / div_fixup would not intervene.
+    v2f q = num * e.erinv;
+    v2f rem = __builtin_elementwise_fma(-e.eden, q, num);
+    q = __builtin_elementwise_fma(rem, e.erinv, q);
+    rem = __builtin_elementwise_fma(-e.eden, q, num);
+    q = __builtin_elementwise_fma(rem, e.erinv, q);
+    const v2f lvl = e.eC * (e.eA + e.eB * q);
+    gain = e.ampv * (lvl * e.velv);
+  } else {
+    gain.x = fast2_env_general(r, e, 0, rel0);
+    gain.y = fast2_env_general(r, e, 1, rel1);
+  }
+  r.sgain = r.sgain + r.k * (gain - r.sgain);
+  s = s * r.sgain;
+  r.sample = s;
+  // ---- pan, lane-local sum of the two voices ----
+  v2f so = s;
+  if (!TAME) {          // TAME loops run only when no live lane is muted (dead lanes already yield exact zeros)
+    so.x = silent0 ? 0.0f : s.x;
+    so.y = silent1 ? 0.0f : s.y;
+  }
+  const v2f l2 = so * r.pan_l;
+  const v2f r2 = so * r.pan_r;
+  out_l = l2.x + l2.y;
+  out_r = r2.x + r2.y;
+}
+
+template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP>
+__device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
+                                            const bool rel0, const bool rel1, const bool silent0,
+                                            const bool silent1, const char *lds_tab,
+                                            const char *__restrict__ glb_tab, float &out_l, float &out_r) {
+  const v2f s = fast2_osc<TAB_LDS, TAME, INTERP>(r, lds_tab, glb_tab);
+  fast2_post<FILTER, EM, TAME>(r, e, s, xn, xo, yn, yo, rel0, rel1, silent0, silent1, out_l, out_r);
+}
+
+#define SK_F2_ARGS released[0], released[1], silent[0], silent[1], lds_tab, glb_tab
+// one frame (J) / two frames (J, J+1; delay-line roles swap in between, one 4-chain DPP reduction)
+#define SK_FAST2_ONE(J, EM_, TAME_)                                                                      \
+  {                                                                                                      \
+    float l, rr;                                                                                         \
+    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l, rr);   \
+    SK_REDUCE_AND_STORE(J)                                                                               \
+    { v2f t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }                        \
+  }
+#define SK_FAST2_PAIR(J, EM_, TAME_)                                                                     \
+  {                                                                                                      \
+    float l0, r0, l1, r1;                                                                                \
+    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);  \
+    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);  \
+    SK_REDUCE4_AND_STORE(J)                                                                              \
+  }
+// Eight frames (J..J+7) with the cross-lane sum through LDS instead of the VALU: every lane parks its (L,R) of
+// 8 frames in a wave-private transposition tile xp[8][65] (one ds_write_b64 per frame, row stride 65 keeps the
+// column reads conflict-free); then lane (f = lane&7, seg = lane>>3) adds the 8 lanes of segment seg for frame f,
+// the 8 segment sums go through xq[8][8], and lanes 0..7 finish one frame each.  ~1.75 VALU + 3.25 LDS
+// instructions per frame instead of 12 VALU.  All traffic stays inside one wavefront (LDS executes a wave's
+// accesses in order): no s_barrier.
+#define SK_WAVE_SYNC()                                      \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+  __builtin_amdgcn_wave_barrier();                          \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#define SK_FAST2_LDS_BLOCK(J, EM_)                                                                       \
+  {                                                                                                      \
+    /* software pipeline: the table gather of the NEXT frame is issued before the biquad/gain chain of the   \
+       current one (the source order matters: the compiler may not move an LDS read above the tile write) */  \
+    v2f s0_ = fast2_osc<TAB_LDS, true, INTERP>(r, lds_tab, glb_tab);                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      float l0, r0, l1, r1;                                                                              \
+      const v2f s1_ = fast2_osc<TAB_LDS, true, INTERP>(r, lds_tab, glb_tab);                              \
+      fast2_post<FILTER, EM_, true>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
+      if (q_ < 6) s0_ = fast2_osc<TAB_LDS, true, INTERP>(r, lds_tab, glb_tab);                            \
+      fast2_post<FILTER, EM_, true>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
+      xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
+      xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
+    }                                                                                                    \
+    SK_WAVE_SYNC()                                                                                       \
+    {                                                                                                    \
+      const float2 *src_ = xp + (lane & 7) * 65 + (lane >> 3) * 8;                                       \
+      float2 a0_ = src_[0];                                                                              \
+      _Pragma("unroll") for (int i_ = 1; i_ < 8; ++i_) { const float2 t_ = src_[i_]; a0_.x += t_.x; a0_.y += t_.y; } \
+      xq[lane] = a0_; /* == xq[seg * 8 + f] */                                                           \
+    }                                                                                                    \
+    SK_WAVE_SYNC()                                                                                       \
+    if (lane < 8) {                                                                                      \
+      float2 t0_ = xq[lane];                                                                             \
+      _Pragma("unroll") for (int g_ = 1; g_ < 8; ++g_) { const float2 t_ = xq[g_ * 8 + lane]; t0_.x += t_.x; t0_.y += t_.y; } \
+      wsum[wave * SK_CHUNK + (J) + lane] = t0_;                                                          \
+    }                                                                                                    \
+    SK_WAVE_SYNC()                                                                                       \
+  }
+// a whole chunk of cn frames in mode EM_: LDS blocks of 8 when tame, DPP pairs otherwise, single-frame tail
+#if SK_LDS_REDUCE
+#define SK_FAST2_CHUNK(EM_)                                                     \
+  {                                                                             \
+    int j = 0;                                                                  \
+    if (tame) { if (TAB_LDS) for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK(j, EM_) \
+                for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, true)          \
+                if (j < cn) SK_FAST2_ONE(j, EM_, true) }                        \
+    else      { for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, false)         \
+                if (j < cn) SK_FAST2_ONE(j, EM_, false) }                       \
+  }
+#else
+#define SK_FAST2_CHUNK(EM_)                                                     \
+  {                                                                             \
+    int j = 0;                                                                  \
+    if (tame) { for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, true)          \
+                if (j < cn) SK_FAST2_ONE(j, EM_, true) }                        \
+    else      { for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, false)         \
+                if (j < cn) SK_FAST2_ONE(j, EM_, false) }                       \
+  }
+#endif
+// wave sums of the chunk -> this workgroup's partial-mix row (ACCUM_: add to what is there)
+#define SK_FAST2_FLUSH(ACCUM_)                                                   \
+  __syncthreads();                                                              \
+  if (tid < 2 * cn) {                                                           \
+    const float *w_ = reinterpret_cast<const float *>(wsum);                    \
+    float s_ = w_[0 * 2 * SK_CHUNK + tid];                                      \
+    s_ += w_[1 * 2 * SK_CHUNK + tid];                                           \
+    s_ += w_[2 * 2 * SK_CHUNK + tid];                                           \
+    s_ += w_[3 * 2 * SK_CHUNK + tid];                                           \
+    float *p_ = a.partial + part_base + (size_t)c0 * 2 + tid;                   \
+    if (ACCUM_) *p_ += s_; else *p_ = s_;                                       \
+  }                                                                             \
+  __syncthreads();
+
+// load the two voices of this lane for workgroup pass g; returns whether the wave is tame
+template <bool FILTER, bool ENV>
+__device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int g, int wave, int lane, Fast2Regs &r,
+                                           Env2Regs &e, bool dead[2], bool silent[2], bool released[2],
+                                           uint64_t t_start[2], uint64_t t_release[2], int vidx[2]) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int v = g * (2 * SK_GROUP) + wave * 128 + c * 64 + lane;
+    vidx[c] = v;
+    const uint4 osc = *reinterpret_cast<const uint4 *>(&a.ro[SKP_OSC][v]);
+    const uint4 tab = *reinterpret_cast<const uint4 *>(&a.ro[SKP_TAB][v]);
+    const uint4 gn = *reinterpret_cast<const uint4 *>(&a.ro[SKP_GAIN][v]);
+    const uint4 s0 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_OSC][v]);
+    const uint4 s1 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_FILT][v]);
+    const uint4 s2 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_MISC][v]);
+    r.inc[c] = __uint_as_float(osc.x); r.lo[c] = __uint_as_float(osc.y);
+    r.hi[c] = __uint_as_float(osc.z);
+    e.ampv[c] = __uint_as_float(osc.w);
+    r.toff4[c] = (int)tab.x << 2; r.tsize_m1[c] = (int)tab.y - 1;
+    const uint32_t flags = tab.z;
+    e.velv[c] = __uint_as_float(gn.x); r.k[c] = __uint_as_float(gn.y);
+    r.b0[c] = __uint_as_float(gn.z);   r.b1[c] = __uint_as_float(gn.w);
+    r.phase[c] = __uint_as_float(s0.x); r.sgain[c] = __uint_as_float(s0.y);
+    r.x1[c] = __uint_as_float(s0.z);    r.x2[c] = __uint_as_float(s0.w);
+    r.y1[c] = __uint_as_float(s1.x);    r.y2[c] = __uint_as_float(s1.y);
+    r.sample[c] = __uint_as_float(s1.z); r.rw[c] = s1.w;
+    r.pan_l[c] = __uint_as_float(s2.z); r.pan_r[c] = __uint_as_float(s2.w);
+    r.b2[c] = 0.0f; r.a1[c] = 0.0f; r.a2[c] = 0.0f;
+    if (FILTER) {
+      const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
+      r.b2[c] = __uint_as_float(fl.x); r.a1[c] = __uint_as_float(fl.y); r.a2[c] = __uint_as_float(fl.z);
+    }
+    released[c] = false; t_start[c] = 0; t_release[c] = 0;
+    r.gain_const[c] = e.ampv[c];                       // no envelope: amp * 1.0f * 1.0f
+    e.att[c] = e.attdec[c] = e.dec[c] = e.rel[c] = 0.0f;
+    e.susv[c] = 0.0f; e.omsv[c] = 0.0f; e.tf[c] = 0.0f; e.trf[c] = 0.0f;
+    if (ENV) {
+      const uint4 et = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_T][v]);
+      const uint4 es = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_S][v]);
+      e.att[c] = __uint_as_float(et.x); e.dec[c] = __uint_as_float(et.y);
+      e.susv[c] = __uint_as_float(et.z); e.rel[c] = __uint_as_float(et.w);
+      e.attdec[c] = e.att[c] + e.dec[c];               // synth.c:410: decay_start + decay_time
+      e.omsv[c] = 1.0f - e.susv[c];                    // synth.c:413
+      t_start[c] = ((uint64_t)es.y << 32) | es.x;
+      t_release[c] = ((uint64_t)es.w << 32) | es.z;
+      released[c] = t_release[c] != 0;                 // synth.c:417
+    }
+    dead[c] = (r.rw[c] & SKR_FINISHED) || e.ampv[c] == 0.0f || (flags & SKF_INERT);
+    silent[c] = dead[c] || (flags & SKF_MUTED);
+    if (dead[c]) {   // never stored back: inert numbers -> exact zeros, table index 0 (see sk_render_fast_kernel)
+      r.inc[c] = 0.0f; r.lo[c] = 0.0f; r.hi[c] = 1.0f; r.phase[c] = 0.0f;
+      r.toff4[c] = 0; r.tsize_m1[c] = 0;
+      r.k[c] = 0.0f; r.sgain[c] = 0.0f; e.ampv[c] = 0.0f; r.gain_const[c] = 0.0f;
+      r.b0[c] = r.b1[c] = r.b2[c] = r.a1[c] = r.a2[c] = 0.0f;
+      r.x1[c] = r.x2[c] = r.y1[c] = r.y2[c] = 0.0f;
+      r.pan_l[c] = r.pan_r[c] = 0.0f; r.rw[c] &= ~SKR_ENV_ACTIVE;
+    }
+  }
+  r.span = r.hi - r.lo;
+  r.span2 = r.span + r.span;
+  bool tame_lane = true;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    tame_lane = tame_lane && !(silent[c] && !dead[c]) &&
+                (dead[c] || (r.inc[c] >= 0.0f && r.inc[c] <= 0.5f * r.span[c] && r.phase[c] >= r.lo[c] &&
+                             r.phase[c] <= r.hi[c] && r.lo[c] >= 0.0f && r.hi[c] <= (float)(r.tsize_m1[c] + 1)));
+  return __all(tame_lane);
+}
+
+__device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fast2Regs &r, const bool dead[2],
+                                            const int vidx[2]) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int v = vidx[c];
+    if (!dead[c]) {
+      uint4 s0, s1;
+      s0.x = __float_as_uint(r.phase[c]); s0.y = __float_as_uint(r.sgain[c]);
+      s0.z = __float_as_uint(r.x1[c]);    s0.w = __float_as_uint(r.x2[c]);
+      s1.x = __float_as_uint(r.y1[c]);    s1.y = __float_as_uint(r.y2[c]);
+      s1.z = __float_as_uint(r.sample[c]); s1.w = r.rw[c];
+      *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
+      *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;
+    } else {
+      reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][v])[2] = 0u;     // voice_sample = 0, synth.c:532,538
+    }
+  }
+}
+
+#define SK_FAST2_PROLOGUE()                                                                          \
+  extern __shared__ float lds[];                                                                     \
+  float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));               \
+  const char *lds_tab = reinterpret_cast<const char *>(lds);                                         \
+  const char *glb_tab = reinterpret_cast<const char *>(a.tables);                                    \
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                     \
+  float2 *xp = wsum + 4 * SK_CHUNK + wave * (8 * 65 + 64);   /* wave-private: tile [8][65] then xq [64] */ \
+  float2 *xq = xp + 8 * 65;                                                                          \
+  (void)xp; (void)xq;                                                                                \
+  if (TAB_LDS) {                                                                                     \
+    const int n4 = a.lds_table_floats >> 2;                                                          \
+    const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);                                 \
+    float4 *dst4 = reinterpret_cast<float4 *>(lds);                                                  \
+    for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];                                      \
+    __syncthreads();                                                                                 \
+  }                                                                                                  \
+  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;                            \
+  const int n_groups2 = a.n_groups >> 1;   /* 512 voices per workgroup pass (host pads to 512) */
+
+#ifndef SK_FAST2_MIN_WAVES
+#define SK_FAST2_MIN_WAVES 4     /* <= 128 VGPRs */
+#endif
+
+// Constant-level groups.  ENV: the bank uses envelopes, so every group is classified first.
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
+__global__ __launch_bounds__(SK_GROUP, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
+  SK_FAST2_PROLOGUE()
+  bool first_pass = true;
+  for (int g = blockIdx.x; g < n_groups2; g += gridDim.x) {
+    Fast2Regs r;
+    Env2Regs e;
+    bool dead[2], silent[2], released[2];
+    uint64_t t_start[2], t_release[2];
+    int vidx[2];
+    const bool tame = fast2_load<FILTER, ENV>(a, g, wave, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    if (ENV) {
+      // constant envelope level on the first frame of the launch <=> for the whole launch (absorbing codes)
+      bool ok = true;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint64_t d_on = a.count0 + 1 - t_start[c], d_off = a.count0 + 1 - t_release[c];
+        const int code = env_stage_code((r.rw[c] & SKR_ENV_ACTIVE) != 0, released[c], (float)d_on, (float)d_off,
+                                        e.att[c], e.attdec[c], e.rel[c]);
+        ok = ok && (dead[c] || code == 0 || code == 3 || code == 5);
+        const float level = code == 3 ? e.susv[c] : 0.0f;
+        r.gain_const[c] = e.ampv[c] * (level * e.velv[c]);                       // synth.c:582,588
+        if (!dead[c] && code == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;                   // synth.c:429
+      }
+      const int group_ok = __syncthreads_and(ok ? 1 : 0);
+      if (tid == 0) a.group_flag[g] = group_ok ? 0 : 1;
+      if (!group_ok) continue;                          // sk_render_env2_kernel renders this group
+    }
+    for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
+      const int cn = min(SK_CHUNK, a.num_frames - c0);
+      SK_FAST2_CHUNK(0)
+      SK_FAST2_FLUSH(!first_pass)
+    }
+    fast2_store(a, r, dead, vidx);
+    first_pass = false;
+  }
+  if (first_pass) {   // every group of this workgroup was deferred: its partial-mix row must still exist
+    for (int i = tid; i < 2 * a.num_frames; i += SK_GROUP) a.partial[part_base + i] = 0.0f;
+  }
+}
+
+// Groups with envelopes in motion (flagged by sk_render_fast2_kernel, which ran just before on the stream).
+#ifndef SK_ENV2_MIN_WAVES
+#define SK_ENV2_MIN_WAVES 3      /* the envelope machinery wants ~170 VGPRs: 3 waves per SIMD measured best (2: no spills, 4: 220 B of scratch) */
+#endif
+template <bool TAB_LDS, bool FILTER, int INTERP>
+__global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
+  SK_FAST2_PROLOGUE()
+  for (int g = blockIdx.x; g < n_groups2; g += gridDim.x) {
+    if (a.group_flag[g] == 0) continue;
+    Fast2Regs r;
+    Env2Regs e;
+    bool dead[2], silent[2], released[2];
+    uint64_t t_start[2], t_release[2];
+    int vidx[2];
+    const bool tame = fast2_load<FILTER, true>(a, g, wave, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    bool all_const_from_here = false;
+    for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
+      const int cn = min(SK_CHUNK, a.num_frames - c0);
+      bool steady = true, exact = true, ramp = false;
+      float cb_tf[2] = {0.0f, 0.0f}, cb_trf[2] = {0.0f, 0.0f};     // clocks of the frame BEFORE the chunk
+      if (!all_const_from_here) {
+        const uint64_t base = a.count0 + (uint64_t)c0;              // frame c0+j has now = base + j + 1 (synth.c:521)
+        const uint64_t lim = (1ull << 24) - (uint64_t)SK_CHUNK - 2; // x + 1.0f stays exact below 2^24
+        bool ex = true, st = true, same = true;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint64_t d_on = base - t_start[c], d_off = base - t_release[c];
+          ex = ex && (dead[c] || ((d_on < lim) && (!released[c] || d_off < lim)));
+          cb_tf[c] = (float)d_on;
+          cb_trf[c] = released[c] ? (float)d_off : 0.0f;
+          fast2_env_span(r, e, c, dead[c], released[c], (float)(d_on + 1), (float)(d_off + 1),
+                         (float)(d_on + (uint64_t)cn), (float)(d_off + (uint64_t)cn), cb_tf[c], cb_trf[c], st, same);
+        }
+        exact = __all(ex);
+        steady = __all(st);
+        ramp = !steady && exact && __all(same);
+        all_const_from_here = steady;       // constant levels are absorbing within a launch
+      }
+      if (steady) {
+        SK_FAST2_CHUNK(0)
+      } else if (ramp) {
+        SK_FAST2_CHUNK(1)
+      } else if (exact && tame && !(cn & 7)) {
+        // some lane changes stage inside this chunk: re-decide per 8-frame block (clocks are exact floats here)
+        for (int jb = 0; jb < cn; jb += 8) {
+          bool st = true, same = true;
+          const float fb = (float)jb;
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            fast2_env_span(r, e, c, dead[c], released[c], cb_tf[c] + fb + 1.0f, cb_trf[c] + fb + 1.0f,
+                           cb_tf[c] + fb + 8.0f, cb_trf[c] + fb + 8.0f, cb_tf[c] + fb, cb_trf[c] + fb, st, same);
+          const bool b_const = __all(st), b_ramp = __all(same);
+#if SK_LDS_REDUCE
+          if (TAB_LDS && b_const) SK_FAST2_LDS_BLOCK(jb, 0)
+          else if (TAB_LDS && b_ramp) SK_FAST2_LDS_BLOCK(jb, 1)
+          else
+#endif
+          {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { e.tf[c] = cb_tf[c] + fb; e.trf[c] = cb_trf[c] + fb; }
+            for (int q = 0; q < 8; q += 2) {
+              float l0, r0, l1, r1;
+              e.tf[0] += 1.0f; e.trf[0] += 1.0f; e.tf[1] += 1.0f; e.trf[1] += 1.0f;
+              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);
+              e.tf[0] += 1.0f; e.trf[0] += 1.0f; e.tf[1] += 1.0f; e.trf[1] += 1.0f;
+              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);
+              { const int J_ = jb + q; wave_sum4_to_lane63(l0, r0, l1, r1);
+                if (lane == 63) *reinterpret_cast<float4 *>(&wsum[wave * SK_CHUNK + J_]) = make_float4(l0, r0, l1, r1); }
+            }
+          }
+        }
+      } else {
+        // clocks past 2^24 frames, ragged chunk lengths, untame waves: integer clocks, one frame at a time
+        for (int j = 0; j < cn; ++j) {
+          const uint64_t now = a.count0 + (uint64_t)(c0 + j) + 1;
+          e.tf[0] = (float)(now - t_start[0]); e.trf[0] = (float)(now - t_release[0]);
+          e.tf[1] = (float)(now - t_start[1]); e.trf[1] = (float)(now - t_release[1]);
+          SK_FAST2_ONE(j, 2, false)
+        }
+      }
+      SK_FAST2_FLUSH(true)
+    }
+    fast2_store(a, r, dead, vidx);
+  }
+}
+
+// ---------------------------------------------------------------- launcher (C linkage)
+
+// sk_render_fast2_kernel renders the constant-envelope groups and flags the others; when the bank has
+// envelopes at all, sk_render_env2_kernel follows on the same stream and renders the flagged groups.
+extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
+                                      hipStream_t stream) {
+  const bool tab_lds = args->lds_table_floats > 0;
+  lds_bytes += (size_t)4 * (8 * 65 + 64) * sizeof(float2);   // per-wave transposition tile + row sums
+  dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
+  const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
+                  ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
+#define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
+  case K:                                                                                               \
+    hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I>), grid, block, lds_bytes, stream, *args);    \
+    if (E) hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I>), grid, block, lds_bytes, stream, *args); \
+    break;
+  switch (key) {
+    SK_FAST2_CASE(0, false, false, false, 0) SK_FAST2_CASE(1, false, false, false, 1)
+    SK_FAST2_CASE(2, false, false, true, 0)  SK_FAST2_CASE(3, false, false, true, 1)
+    SK_FAST2_CASE(4, false, true, false, 0)  SK_FAST2_CASE(5, false, true, false, 1)
+    SK_FAST2_CASE(6, false, true, true, 0)   SK_FAST2_CASE(7, false, true, true, 1)
+    SK_FAST2_CASE(8, true, false, false, 0)  SK_FAST2_CASE(9, true, false, false, 1)
+    SK_FAST2_CASE(10, true, false, true, 0)  SK_FAST2_CASE(11, true, false, true, 1)
+    SK_FAST2_CASE(12, true, true, false, 0)  SK_FAST2_CASE(13, true, true, false, 1)
+    SK_FAST2_CASE(14, true, true, true, 0)   SK_FAST2_CASE(15, true, true, true, 1)
+  }
+#undef SK_FAST2_CASE
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,352 @@
+// skred_render_generic.hip -- the general render kernels (any bank; modulated banks) + the launch dispatcher.
+//
+// What is computed: the two nested loops of the reference's synth() (synth.c:520-613):
+// for every frame, for every voice: phase-accumulator oscillator with table lookup
+// (osc_next, synth.c:217-275), sample&hold / bit-crush (synth.c:560-574,341-345), RBJ biquad
+// (mmf_process, synth.c:349-364), linear ADSR keyed on the global sample counter
+// (amp_envelope_step, synth.c:398-431), one-pole amp smoother (synth.c:588-593), pan and the
+// polyphonic stereo sum (synth.c:595-612); then the master volume stage (synth.c:616-624).
+//
+// Mapping to the machine:
+//   * one lane per voice, 64 voices per wavefront, 256 per workgroup pass; the time loop runs
+//     INSIDE the kernel with all recurrences (phase, smoother, biquad delay line) in registers;
+//   * voice parameters/state are 16-byte planes (skred_device_layout.h): one coalesced
+//     dwordx4 load per plane per launch, one dwordx4 store per read-write plane;
+//   * wavetables are staged into LDS once per workgroup when the pool fits (gather = ds_read);
+//     larger pools (PCM) are gathered from L2/HBM;
+//   * per frame the 64 lanes' L/R are summed with a fixed-order DPP reduction (no LDS traffic,
+//     no atomics: results are bit-reproducible run to run); wave sums meet in LDS every
+//     SK_CHUNK frames and leave as coalesced stores into a per-workgroup partial mix;
+//   * no MFMA: this is gather + multiply-add along a serial recurrence, not a contraction.
+//
+// Arithmetic contract (must match oracle/cpu_ref.c bit for bit per voice): compiled with
+// -ffp-contract=off (no FMA fusion), fp32 subnormals kept (hipcc default), IEEE-rounded
+// divide (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), exact fmod.
+#include <hip/hip_runtime.h>
+#include "skred_kernel_common.hpp"
+#include "skred_launch.h"
+
+// ---------------------------------------------------------------- render kernel
+
+// LDS: [lds_table_floats] staged table pool, then [4 waves][SK_CHUNK][2] wave sums.
+template <bool TAB_LDS, bool STEMS>
+__global__ __launch_bounds__(SK_GROUP) void sk_render_kernel(const sk_render_args_t a) {
+  extern __shared__ float lds[];
+  float *lds_tab = lds;
+  float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  if (TAB_LDS) {
+    // stage the whole pool; float4 when aligned, coalesced
+    const int n4 = a.lds_table_floats >> 2;
+    const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);
+    float4 *dst4 = reinterpret_cast<float4 *>(lds_tab);
+    for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];
+    for (int i = (n4 << 2) + tid; i < a.lds_table_floats; i += SK_GROUP) lds_tab[i] = a.tables[i];
+    __syncthreads();
+  }
+
+  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;
+  bool first_pass = true;
+
+  for (int g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+    const int v = g * SK_GROUP + tid;
+    VoiceRegs r;
+    load_voice(a, v, r);
+
+    uint64_t rng = a.rng0;
+    for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
+      const int cn = min(SK_CHUNK, a.num_frames - c0);
+      for (int j = 0; j < cn; ++j) {
+        const int i = c0 + j;
+        const uint64_t now = a.count0 + (uint64_t)i + 1;       // synth.c:521 (pre-increment)
+        float white = 0.0f;
+        if (a.features & SKB_ANY_NOISE) {                        // synth.c:525, one draw per frame
+          rng = rng * LCG_A + LCG_C;
+          white = (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f;
+        }
+        float l, rr;
+        voice_frame<TAB_LDS>(r, lds_tab, a.tables, now, white, a.interp, l, rr);
+        if (STEMS) {
+          if (v < a.n_voices)
+            reinterpret_cast<float2 *>(a.stems)[(size_t)i * (size_t)a.n_voices + (size_t)v] =
+                make_float2(l, rr);
+        }
+        float sl = l, sr = rr;
+        wave_sum2_to_lane63(sl, sr);
+        if (lane == 63) wsum[wave * SK_CHUNK + j] = make_float2(sl, sr);
+      }
+      __syncthreads();
+      if (tid < 2 * cn) {
+        const float *w = reinterpret_cast<const float *>(wsum);
+        float s = w[0 * 2 * SK_CHUNK + tid];
+        s += w[1 * 2 * SK_CHUNK + tid];
+        s += w[2 * 2 * SK_CHUNK + tid];
+        s += w[3 * 2 * SK_CHUNK + tid];
+        float *p = a.partial + part_base + (size_t)c0 * 2 + tid;
+        if (first_pass) *p = s; else *p += s;
+      }
+      __syncthreads();
+    }
+    store_voice(a, v, r);
+    first_pass = false;
+  }
+}
+
+// ---------------------------------------------------------------- modulated banks
+//
+// Cross-voice modulation (FM synth.c:548-558, AM 584-587, pan 597-602, CZ amount 262-267) and CZ
+// phase distortion (cz_phasor, synth.c:149-215).  The reference walks voices in index order inside a
+// frame, so a carrier n sees THIS frame's voice_sample[m] of a modulator m < n and the PREVIOUS
+// frame's of a modulator m > n.  Here a workgroup is one wavefront = one aligned group of 64 voices
+// (the reference's VOICE_MAX; the host refuses banks whose modulators leave their group).  The host
+// assigns every voice a dependency level (0 = needs no same-frame value; else 1 + max level of its
+// modulators with a lower index); per frame the levels run one after the other, exchanging
+// voice_sample through two LDS arrays (previous / current frame).  Cost = (max level + 1) passes per
+// frame -- irrelevant for the 64-voice drop-in, and banks without modulators never come here.
+
+// == fast_pow, synth.c:140-147.  The float->int cast saturates on the GPU exactly where the x86
+// conversion of the reference returns INT_MIN (large negative products), so the bits agree.
+__device__ __forceinline__ float pow_bits(float base, float expo) {
+  if (base <= 0.0f) return 0.0f;
+  int i = __float_as_int(base);
+  i = (int)(expo * (float)(i - 1065353216) + 1065353216.0f);
+  return __int_as_float(i);
+}
+
+// == cz_phasor, synth.c:149-215
+__device__ float cz_warp(int mode, float table_phase, float amount, int table_size) {
+  const float size_f = (float)table_size;
+  float x = table_phase / size_f;
+  float d = amount;
+  if (d < 0.0f) d = 0.0f; else if (d > 0.999f) d = 0.999f;
+  switch (mode) {
+    case 1: {
+      const float k_lo = 0.5f / d, k_hi = 0.5f / (1.0f - d);
+      x = (x < d) ? x * k_lo : 0.5f + (x - d) * k_hi;
+      break;
+    }
+    case 2: {
+      const float k = 0.5f / (0.5f - d * 0.5f);
+      x = (x < 0.5f) ? x * k : 1.0f - (1.0f - x) * k;
+      break;
+    }
+    case 3: {
+      const float k = 0.5f / (0.5f - d * 0.5f);
+      x = (x < 0.5f) ? x * k : 0.5f + (x - 0.5f) * k;
+      break;
+    }
+    case 4: x = fmodf(x * 2.0f, 1.0f); break;
+    case 5: {
+      const float h = d * 0.5f;
+      const float k_lo = 0.5f / (0.5f - h), k_hi = 0.5f / (0.5f + h);
+      x = (x < 0.5f) ? x * k_lo : 0.5f + (x - 0.5f) * k_hi;
+      break;
+    }
+    case 6: x = pow_bits(x, 1.0f + 4.0f * d); break;
+    case 7: x = pow_bits(x, 1.0f + 8.0f * d); break;
+    default: return table_phase;
+  }
+  return x * size_f;
+}
+
+struct ModRegs {
+  int fm, am, pm, cz;            // modulator lane inside the 64-voice group, or -1
+  float fm_depth, freq_scale, am_depth, pm_depth, cz_depth, cz_dist;
+  int cz_mode, level;
+  float inc_raw;                 // voice_phase_inc before the direction sign
+};
+
+// One voice, one frame, with modulation: synth.c:531-612.  `prev`/`cur` are the LDS exchange arrays.
+__device__ __forceinline__ void voice_frame_mod(VoiceRegs &r, const ModRegs &m, int lane,
+                                                const float *prev, float *cur, const float *incs,
+                                                const float *__restrict__ tab, uint64_t now, float white,
+                                                int interp, float &out_l, float &out_r) {
+  auto other = [&](int src) -> float { return src < lane ? cur[src] : prev[src]; };
+  out_l = 0.0f; out_r = 0.0f;
+  float raw;
+  if (r.flags & SKF_NOISE) {
+    raw = white;
+  } else {
+    float inc = m.inc_raw;
+    if (m.fm >= 0 && m.fm != lane) {                                   // synth.c:548-555
+      const float g = other(m.fm) * m.fm_depth;
+      inc = inc + (incs[m.fm] * m.freq_scale * g);
+    }
+    if (r.flags & SKF_REVERSE) inc = -inc;
+    float ph = r.phase + inc;
+    if (!__builtin_isfinite(ph)) {
+      r.phase = 0.0f;
+      if (r.flags & SKF_ONE_SHOT) r.rw |= SKR_FINISHED;
+      raw = 0.0f;
+    } else {
+      const bool stops = (r.flags & SKF_ONE_SHOT) && !(r.flags & SKF_LOOPING);
+      const float span = r.hi - r.lo;
+      if (ph >= r.hi) {
+        if (stops) { ph = r.hi - 1e-6f; r.rw |= SKR_FINISHED; }
+        else ph = r.lo + fmod_pos(ph - r.lo, span);
+      } else if (ph < r.lo) {
+        if (stops) { ph = r.lo; r.rw |= SKR_FINISHED; }
+        else ph = r.hi - fmod_pos(r.lo - ph, span);
+      }
+      r.phase = ph;
+      float pos = ph;
+      if (m.cz_mode) {                                                 // synth.c:262-267
+        // the carrier's own voice_sample still holds last frame's value at this point
+        const float dm = (m.cz >= 0) ? (m.cz == lane ? prev[lane] : other(m.cz)) * m.cz_depth : 1.0f;
+        pos = cz_warp(m.cz_mode, ph, m.cz_dist + dm, r.tsize);
+      }
+      raw = table_fetch<false>(nullptr, tab, r, pos, interp, !stops);
+    }
+  }
+  if (r.hold_max) {
+    if (r.hold_count == 0) r.hold = raw;
+    raw = r.hold;
+    if (++r.hold_count >= r.hold_max) r.hold_count = 0;
+  }
+  float s = raw;
+  if (r.quant) s = crush(s, r.quant);
+  if (r.flags & SKF_FILTER) {
+    float y = r.b0 * s;
+    y = y + r.b1 * r.x1;
+    y = y + r.b2 * r.x2;
+    y = y - r.a1 * r.y1;
+    y = y - r.a2 * r.y2;
+    r.x2 = r.x1; r.x1 = s;
+    r.y2 = r.y1; r.y1 = y;
+    s = y;
+  }
+  float env = 1.0f;
+  if (r.flags & SKF_USE_ENV) {
+    float e = 0.0f;
+    if (r.rw & SKR_ENV_ACTIVE) {
+      const float t = (float)(now - r.t_start);
+      if (t < r.att) {
+        e = t / r.att;
+      } else if (t < r.att + r.dec) {
+        const float prog = (t - r.att) / r.dec;
+        e = 1.0f - prog * (1.0f - r.sus);
+      } else if (r.t_release == 0) {
+        e = r.sus;
+      } else {
+        const float tr = (float)(now - r.t_release);
+        if (tr < r.rel) {
+          const float prog = tr / r.rel;
+          e = r.sus * (1.0f - prog);
+        } else {
+          r.rw &= ~SKR_ENV_ACTIVE;
+        }
+      }
+    }
+    env = e * r.vel;
+  }
+  float am = 1.0f;                                                     // synth.c:583-587
+  if (m.am >= 0) am = (m.am == lane ? s : other(m.am)) * m.am_depth;   // own slot holds the post-filter sample
+  float gain = r.amp * env * am;
+  if (r.flags & SKF_SMOOTH) {
+    r.sgain += r.smooth_k * (gain - r.sgain);
+    gain = r.sgain;
+  }
+  s *= gain;
+  r.sample = s;
+  if (!(r.flags & SKF_MUTED)) {
+    if (m.pm >= 0) {                                                   // synth.c:597-602
+      const float q = (m.pm == lane ? s : other(m.pm)) * m.pm_depth;
+      r.pan_l = (1.0f - q) / 2.0f;
+      r.pan_r = (1.0f + q) / 2.0f;
+    }
+    out_l = s * r.pan_l;
+    out_r = s * r.pan_r;
+  }
+}
+
+template <bool STEMS>
+__global__ __launch_bounds__(64) void sk_render_mod_kernel(const sk_render_args_t a, const int *__restrict__ levels,
+                                                           int max_level) {
+  __shared__ float xch[2][64];
+  __shared__ float incs[64];
+  const int lane = threadIdx.x;
+  const int v = blockIdx.x * 64 + lane;
+  VoiceRegs r;
+  load_voice(a, v, r);
+  ModRegs m;
+  {
+    const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
+    const uint4 mf = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODF][v]);
+    const uint4 mx = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODX][v]);
+    const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
+    m.fm = (int)mi.x; m.am = (int)mi.y; m.pm = (int)mi.z; m.cz = (int)mi.w;
+    m.fm_depth = __uint_as_float(mf.x); m.freq_scale = __uint_as_float(mf.y);
+    m.am_depth = __uint_as_float(mf.z); m.pm_depth = __uint_as_float(mf.w);
+    m.cz_depth = __uint_as_float(mx.x); m.cz_mode = (int)mx.y;
+    m.cz_dist = __uint_as_float(fl.w);
+    m.level = levels[v];
+    m.inc_raw = (r.flags & SKF_REVERSE) ? -r.inc : r.inc;    // load_voice applied the direction sign
+  }
+  incs[lane] = m.inc_raw;
+  xch[0][lane] = r.sample;                                   // voice_sample[] as the last callback left it
+  __syncthreads();
+
+  uint64_t rng = a.rng0;
+  int cur_i = 1;
+  float *part = a.partial + (size_t)blockIdx.x * (size_t)a.num_frames * 2;
+  for (int i = 0; i < a.num_frames; ++i) {
+    const uint64_t now = a.count0 + (uint64_t)i + 1;
+    rng = rng * LCG_A + LCG_C;
+    const float white = (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f;
+    float *cur = xch[cur_i];
+    const float *prev = xch[cur_i ^ 1];
+    const bool live = !((r.rw & SKR_FINISHED) || r.amp == 0.0f || (r.flags & SKF_INERT));
+    if (!live) { r.sample = 0.0f; cur[lane] = 0.0f; }         // synth.c:531-542
+    __syncthreads();
+    float l = 0.0f, rr = 0.0f;
+    for (int lev = 0; lev <= max_level; ++lev) {
+      if (live && m.level == lev) {
+        voice_frame_mod(r, m, lane, prev, cur, incs, a.tables, now, white, a.interp, l, rr);
+        cur[lane] = r.sample;
+      }
+      __syncthreads();
+    }
+    if (STEMS) {
+      if (v < a.n_voices)
+        reinterpret_cast<float2 *>(a.stems)[(size_t)i * (size_t)a.n_voices + (size_t)v] = make_float2(l, rr);
+    }
+    float sl = l, sr = rr;
+    wave_sum2_to_lane63(sl, sr);
+    if (lane == 63) reinterpret_cast<float2 *>(part)[i] = make_float2(sl, sr);
+    cur_i ^= 1;
+  }
+  store_voice(a, v, r);
+}
+// ---------------------------------------------------------------- launchers (C linkage)
+
+extern "C" int sk_launch_render(const sk_render_args_t *args, int n_workgroups, hipStream_t stream) {
+  const bool tab_lds = args->lds_table_floats > 0;
+  const bool stems = args->stems != nullptr;
+  const size_t lds_bytes = (size_t)(tab_lds ? args->lds_table_floats : 0) * sizeof(float) +
+                           (size_t)4 * SK_CHUNK * sizeof(float2);
+  // clean banks (skred_bank.c:classify) have specialised kernels; stems need the generic one
+  if ((args->fast_mode & SKM_FAST) && !stems)
+    return (args->fast_mode & SKM_TWO_PER_LANE) ? sk_launch_render_fast2(args, n_workgroups, lds_bytes, stream)
+                                                : sk_launch_render_fast(args, n_workgroups, lds_bytes, stream);
+  dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
+  if (tab_lds) {
+    if (stems) hipLaunchKernelGGL((sk_render_kernel<true, true>), grid, block, lds_bytes, stream, *args);
+    else       hipLaunchKernelGGL((sk_render_kernel<true, false>), grid, block, lds_bytes, stream, *args);
+  } else {
+    if (stems) hipLaunchKernelGGL((sk_render_kernel<false, true>), grid, block, lds_bytes, stream, *args);
+    else       hipLaunchKernelGGL((sk_render_kernel<false, false>), grid, block, lds_bytes, stream, *args);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int sk_launch_render_mod(const sk_render_args_t *args, int n_groups64, const int *levels,
+                                    int max_level, hipStream_t stream) {
+  dim3 grid((unsigned)n_groups64), block(64);
+  if (args->stems) hipLaunchKernelGGL((sk_render_mod_kernel<true>), grid, block, 0, stream, *args, levels, max_level);
+  else             hipLaunchKernelGGL((sk_render_mod_kernel<false>), grid, block, 0, stream, *args, levels, max_level);
+  return (int)hipGetLastError();
+}

@@ -11,7 +11,7 @@ gloo tests on CPU (tests/test_sharded_gloo.py: callables wrap the oracle).
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -39,6 +39,9 @@ class ShardedRender:
     def __init__(self, total_voices: int, rank: int = 0, world: int = 1, root: int = 0):
         self.total, self.rank, self.world, self.root = total_voices, rank, world, root
         self.lo, self.hi = partition(total_voices, world, rank)
+        self._bufs: Optional[Sequence[torch.Tensor]] = None
+        self._work: List[Optional[object]] = [None, None]
+        self._k = 0
 
     @property
     def n_local(self) -> int:
@@ -53,3 +56,46 @@ class ShardedRender:
             dist.reduce(partial, dst=self.root, op=dist.ReduceOp.SUM)
         if self.rank == self.root:
             master(partial, out)
+
+    # ---- overlapped form ("launch k+1 renders while launch k reduces") ----
+    #
+    # Two partial buffers alternate.  Block k is rendered into buffer k&1 and its reduce is started
+    # asynchronously; the root runs the master stage for block k-1 meanwhile, so a block's mix is
+    # delivered one call later (and the last one by drain()).  With RCCL, Work.wait() only makes the
+    # current HIP stream wait for the collective -- the host never blocks -- so render k+1 and
+    # reduce k run concurrently on the device.  Output samples are identical to step()'s.
+
+    def begin(self, partials: Sequence[torch.Tensor]) -> None:
+        assert len(partials) == 2 and self._k == 0
+        self._bufs = partials
+
+    def _deliver(self, j: int, master, out) -> None:
+        if self._work[j] is not None:
+            self._work[j].wait()
+            self._work[j] = None
+        if self.rank == self.root:
+            master(self._bufs[j], out)
+
+    def step_overlapped(self, render_partial: Callable[[torch.Tensor], None],
+                        master: Callable[[torch.Tensor, torch.Tensor], None], out: torch.Tensor) -> bool:
+        """Render block k, start its reduce, finish block k-1.  True when `out` now holds block k-1."""
+        i = self._k & 1
+        if self._work[i] is not None:          # the reduce of block k-2 still owns this buffer
+            self._work[i].wait()
+            self._work[i] = None
+        render_partial(self._bufs[i])
+        if self.world > 1:
+            self._work[i] = dist.reduce(self._bufs[i], dst=self.root, op=dist.ReduceOp.SUM, async_op=True)
+        delivered = self._k > 0
+        if delivered:
+            self._deliver(1 - i, master, out)
+        self._k += 1
+        return delivered
+
+    def drain(self, master: Callable[[torch.Tensor, torch.Tensor], None], out: torch.Tensor) -> bool:
+        """Finish the block still in flight.  True when `out` now holds it."""
+        if self._k == 0:
+            return False
+        self._deliver((self._k - 1) & 1, master, out)
+        self._k = 0
+        return True

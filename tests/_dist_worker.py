@@ -18,6 +18,7 @@ from skred_amd.sharded import ShardedRender, modulation_components_ok  # noqa: E
 
 def main():
     out_path, n, frames, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    overlapped = len(sys.argv) > 5 and sys.argv[5] == "overlapped"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     full, tables, g = banks.bank_c2(n)
@@ -37,10 +38,18 @@ def main():
     def master(p, o):
         o.copy_(torch.from_numpy(cpuref.master(g_master, p.numpy())))
 
-    for _ in range(steps):
-        sh.step(render_partial, master, partial, out)
-        if rank == 0:
+    if overlapped:
+        sh.begin([partial, torch.zeros_like(partial)])
+        for _ in range(steps):
+            if sh.step_overlapped(render_partial, master, out) and rank == 0:
+                outs.append(out.numpy().copy())
+        if sh.drain(master, out) and rank == 0:
             outs.append(out.numpy().copy())
+    else:
+        for _ in range(steps):
+            sh.step(render_partial, master, partial, out)
+            if rank == 0:
+                outs.append(out.numpy().copy())
     if rank == 0:
         np.save(out_path, np.concatenate(outs))
     dist.barrier()

@@ -34,9 +34,10 @@ def test_partition_covers_bank():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.parametrize("world,n", [(2, 2048), (3, 1000)])
-def test_sharded_matches_single_process(tmp_path, world, n):
-    frames, steps = 256, 3
+@pytest.mark.parametrize("world,n,mode", [(2, 2048, "sync"), (3, 1000, "sync"), (2, 2048, "overlapped"),
+                                          (3, 1000, "overlapped")])
+def test_sharded_matches_single_process(tmp_path, world, n, mode):
+    frames, steps = 256, 4 if mode == "overlapped" else 3
     out = str(tmp_path / "mix.npy")
     port = free_port()
     procs = []
@@ -44,10 +45,11 @@ def test_sharded_matches_single_process(tmp_path, world, n):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), out,
-                                       str(n), str(frames), str(steps)], env=env))
+                                       str(n), str(frames), str(steps), mode], env=env))
     for p in procs:
         assert p.wait(timeout=240) == 0
     got = np.load(out)
+    assert got.shape == (frames * steps, 2)
     bank, tables, g = banks.bank_c2(n)
     ref, _ = cpuref.synth(bank, g, tables, frames * steps)
     err = np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))

@@ -41,6 +41,7 @@ enum {
   SKRED_E_NO_MEM = -3,
   SKRED_E_RANGE = -4,       /* voice window or table offset outside the bank / pool */
   SKRED_E_UNSUPPORTED = -5, /* feature of synth() not implemented by the kernels (see flags) */
+  SKRED_E_IO = -6,          /* file cannot be opened / written (skred_wav.h) */
 };
 
 /* ---- structs kept from the reference (layout-identical) ---------------- */

@@ -190,6 +190,12 @@ void skred_patch_init(skred_patch_t *p);
 int  skred_patch_line(skred_patch_t *p, const char *line);  /* returns unsupported tokens met in this line */
 int  skred_patch_load(const char *path, skred_patch_t *p);  /* -1: cannot open; else total unsupported tokens */
 
+/* ---- `:wN,slot,ch` -- N.wav -> EXT slot (wire.c:406-441 wave_load, with include/skred_wav.h's reader) ----
+ * 0 on success, SKRED_ERR_INVALID_EXT_SAMPLE when the slot is outside [200, 1199) or the file cannot be
+ * decoded (the reference returns ERR_INVALID_EXT_SAMPLE, wire.h:152, in both cases). */
+#define SKRED_ERR_INVALID_EXT_SAMPLE 17   /* position of ERR_INVALID_EXT_SAMPLE in wire.h:134-155 */
+int skred_wave_load(int which, int where, int ch);
+
 /* ---- additions of this build (no counterpart in the reference) ---- */
 int         skred_synth_last_rc(void);          /* SKRED_E_* of the most recent synth() call */
 const char *skred_synth_last_error(void);

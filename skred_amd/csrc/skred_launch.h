@@ -6,13 +6,19 @@
  *   skred_render_fast.hip     sk_launch_render_fast
  *   skred_render_fast2.hip    sk_launch_render_fast2
  *   skred_mix_kernels.hip     sk_launch_reduce, sk_reduce_tmp_floats, sk_launch_master
+ *   skred_rec_kernels.hip     sk_launch_rec_minmax, sk_rec_partial_floats, sk_launch_rec_convert
  *
  * Every launcher returns the hipError_t of the launch as an int.
  */
 #ifndef SKRED_LAUNCH_H
 #define SKRED_LAUNCH_H
 
+#ifndef __HIP_PLATFORM_AMD__
+#define __HIP_PLATFORM_AMD__ 1   /* C hosts (gcc): hipcc defines it itself */
+#endif
 #include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
 
 #include "skred_device_layout.h"
 
@@ -34,6 +40,12 @@ int sk_launch_reduce(const float *partial, float *tmp, float *out, int W, int nc
 int sk_reduce_tmp_floats(int ncols);
 int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels, float target, float k,
                      float *gain_state, hipStream_t stream);
+
+/* stem recorder (skred_recorder.c): min/max partials of rec[n_floats]; selected voices -> int16 pairs */
+int sk_rec_partial_floats(void);
+int sk_launch_rec_minmax(const float *rec, size_t n_floats, float *partial, int *n_blocks_out, hipStream_t stream);
+int sk_launch_rec_convert(const float *rec, long frames, int n_voices, const int *sel, int n_sel, float scale,
+                          int16_t *out, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "skred_synth_abi.h"
+#include "skred_wav.h"
 
 #define MAX_ARGS 8                      /* ARG_MAX, skode.c:33 */
 
@@ -30,11 +31,54 @@ static int is_atom_char(int c) { return isalpha(c) || (c && strchr("!@%^&*_=:\"'
 void skred_patch_init(skred_patch_t *p) { p->voice = 0; p->unsupported = 0; p->errors = 0; }
 
 /* one atom with its arguments: wire.c:606-759 for the voice subset */
+/* `:wN,slot,ch` -- load N.wav from the current directory into an EXT slot: the reference's wave_load
+ * (wire.c:406-441) on this library's wave arrays, with skred_wav_get in place of mw_get.  A table that
+ * is replaced may still be some voice's voice_table, so it is parked in a small ring and freed eight
+ * loads later, as the reference does (wire.c:370-390,417-426). */
+#define SKRED_EXT_SAMPLE_000 200                              /* skred.h:70 */
+#define SKRED_EXT_SAMPLE_999 (200 + 999)                      /* skred.h:71 */
+#define SKRED_RETIRED 8
+static float *retired[SKRED_RETIRED];
+static int retired_ptr = 0;
+
+int skred_wave_load(int which, int where, int ch) {
+  if (where < SKRED_EXT_SAMPLE_000 || where >= SKRED_EXT_SAMPLE_999) return SKRED_ERR_INVALID_EXT_SAMPLE;
+  char name[64];
+  snprintf(name, sizeof(name), "%d.wav", which);
+  skred_wav_info_t info;
+  int len = 0;
+  float *table = skred_wav_get(name, &len, &info, ch);
+  if (!table) return SKRED_ERR_INVALID_EXT_SAMPLE;
+  if (wave_table_data[where]) {
+    if (retired_ptr >= SKRED_RETIRED) retired_ptr = 0;
+    free(retired[retired_ptr]);
+    retired[retired_ptr++] = wave_table_data[where];
+  }
+  wave_is_miniwav[where] = 1;
+  wave_table_data[where] = table;
+  wave_size[where] = len;
+  wave_rate[where] = (float)info.sample_rate;
+  wave_one_shot[where] = 1;
+  wave_loop_enabled[where] = 0;
+  wave_loop_start[where] = 1;
+  wave_loop_end[where] = len;
+  wave_midi_note[where] = 69;
+  wave_offset_hz[where] = (float)len / (float)info.sample_rate * 440.0f;
+  return 0;
+}
+
 static void dispatch(skred_patch_t *p, const char *atom, const double *arg, int argc) {
   const int v = p->voice;
   const int x = argc ? (int)arg[0] : 0;
   int rc = 0;
-  if (atom[1] != '\0') { p->unsupported++; return; }          /* multi-character atoms: system / sequencer */
+  if ((atom[0] == ':' || atom[0] == '/') && atom[1] == 'w' && atom[2] == '\0') {   /* wire.c:801-814 */
+    const int which = argc >= 1 ? (int)arg[0] : 0;
+    const int where = argc >= 2 ? (int)arg[1] : SKRED_EXT_SAMPLE_000;
+    const int ch = argc > 2 ? (int)arg[2] : -1;
+    if (skred_wave_load(which, where, ch)) p->errors++;
+    return;
+  }
+  if (atom[1] != '\0') { p->unsupported++; return; }          /* other multi-character atoms: system / sequencer */
   switch (atom[0]) {
     case 'a': if (argc) rc = amp_set(v, (float)arg[0]); break;
     case 'A': if (argc == 1) rc = amp_mod_set(v, -1, 0); else if (argc > 1) rc = amp_mod_set(v, x, (float)arg[1]); break;

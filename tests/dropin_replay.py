@@ -49,7 +49,7 @@ def main():
     gg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gg)
     golden = gio.load(case)
-    res = {"case": case, "segments": []}
+    res = {"case": case, "segments": [], "extras": {}}
 
     class CompareSink:
         def __init__(self, name, desc):
@@ -79,6 +79,13 @@ def main():
             r["state_out"] = bank_out.rw_equal(gio.expected_out_bank(seg))
             r["count_out_equal"] = bool(ref.globals().synth_sample_count == seg.g_out.synth_sample_count)
             self.k += 1
+
+        def extra(self, name, value):
+            # case-specific data: what the replay produced (decoded tables, slot fields, the recorder's
+            # WAV file) must equal what the reference produced when the fixture was made
+            want = golden.extras[name]
+            got = np.ascontiguousarray(value)
+            res.setdefault("extras", {})[name] = bool(got.shape == want.shape and got.tobytes() == want.tobytes())
 
         def save(self):
             pass

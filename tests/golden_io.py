@@ -13,9 +13,10 @@ from skred_amd.bank import RW_FIELDS, GlobalsC, VoiceBank, globals_from_json
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["c0_0sk", "c1_sine_adsr64", "c2_mixed_filter64", "c2_notamy64", "c4_pcm_oneshot",
-         "edge_basic", "edge_mod"]
+         "edge_basic", "edge_mod", "wav_samples"]
 # cases whose voices are independent (no FM/AM/pan/CZ modulators)
-MOD_FREE_CASES = ["c1_sine_adsr64", "c2_mixed_filter64", "c2_notamy64", "c4_pcm_oneshot", "edge_basic"]
+MOD_FREE_CASES = ["c1_sine_adsr64", "c2_mixed_filter64", "c2_notamy64", "c4_pcm_oneshot", "edge_basic",
+                  "wav_samples"]
 
 
 @dataclass
@@ -39,6 +40,7 @@ class Golden:
     meta: dict
     tables: np.ndarray
     segments: List[Segment]
+    extras: dict                 # case-specific arrays (Case.extra in gen_golden.py), e.g. input / expected files
 
 
 def load(name: str) -> Golden:
@@ -56,7 +58,8 @@ def load(name: str) -> Golden:
             mix=z[p + "mix"], stems_sha256=str(z[p + "stems_sha256"]),
             stems=z[p + "stems"] if (p + "stems") in z else None,
             stems_voices=z[p + "stems_voices"] if (p + "stems_voices") in z else None))
-    return Golden(name, meta, np.ascontiguousarray(z["tables"], np.float32), segs)
+    extras = {k[2:]: z[k] for k in z.files if k.startswith("x_")}
+    return Golden(name, meta, np.ascontiguousarray(z["tables"], np.float32), segs, extras)
 
 
 def expected_out_bank(seg: Segment) -> VoiceBank:

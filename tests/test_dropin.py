@@ -82,6 +82,8 @@ def test_dropin_render_matches_reference(case):
         assert s["state_out"] == {}, s
         assert s["mix_rms_err"] <= 1e-5, s
         assert s["count_out_equal"], s
+    # e.g. wav_samples: the reference's recorder (skred.c:120-131, wire.c:94-185) fed by OUR stems
+    assert all(r["extras"].values()), r["extras"]
 
 
 @pytest.mark.gpu

@@ -268,6 +268,18 @@ __device__ __forceinline__ void voice_frame(VoiceRegs &r, const float *lds_tab,
 // two adjacent table samples, fetched with one 4-byte-aligned 8-byte access (global_load_dwordx2 /
 // ds_read2_b32).  The pool is padded by the host so that reading one float past any table is in bounds.
 struct __attribute__((packed, aligned(4))) tap_pair_t { float a, b; };
+// The same access for HBM/L2-resident pools, kept as ONE <2 x float> load of alignment 4 so that it is selected
+// as a single global_load_dwordx2 (multi-dword global loads only need dword alignment).  The struct form above is
+// split into two global_load_dword by the optimiser, and the texture-address unit processes a scattered wave
+// gather at about one lane-dword per cycle, so two loads cost twice one (C4: TA busy 83 %).
+typedef float tap_pair_v __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ tap_pair_t load_tap_pair_global(const char *__restrict__ p) {
+  const tap_pair_v v = *reinterpret_cast<const tap_pair_v *>(p);
+  tap_pair_t r;
+  r.a = v.x;
+  r.b = v.y;
+  return r;
+}
 
 // exact wrap for the cases the straight-line code does not cover (synth.c:241-256, looping voice)
 __device__ __forceinline__ float slow_wrap(float ph, float lo, float hi, float span) {

@@ -47,7 +47,8 @@ __device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__r
   // linear: oracle/cpu_ref.c:table_fetch.  Every voice of a fast bank wraps (no stopping one-shots).
   // Both taps come from ONE 8-byte gather (4-byte aligned pair) -- the neighbour is idx+1 except on
   // the last sample before the loop end, where a second (rare) gather fetches the loop start.
-  const tap_pair_t pr = *reinterpret_cast<const tap_pair_t *>(tab + (r.toff4 + (idx << 2)));
+  const tap_pair_t pr = TAB_LDS ? *reinterpret_cast<const tap_pair_t *>(tab + (r.toff4 + (idx << 2)))
+                                : load_tap_pair_global(tab + (r.toff4 + (idx << 2)));
   const float a = pr.a;
   float b = pr.b;
   int nxt = idx + 1;

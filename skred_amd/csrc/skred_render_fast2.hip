@@ -48,7 +48,8 @@ __device__ __forceinline__ float fast2_fetch(const char *lds_tab, const char *__
   if (!NOCLAMP) idx = max(min(idx, tsize_m1), 0);
   const char *tab = TAB_LDS ? lds_tab : glb_tab;
   if (INTERP == 0) return *reinterpret_cast<const float *>(tab + (toff4 + (idx << 2)));
-  const tap_pair_t pr = *reinterpret_cast<const tap_pair_t *>(tab + (toff4 + (idx << 2)));   // see fast_fetch
+  const tap_pair_t pr = TAB_LDS ? *reinterpret_cast<const tap_pair_t *>(tab + (toff4 + (idx << 2)))   // see fast_fetch
+                                : load_tap_pair_global(tab + (toff4 + (idx << 2)));
   const float a = pr.a;
   float b = pr.b;
   int nxt = idx + 1;

@@ -201,7 +201,7 @@ int skred_bank_set_tables_f32(skred_bank_t *b, const float *pool, size_t n_float
   HIP_TRY(hipSetDevice(b->device));
   if (b->d_tables) { hipFree(b->d_tables); b->d_tables = NULL; }
   b->table_floats = n_floats;
-  b->table_floats_padded = (n_floats + 1 + 3) & ~(size_t)3;   /* +1: the two-tap gather may read one float past the last table */
+  b->table_floats_padded = (n_floats + SK_TABLE_PAD + 3) & ~(size_t)3;   /* readable past the last table: see SK_TABLE_PAD */
   HIP_TRY(hipMalloc((void **)&b->d_tables, b->table_floats_padded * sizeof(float)));
   HIP_TRY(hipMemset(b->d_tables, 0, b->table_floats_padded * sizeof(float)));
   HIP_TRY(hipMemcpy(b->d_tables, pool, n_floats * sizeof(float), hipMemcpyHostToDevice));

@@ -75,6 +75,10 @@ enum {
 #define SK_CHUNK 64                /* frames between two workgroup-level mix flushes */
 #define SK_LDS_TABLE_MAX_FLOATS 12288  /* 48 KiB: pools up to this size are staged in LDS */
 #define SK_MAX_WORKGROUPS 2048
+#define SK_WIN 20                  /* floats of one voice's table window (skred_render_fast2.hip: 8 frames at up to
+                                      2.1875 table samples per frame, plus the second tap) */
+#define SK_TABLE_PAD 24            /* zero floats the host appends to the pool: a window (or the two-tap gather)
+                                      may start at the last sample of the last table */
 
 typedef struct {
   uint32_t w[4];

@@ -221,6 +221,85 @@ __device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, 
   fast2_post<FILTER, EM, TAME>(r, e, s, xn, xo, yn, yo, rel0, rel1, silent0, silent1, out_l, out_r);
 }
 
+// ---- table windows for pools that do not fit in LDS (PCM banks) ----
+//
+// A scattered wave gather from L2 costs one cache-line request per lane (~2.5 cycles per lane and CU measured,
+// tools/ta_rate.hip) whatever its width, and a voice that advances ~1 sample per frame asks for the same line
+// many frames in a row -- but 16 waves per CU evict it from the 32 KB L1 in between.  So every 8 frames each lane
+// copies the SK_WIN table samples its two voices are about to cross (5 dword-aligned global_load_dwordx4 each,
+// 1-2 lines) into a wave-private LDS window win[voice][j][lane] (lane-minor: conflict-free whatever j the lanes
+// pick) and the 8 frames read their taps with one ds_read2st64_b32.  Line requests drop ~5x.
+// A lane whose voice could reach its loop end inside the block (wrap, or the second tap folding back to the loop
+// start) or advances more than 2.1875 samples per frame is `direct` for that block: it takes the ordinary
+// gather, in a branch the wave only enters when some lane needs it.  Same arithmetic either way.
+typedef float win4_t __attribute__((ext_vector_type(4), aligned(4)));
+
+struct WinRegs {
+  int base[2];       // table index of win[c][0]
+  bool direct[2];    // this lane's voice c bypasses the window in the current block
+  bool any_direct;   // some lane of the wave does
+};
+
+__device__ __forceinline__ void fast2_win_fill(const Fast2Regs &r, const bool dead[2], WinRegs &w, float *win,
+                                               int lane, const char *__restrict__ glb_tab) {
+  bool any = false;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float d8 = 8.0f * r.inc[c];
+    // after 8 advances the position is at most phase + d8 (+ rounding << 1): both taps stay inside
+    // [base, base + SK_WIN) and below the loop end, so neither the wrap nor the folded tap can occur
+    const bool fits = d8 <= (float)(SK_WIN - 3) + 0.5f && r.phase[c] + d8 + 2.0f < r.hi[c];
+    w.direct[c] = !dead[c] && !fits;
+    w.base[c] = (int)r.phase[c];
+    any = any || w.direct[c];
+    if (!w.direct[c]) {
+      const char *src = glb_tab + (r.toff4[c] + (w.base[c] << 2));
+      float *dst = win + (c * SK_WIN) * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < SK_WIN / 4; ++k) {
+        const win4_t t = *reinterpret_cast<const win4_t *>(src + 16 * k);
+        dst[(4 * k + 0) * 64] = t.x; dst[(4 * k + 1) * 64] = t.y;
+        dst[(4 * k + 2) * 64] = t.z; dst[(4 * k + 3) * 64] = t.w;
+      }
+    }
+  }
+  w.any_direct = __any(any);
+}
+
+// oscillator half of a frame with the window (tame waves only): same phase arithmetic as fast2_osc<.., true, ..>
+template <int INTERP>
+__device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, const float *win, int lane,
+                                             const char *__restrict__ glb_tab) {
+  const v2f ph0 = r.phase + r.inc;
+  const v2f x = ph0 - r.lo;
+  const v2f phw = r.lo + (x - r.span);
+  v2f ph, s;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float p = (ph0[c] >= r.hi[c]) ? phw[c] : ph0[c];
+    ph[c] = p;
+    const int idx = (int)p;
+    const int rel = w.direct[c] ? 0 : idx - w.base[c];
+    const float *src = win + (c * SK_WIN + rel) * 64 + lane;
+    const float ta = src[0];
+    if (INTERP == 0) {
+      s[c] = ta;
+    } else {
+      const float tb = src[64];
+      const float frac = p - (float)idx;
+      s[c] = ta + frac * (tb - ta);
+    }
+  }
+  r.phase = ph;
+  if (w.any_direct) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (w.direct[c])
+        s[c] = fast2_fetch<false, INTERP, true>(nullptr, glb_tab, r.toff4[c], r.tsize_m1[c], r.lo[c], r.hi[c], ph[c]);
+  }
+  return s;
+}
+
 #define SK_F2_ARGS released[0], released[1], silent[0], silent[1], lds_tab, glb_tab
 // one frame (J) / two frames (J, J+1; delay-line roles swap in between, one 4-chain DPP reduction)
 #define SK_FAST2_ONE(J, EM_, TAME_)                                                                      \
@@ -276,12 +355,27 @@ __device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, 
     }                                                                                                    \
     SK_WAVE_SYNC()                                                                                       \
   }
+// Eight frames (J..J+7) of a tame wave of a global-table bank through the table windows; DPP pair reductions.
+#define SK_FAST2_WIN_BLOCK(J, EM_)                                                                       \
+  {                                                                                                      \
+    WinRegs wr_;                                                                                         \
+    fast2_win_fill(r, dead, wr_, win, lane, glb_tab);                                                    \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      float l0, r0, l1, r1;                                                                              \
+      const v2f s0_ = fast2_osc_win<INTERP>(r, wr_, win, lane, glb_tab);                                  \
+      fast2_post<FILTER, EM_, true>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
+      const v2f s1_ = fast2_osc_win<INTERP>(r, wr_, win, lane, glb_tab);                                  \
+      fast2_post<FILTER, EM_, true>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
+      SK_REDUCE4_AND_STORE((J) + q_)                                                                     \
+    }                                                                                                    \
+  }
 // a whole chunk of cn frames in mode EM_: LDS blocks of 8 when tame, DPP pairs otherwise, single-frame tail
 #if SK_LDS_REDUCE
 #define SK_FAST2_CHUNK(EM_)                                                     \
   {                                                                             \
     int j = 0;                                                                  \
     if (tame) { if (TAB_LDS) for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK(j, EM_) \
+                else for (; j + 8 <= cn; j += 8) SK_FAST2_WIN_BLOCK(j, EM_)     \
                 for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, true)          \
                 if (j < cn) SK_FAST2_ONE(j, EM_, true) }                        \
     else      { for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, false)         \
@@ -407,7 +501,9 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                     \
   float2 *xp = wsum + 4 * SK_CHUNK + wave * (8 * 65 + 64);   /* wave-private: tile [8][65] then xq [64] */ \
   float2 *xq = xp + 8 * 65;                                                                          \
-  (void)xp; (void)xq;                                                                                \
+  /* global-table banks: the same LDS holds the wave's table windows instead (2 voices x SK_WIN x 64 lanes) */ \
+  float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (2 * SK_WIN * 64);            \
+  (void)xp; (void)xq; (void)win;                                                                     \
   if (TAB_LDS) {                                                                                     \
     const int n4 = a.lds_table_floats >> 2;                                                          \
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);                                 \
@@ -519,6 +615,8 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
 #if SK_LDS_REDUCE
           if (TAB_LDS && b_const) SK_FAST2_LDS_BLOCK(jb, 0)
           else if (TAB_LDS && b_ramp) SK_FAST2_LDS_BLOCK(jb, 1)
+          else if (!TAB_LDS && b_const) SK_FAST2_WIN_BLOCK(jb, 0)
+          else if (!TAB_LDS && b_ramp) SK_FAST2_WIN_BLOCK(jb, 1)
           else
 #endif
           {
@@ -557,7 +655,8 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
 extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
                                       hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
-  lds_bytes += (size_t)4 * (8 * 65 + 64) * sizeof(float2);   // per-wave transposition tile + row sums
+  // per wave: the transposition tile + row sums (LDS-table banks) or the table windows (global-table banks)
+  lds_bytes += tab_lds ? (size_t)4 * (8 * 65 + 64) * sizeof(float2) : (size_t)4 * (2 * SK_WIN * 64) * sizeof(float);
   dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
   const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);

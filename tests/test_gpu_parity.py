@@ -220,7 +220,7 @@ def test_empty_and_bad_arguments(dev):
 
 # ---------------------------------------------------------------- the specialised ("fast") kernel
 
-def _run_scenario(dev, bank, tables, g, interp, segments, force_generic):
+def _run_scenario(dev, bank, tables, g, interp, segments, force_generic, fast2=False):
     """Render `segments` = [(frames, event)] where event(bank_host, now) mutates the host bank
     between launches (host arrays are the source of truth: download -> edit -> upload)."""
     db = dev.DeviceBank(bank.n)
@@ -229,6 +229,8 @@ def _run_scenario(dev, bank, tables, g, interp, segments, force_generic):
     db.upload(host)
     db.set_globals(g)
     db.force_generic(force_generic)
+    if fast2:
+        db.fast2_min_voices(0)
     mixes, kernels = [], []
     for frames, event in segments:
         if event is not None:
@@ -316,7 +318,7 @@ def test_exotic_voice_forces_generic_kernel(dev):
     assert k == [0]
 
 
-@pytest.mark.parametrize("recipe,interp", [("c1", 0), ("c2", 0), ("c2", 1), ("c4", 1)])
+@pytest.mark.parametrize("recipe,interp", [("c1", 0), ("c2", 0), ("c2", 1), ("c4", 0), ("c4", 1)])
 def test_two_per_lane_kernel_matches_oracle(dev, recipe, interp):
     """sk_render_fast2_kernel (two voices per lane, packed fp32): per-voice state bit-exact against the
     oracle through attack/decay, note-off, release end and the smoother tail; mix within tolerance
@@ -346,6 +348,42 @@ def test_two_per_lane_kernel_matches_oracle(dev, recipe, interp):
     assert kernels == [3] * len(segs), kernels
     assert not host.rw_equal(ref_state), host.rw_equal(ref_state)
     assert rel_rms(np.concatenate(mixes), ref_mix) <= 1e-5
+
+
+@pytest.mark.parametrize("interp", [0, 1])
+def test_table_window_edges(dev, interp):
+    """PCM bank (pool in L2/HBM) on the two-per-lane kernel, which serves tame waves from per-voice LDS table
+    windows refilled every 8 frames: voices that wrap in (almost) every block (loops of 9..40 samples), voices
+    faster than a window can cover (> 2.1875 samples per frame), voices parked just below their loop end
+    (second tap folds back to the loop start), a voice on the last table of the pool (window reads into the
+    pool's padding) -- all must equal the oracle bit for bit per voice."""
+    n = 4096
+    bank, tables, g = banks.bank_c4(n)
+    lo = bank["voice_loop_start_f"]
+    hi = bank["voice_loop_end_f"]
+    size = bank["voice_table_size"].astype(np.float32)
+    tiny = np.arange(n) % 5 == 0                                  # short loops: every block has wrapping lanes
+    span = (9 + (np.arange(n) % 32)).astype(np.float32)
+    hi[tiny] = np.minimum(lo[tiny] + span[tiny], size[tiny])
+    bank["voice_loop_valid"][tiny] = 1
+    bank["voice_phase"][tiny] = lo[tiny]
+    fast = np.arange(n) % 7 == 3                                  # faster than the window, still <= span / 2
+    bank["voice_phase_inc"][fast & ~tiny] = np.float32(2.19) + np.float32(0.013) * (np.arange(n)[fast & ~tiny] % 200)
+    park = np.arange(n) % 11 == 5                                 # sits in [hi - 1, hi): folded second tap
+    sel = park & ~tiny
+    bank["voice_phase"][sel] = hi[sel] - np.float32(0.75)
+    bank["voice_phase_inc"][sel] = np.float32(0.015625)
+    last = np.argmax(bank["voice_table_offset"])                  # last table of the pool, phase near its end
+    bank["voice_loop_enabled"][last] = 0
+    bank["voice_one_shot"][last] = 0
+    bank["voice_phase"][last] = np.float32(bank["voice_table_size"][last] - 3)
+    bank["voice_phase_inc"][last] = np.float32(0.01)
+    segs = [(512, None), (77, None), (1024, None)]
+    fast_mix, fast_state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False, fast2=True)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert k == [3] * len(segs), k
+    assert not fast_state.rw_equal(ref_state), fast_state.rw_equal(ref_state)
+    assert rel_rms(fast_mix, ref_mix) <= 1e-5
 
 
 def test_two_per_lane_kernel_full_size_c3(dev):

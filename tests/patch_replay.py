@@ -52,6 +52,7 @@ def main():
             _fields_ = [("voice", C.c_int), ("unsupported", C.c_int), ("errors", C.c_int)]
         p = Patch()
         L.skred_patch_init(C.byref(p))
+        os.chdir(REF)                      # `:wN` reads N.wav from the current directory (wire.c:409), as ref_load_patch does
         res["rc"] = L.skred_patch_load(path.encode(), C.byref(p))
         res["unsupported"], res["errors"] = p.unsupported, p.errors
     res["digest"] = digest(L)

@@ -204,6 +204,54 @@ int  skred_bank_master(skred_bank_t *bank, const float *d_sum, int num_frames,
 int  skred_bank_render_host(skred_bank_t *bank, float *buffer, int num_frames,
                             int num_channels, int interp, float *stems_or_null);
 
+/* ---- block-granular updates of device-resident voices (SURVEY 8f "next" #4) -------------------------
+ *
+ * The reference's control path (wire.c:606-716 commands, seq.c pattern steps, deferred items) stores into the
+ * per-voice arrays and the next audio block sees the change.  With the voices in HBM the host view
+ * (skred_voice_bank_t, same array names) stays what control code writes to; afterwards it names the voices it
+ * touched and which KIND of field, and only those travel.  Everything not named keeps the value the GPU last
+ * computed -- a full skred_bank_upload() would overwrite the running phase, filter memory and smoother with
+ * the host's stale copies.
+ */
+enum {
+  SKRED_DIRTY_PARAMS        = 1u << 0, /* every parameter: phase_inc, amp, table / loop window, direction, flags, quantize,
+                                          hold_max, envelope times + velocity, filter coefficients, smoother k,
+                                          modulation routing and depths, cz mode -- but not the envelope clock */
+  SKRED_DIRTY_PHASE         = 1u << 1, /* voice_phase, voice_finished                    (osc_trigger, synth.c:316-339) */
+  SKRED_DIRTY_ENV_STATE     = 1u << 2, /* voice_amp_envelope.is_active */
+  SKRED_DIRTY_PAN           = 1u << 3, /* voice_pan_left, voice_pan_right                (pan_set, synth.c:838-847) */
+  SKRED_DIRTY_FILTER_STATE  = 1u << 4, /* voice_filter.x1 x2 y1 y2                       (mmf_init, synth.c:1015-1030) */
+  SKRED_DIRTY_SMOOTHER      = 1u << 5, /* voice_smoother_gain */
+  SKRED_DIRTY_HOLD          = 1u << 6, /* voice_sample_hold, voice_sample_hold_count */
+  SKRED_DIRTY_SAMPLE        = 1u << 7, /* voice_sample */
+  /* the two control actions whose stores depend on WHEN they run: the library stamps the bank's
+   * synth_sample_count at application time, as the reference's functions read the global */
+  SKRED_STAMP_TRIGGER       = 1u << 8, /* amp_envelope_trigger (synth.c:383-388): sample_start = now, sample_release = 0,
+                                          is_active = 1; send the velocity with SKRED_DIRTY_PARAMS */
+  SKRED_STAMP_RELEASE       = 1u << 9, /* amp_envelope_release (synth.c:391-395): if is_active (device state), sample_release = now */
+  SKRED_DIRTY_ENV_CLOCK     = 1u << 10, /* voice_amp_envelope.sample_start / .sample_release as the host has them (kept out
+                                           of PARAMS so that a later parameter change cannot undo a stamped note-on / -off) */
+  SKRED_DIRTY_VALID_MASK    = 0x7FF
+};
+#define SKRED_QUEUE_SIZE 1024          /* skred.h:86 QUEUE_SIZE */
+
+/* Rewrite the `dirty` parts of the listed voices (indices into both the host view and the bank) from the host
+ * view, on `stream` (a hipStream_t; pass the render stream: the update is ordered before the next render on it).
+ * A voice may be listed more than once; the copies are applied in order. */
+int  skred_bank_update(skred_bank_t *bank, const skred_voice_bank_t *host, const int32_t *voices, int n_voices,
+                       uint32_t dirty, void *stream);
+
+/* The deferred queue: seq.c:243-257 queue_item(when, what, voice) + the first loop of seq() (seq.c:170-177).
+ * The reference stores command TEXT and runs it when due; here the values are captured from the host view when
+ * the item is queued (only the STAMP actions read the clock when they run).  skred_bank_run_queue() is what
+ * seq() does after synth(): every item with when <= synth_sample_count + frame_count is applied, in arrival
+ * order, i.e. an item takes effect at the start of the block that contains its time.  Returns the number of
+ * items applied (>= 0) or a SKRED_E_* code. */
+int  skred_bank_defer(skred_bank_t *bank, uint64_t when, const skred_voice_bank_t *host, const int32_t *voices,
+                      int n_voices, uint32_t dirty);
+int  skred_bank_run_queue(skred_bank_t *bank, int frame_count, void *stream);
+int  skred_bank_queue_pending(const skred_bank_t *bank);
+
 /* Options.  Two kernels implement the render loop: a generic one (every synth() feature the path
  * supports) and a specialised one chosen automatically for "clean" banks; their per-voice results are
  * bit-identical.  FORCE_GENERIC pins the generic kernel (used by the parity tests to cross-check). */

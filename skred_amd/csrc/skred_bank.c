@@ -8,80 +8,19 @@
  * skred_mix_kernels.hip (through skred_launch.h).  There is no CPU rendering here: every failure
  * to reach the GPU is reported, never papered over.
  */
-#define __HIP_PLATFORM_AMD__ 1
-#include <hip/hip_runtime_api.h>
 
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
-#include "skred_amd.h"
-#include "skred_device_layout.h"
-#include "skred_launch.h"
-
-#define SK_TIMING_RING 256
-#define SK_FAST2_MIN_VOICES 131072   /* banks at least this large use two voices per lane (measured crossover) */
-
-struct skred_bank {
-  int device;
-  int n_voices, n_padded, n_groups;
-  sk_plane_t *d_ro[SKP_COUNT];
-  sk_plane_t *d_rw[SKS_COUNT];
-  float *d_tables;
-  size_t table_floats;        /* real pool size       */
-  size_t table_floats_padded; /* rounded up to 4      */
-  float *d_partial;           /* [n_wg][F][2]         */
-  size_t partial_cap;         /* floats               */
-  float *d_gain_state;        /* master smoother gain */
-  float *d_redtmp;            /* second-stage scratch of the partial-mix reduction */
-  size_t redtmp_cap;
-  float *d_sum, *d_out, *d_stems; /* scratch of skred_bank_render_host */
-  size_t sum_cap, out_cap, stems_cap;
-  uint8_t *h_class;           /* per-voice SKC_* bits, shadow used to pick the kernel */
-  int8_t *h_mod;              /* [4][n_padded] modulator lane inside the 64-voice group (fm, am, pm, cz) or -1 */
-  int *h_level;               /* [n_padded] dependency level of each voice (modulated banks) */
-  int *d_level;
-  int32_t *d_group_flag;      /* per 512-voice group: deferred to sk_render_env2_kernel */
-  int max_level;
-  int mod_escapes;            /* some modulator lies outside its carrier's 64-voice group */
-  int class_dirty;
-  uint32_t fast_mode;         /* SKM_* from classify() */
-  int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
-  int fast2_min_voices;       /* SKRED_OPT_FAST2_MIN_VOICES */
-  int last_kernel;            /* SKRED_KERNEL_* used by the most recent render */
-  skred_globals_t g;
-  uint32_t features;
-  hipEvent_t ev0[SK_TIMING_RING], ev1[SK_TIMING_RING]; /* around the render kernel of each call */
-  int n_timed;                /* render calls since the last timing reset */
-};
-
-/* per-voice classification (host shadow) */
-#define SKC_REAL   1u   /* a voice was uploaded into this slot and it can sound (has a table) */
-#define SKC_FILTER 2u
-#define SKC_ENV    4u
-#define SKC_EXOTIC 8u   /* needs the generic kernel: see classify() */
+#include "skred_bank_priv.h"
 
 static __thread char g_err[512];
 
-static int fail(int code, const char *fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return code;
-}
-
-#define HIP_TRY(call)                                                              \
-  do {                                                                             \
-    hipError_t e_ = (call);                                                        \
-    if (e_ != hipSuccess)                                                          \
-      return fail(SKRED_E_NO_DEVICE, "%s -> %s", #call, hipGetErrorString(e_));   \
-  } while (0)
-
 const char *skred_amd_last_error(void) { return g_err; }
 
-/* shared with skred_fxbank.c */
+/* every translation unit of the library reports through this (skred_bank_priv.h: fail) */
 int skred_amd_set_error(int code, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -153,6 +92,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   HIP_TRY(hipMalloc((void **)&b->d_group_flag, (size_t)(b->n_groups / 2 + 1) * sizeof(int32_t)));
   HIP_TRY(hipMemset(b->d_group_flag, 0, (size_t)(b->n_groups / 2 + 1) * sizeof(int32_t)));
   b->class_dirty = 1;
+  b->mod_dirty = 1;
   HIP_TRY(hipMalloc((void **)&b->d_gain_state, 4 * sizeof(float)));
   HIP_TRY(hipMemset(b->d_gain_state, 0, 4 * sizeof(float)));
   for (int i = 0; i < SK_TIMING_RING; i++) {
@@ -182,6 +122,10 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_stems) hipFree(b->d_stems);
   if (b->d_redtmp) hipFree(b->d_redtmp);
   free(b->h_class); free(b->h_mod); free(b->h_level);
+  sk_queue_free(b);
+  if (b->d_updates) hipFree(b->d_updates);
+  if (b->h_updates) hipHostFree(b->h_updates);
+  if (b->ev_updates) hipEventDestroy(b->ev_updates);
   if (b->d_level) hipFree(b->d_level);
   if (b->d_group_flag) hipFree(b->d_group_flag);
   for (int i = 0; i < SK_TIMING_RING; i++) {
@@ -210,7 +154,6 @@ int skred_bank_set_tables_f32(skred_bank_t *b, const float *pool, size_t n_float
 
 /* ------------------------------------------------------------------ pack / unpack */
 
-static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_first, int dst_first, int count) {
@@ -221,107 +164,14 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
   HIP_TRY(hipSetDevice(b->device));
   const int NP = SKP_COUNT + SKS_COUNT;
   sk_plane_t *st = (sk_plane_t *)calloc((size_t)NP * (size_t)count, sizeof(sk_plane_t));
-  if (!st) return fail(SKRED_E_NO_MEM, "upload staging");
-  uint32_t features = (dst_first == 0 && count == b->n_voices) ? 0u : b->features;
-  if (dst_first == 0 && count == b->n_voices) b->mod_escapes = 0;
+  sk_voice_meta_t *meta = (sk_voice_meta_t *)malloc((size_t)count * sizeof(sk_voice_meta_t));
+  if (!st || !meta) { free(st); free(meta); return fail(SKRED_E_NO_MEM, "upload staging"); }
   for (int i = 0; i < count; i++) {
-    const int v = src_first + i;
-    sk_plane_t *ro = st, *rw = st + (size_t)SKP_COUNT * count;
-#define RO(p) ro[(size_t)(p) * count + i]
-#define RW(p) rw[(size_t)(p) * count + i]
-    const int size = h->voice_table_size[v];
-    const int64_t off = h->voice_table_offset[v];
-    const int noise = h->voice_wave_table_index[v] == SKRED_WAVE_TABLE_NOISE_ALT;
-    uint32_t flags = 0;
-    int usable = 1;
-    if (!noise) {
-      if (size <= 0) usable = 0;   /* the reference would dereference a NULL/empty table here */
-      else if (off < 0 || (uint64_t)off + (uint64_t)size > b->table_floats) {
-        free(st);
-        return fail(SKRED_E_RANGE, "voice %d: table [%lld,+%d) outside pool of %zu floats", v, (long long)off, size, b->table_floats);
-      }
-    }
-    if (!usable) flags |= SKF_INERT;
-    const int windowed = h->voice_loop_enabled[v] && h->voice_loop_valid[v];   /* synth.c:235-238 */
-    const float lo = windowed ? h->voice_loop_start_f[v] : 0.0f;
-    const float hi = windowed ? h->voice_loop_end_f[v] : (float)size;
-    if (h->voice_one_shot[v]) flags |= SKF_ONE_SHOT;
-    if (h->voice_loop_enabled[v]) flags |= SKF_LOOPING;
-    if (h->voice_direction[v]) flags |= SKF_REVERSE;
-    if (h->voice_use_amp_envelope[v]) { flags |= SKF_USE_ENV; features |= SKB_ANY_ENV; }
-    if (h->voice_filter_mode[v]) { flags |= SKF_FILTER; features |= SKB_ANY_FILTER; }
-    if (h->voice_smoother_enable[v]) flags |= SKF_SMOOTH;
-    if (h->voice_disconnect[v]) flags |= SKF_MUTED;
-    if (noise) { flags |= SKF_NOISE; features |= SKB_ANY_NOISE; }
-    const int has_mod = h->voice_freq_mod_osc[v] >= 0 || h->voice_amp_mod_osc[v] >= 0 ||
-                        h->voice_pan_mod_osc[v] >= 0 || h->voice_cz_mode[v] != 0;
-    if (has_mod) { flags |= SKF_HAS_MOD; features |= SKB_ANY_MOD; }
-    int quant = h->voice_quantize[v], hold = h->voice_sample_hold_max[v];
-    if (quant < 0 || quant > 30) quant = quant < 0 ? 0 : 30;
-    if (hold < 0) hold = 0;
-    if (hold > 0xFFFFFF) hold = 0xFFFFFF;
-    if (quant || hold) features |= SKB_ANY_HOLDQ;
-    {
-      uint8_t c = 0;
-      if (usable || noise) c |= SKC_REAL;
-      if (h->voice_filter_mode[v]) c |= SKC_FILTER;
-      if (h->voice_use_amp_envelope[v]) c |= SKC_ENV;
-      const int stops = h->voice_one_shot[v] && !h->voice_loop_enabled[v];
-      const float ph = h->voice_phase[v], pi = h->voice_phase_inc[v];
-      const int finite = (ph - ph == 0.0f) && (pi - pi == 0.0f) && (lo - lo == 0.0f) && (hi - hi == 0.0f) && hi > lo;
-      if (stops || noise || has_mod || quant || hold || h->voice_direction[v] || !h->voice_smoother_enable[v] || !finite)
-        c |= SKC_EXOTIC;
-      b->h_class[dst_first + i] = c;
-    }
-    const skred_envelope_t *e = &h->voice_amp_envelope[v];
-    const skred_mmf_t *f = &h->voice_filter[v];
-
-    RO(SKP_OSC).w[0] = f2u(h->voice_phase_inc[v]); RO(SKP_OSC).w[1] = f2u(usable ? lo : 0.0f);
-    RO(SKP_OSC).w[2] = f2u(usable ? hi : 1.0f);    RO(SKP_OSC).w[3] = f2u(h->voice_amp[v]);
-    RO(SKP_TAB).w[0] = (uint32_t)(int32_t)(usable && !noise ? off : 0);
-    RO(SKP_TAB).w[1] = (uint32_t)(usable && !noise ? size : 1); RO(SKP_TAB).w[2] = flags;
-    RO(SKP_TAB).w[3] = (uint32_t)quant | ((uint32_t)hold << 8);
-    RO(SKP_ENV_T).w[0] = f2u(e->attack_time);   RO(SKP_ENV_T).w[1] = f2u(e->decay_time);
-    RO(SKP_ENV_T).w[2] = f2u(e->sustain_level); RO(SKP_ENV_T).w[3] = f2u(e->release_time);
-    RO(SKP_ENV_S).w[0] = (uint32_t)(e->sample_start & 0xFFFFFFFFu);
-    RO(SKP_ENV_S).w[1] = (uint32_t)(e->sample_start >> 32);
-    RO(SKP_ENV_S).w[2] = (uint32_t)(e->sample_release & 0xFFFFFFFFu);
-    RO(SKP_ENV_S).w[3] = (uint32_t)(e->sample_release >> 32);
-    RO(SKP_GAIN).w[0] = f2u(e->velocity); RO(SKP_GAIN).w[1] = f2u(h->voice_smoother_smoothing[v]);
-    RO(SKP_GAIN).w[2] = f2u(f->b0);       RO(SKP_GAIN).w[3] = f2u(f->b1);
-    RO(SKP_FILT).w[0] = f2u(f->b2); RO(SKP_FILT).w[1] = f2u(f->a1);
-    RO(SKP_FILT).w[2] = f2u(f->a2); RO(SKP_FILT).w[3] = f2u(h->voice_cz_distortion[v]);
-    {
-      /* modulator indices: host index -> lane inside the carrier's 64-voice device group, -1 = unused
-       * (FM ignores a self reference, synth.c:549; the CZ source only matters with CZ on, synth.c:262) */
-      const int dst = dst_first + i;
-      int src[4] = { h->voice_freq_mod_osc[v], h->voice_amp_mod_osc[v], h->voice_pan_mod_osc[v],
-                     h->voice_cz_mode[v] ? h->voice_cz_mod_osc[v] : -1 };
-      if (src[0] == v) src[0] = -1;
-      for (int k = 0; k < 4; k++) {
-        int lane_k = -1;
-        if (src[k] >= 0) {
-          const int md = src[k] - src_first + dst_first;
-          if (md < 0 || md >= b->n_voices || (md >> 6) != (dst >> 6)) b->mod_escapes = 1;
-          else lane_k = md & 63;
-        }
-        b->h_mod[(size_t)k * b->n_padded + dst] = (int8_t)lane_k;
-        RO(SKP_MODI).w[k] = (uint32_t)(int32_t)lane_k;
-      }
-    }
-    RO(SKP_MODF).w[0] = f2u(h->voice_freq_mod_depth[v]); RO(SKP_MODF).w[1] = f2u(h->voice_freq_scale[v]);
-    RO(SKP_MODF).w[2] = f2u(h->voice_amp_mod_depth[v]);  RO(SKP_MODF).w[3] = f2u(h->voice_pan_mod_depth[v]);
-    RO(SKP_MODX).w[0] = f2u(h->voice_cz_mod_depth[v]); RO(SKP_MODX).w[1] = (uint32_t)h->voice_cz_mode[v];
-
-    RW(SKS_OSC).w[0] = f2u(h->voice_phase[v]); RW(SKS_OSC).w[1] = f2u(h->voice_smoother_gain[v]);
-    RW(SKS_OSC).w[2] = f2u(f->x1);             RW(SKS_OSC).w[3] = f2u(f->x2);
-    RW(SKS_FILT).w[0] = f2u(f->y1); RW(SKS_FILT).w[1] = f2u(f->y2);
-    RW(SKS_FILT).w[2] = f2u(h->voice_sample[v]);
-    RW(SKS_FILT).w[3] = (h->voice_finished[v] ? SKR_FINISHED : 0u) | (e->is_active ? SKR_ENV_ACTIVE : 0u);
-    RW(SKS_MISC).w[0] = f2u(h->voice_sample_hold[v]); RW(SKS_MISC).w[1] = (uint32_t)h->voice_sample_hold_count[v];
-    RW(SKS_MISC).w[2] = f2u(h->voice_pan_left[v]);    RW(SKS_MISC).w[3] = f2u(h->voice_pan_right[v]);
-#undef RO
-#undef RW
+    sk_plane_t ro[SKP_COUNT], rw[SKS_COUNT];
+    const int rc = sk_pack_voice(b, h, src_first + i, dst_first + i, 1, ro, rw, &meta[i]);
+    if (rc) { free(st); free(meta); return rc; }
+    for (int p = 0; p < SKP_COUNT; p++) st[(size_t)p * count + i] = ro[p];
+    for (int p = 0; p < SKS_COUNT; p++) st[(size_t)(SKP_COUNT + p) * count + i] = rw[p];
   }
   const size_t bytes = (size_t)count * sizeof(sk_plane_t);
   hipError_t e = hipSuccess;
@@ -330,9 +180,10 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
   for (int p = 0; p < SKS_COUNT && e == hipSuccess; p++)
     e = hipMemcpy(b->d_rw[p] + dst_first, st + (size_t)(SKP_COUNT + p) * count, bytes, hipMemcpyHostToDevice);
   free(st);
-  HIP_TRY(e);
-  b->features = features;
-  b->class_dirty = 1;
+  if (e != hipSuccess) { free(meta); HIP_TRY(e); }
+  if (dst_first == 0 && count == b->n_voices) { b->features = 0; b->mod_escapes = 0; }   /* whole bank replaced */
+  for (int i = 0; i < count; i++) sk_apply_meta(b, dst_first + i, &meta[i]);
+  free(meta);
   return SKRED_OK;
 }
 
@@ -342,15 +193,7 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
  * by all of them or by none.  Anything else runs the generic kernel; both give identical samples. */
 static void classify(skred_bank_t *b) {
   if (!b->class_dirty) return;
-  int real = 0, filt = 0, env = 0, exotic = 0;
-  for (int v = 0; v < b->n_voices; v++) {
-    const uint8_t c = b->h_class[v];
-    if (!(c & SKC_REAL)) continue;
-    real++;
-    if (c & SKC_FILTER) filt++;
-    if (c & SKC_ENV) env++;
-    if (c & SKC_EXOTIC) exotic++;
-  }
+  const int real = b->cnt_real, filt = b->cnt_filter, env = b->cnt_env, exotic = b->cnt_exotic;
   uint32_t m = 0;
   if (real > 0 && !exotic && (filt == 0 || filt == real) && (env == 0 || env == real)) {
     m = SKM_FAST;
@@ -360,6 +203,8 @@ static void classify(skred_bank_t *b) {
   b->fast_mode = m;
   b->class_dirty = 0;
   /* dependency levels for modulated banks (skred_render_generic.hip: sk_render_mod_kernel) */
+  if (!b->mod_dirty) return;
+  b->mod_dirty = 0;
   b->max_level = 0;
   if (b->features & SKB_ANY_MOD) {
     for (int g0 = 0; g0 < b->n_padded; g0 += 64) {

@@ -1,0 +1,94 @@
+/*
+ * skred_bank_priv.h -- internals shared by the translation units behind include/skred_amd.h
+ * (skred_bank.c: lifecycle, upload / download, render; skred_bank_update.c: block-granular updates
+ * and the deferred queue).  Not installed.
+ */
+#ifndef SKRED_BANK_PRIV_H
+#define SKRED_BANK_PRIV_H
+
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "skred_amd.h"
+#include "skred_device_layout.h"
+#include "skred_launch.h"
+
+#define SK_TIMING_RING 256
+#define SK_FAST2_MIN_VOICES 131072   /* banks at least this large use two voices per lane (measured crossover) */
+
+struct skred_bank {
+  int device;
+  int n_voices, n_padded, n_groups;
+  sk_plane_t *d_ro[SKP_COUNT];
+  sk_plane_t *d_rw[SKS_COUNT];
+  float *d_tables;
+  size_t table_floats;        /* real pool size       */
+  size_t table_floats_padded; /* rounded up to 4      */
+  float *d_partial;           /* [n_wg][F][2]         */
+  size_t partial_cap;         /* floats               */
+  float *d_gain_state;        /* master smoother gain */
+  float *d_redtmp;            /* second-stage scratch of the partial-mix reduction */
+  size_t redtmp_cap;
+  float *d_sum, *d_out, *d_stems; /* scratch of skred_bank_render_host */
+  size_t sum_cap, out_cap, stems_cap;
+  uint8_t *h_class;           /* per-voice SKC_* bits, shadow used to pick the kernel */
+  int8_t *h_mod;              /* [4][n_padded] modulator lane inside the 64-voice group (fm, am, pm, cz) or -1 */
+  int *h_level;               /* [n_padded] dependency level of each voice (modulated banks) */
+  int *d_level;
+  int32_t *d_group_flag;      /* per 512-voice group: deferred to sk_render_env2_kernel */
+  int max_level;
+  int mod_escapes;            /* some modulator lies outside its carrier's 64-voice group */
+  int class_dirty;
+  int cnt_real, cnt_filter, cnt_env, cnt_exotic;   /* voices per SKC_* bit (kept incrementally) */
+  int mod_dirty;              /* modulator lanes changed: dependency levels must be recomputed */
+  uint32_t fast_mode;         /* SKM_* from classify() */
+  int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
+  int fast2_min_voices;       /* SKRED_OPT_FAST2_MIN_VOICES */
+  int last_kernel;            /* SKRED_KERNEL_* used by the most recent render */
+  skred_globals_t g;
+  uint32_t features;
+  hipEvent_t ev0[SK_TIMING_RING], ev1[SK_TIMING_RING]; /* around the render kernel of each call */
+  int n_timed;                /* render calls since the last timing reset */
+  struct sk_queue_item *queue;  /* deferred updates (skred_bank_update.c), singly linked in arrival order */
+  struct sk_queue_item *queue_tail;
+  int queue_len;
+  void *d_updates;            /* device staging of one batch of voice updates */
+  void *h_updates;            /* its pinned host twin */
+  hipEvent_t ev_updates;      /* recorded after the staging copy: the pinned buffer may be reused once it has fired */
+  size_t updates_cap;         /* in records */
+};
+
+/* per-voice classification (host shadow) */
+#define SKC_REAL   1u   /* a voice was uploaded into this slot and it can sound (has a table) */
+#define SKC_FILTER 2u
+#define SKC_ENV    4u
+#define SKC_EXOTIC 8u   /* needs the generic kernel: see classify() */
+
+
+int skred_amd_set_error(int code, const char *fmt, ...);
+#define fail skred_amd_set_error
+#define HIP_TRY(call)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (call);                                                        \
+    if (e_ != hipSuccess)                                                          \
+      return fail(SKRED_E_NO_DEVICE, "%s -> %s", #call, hipGetErrorString(e_));   \
+  } while (0)
+
+/* One voice of the host view -> its device planes.  Pure: nothing in the bank changes; what the voice
+ * means for kernel selection comes back in `meta` and is applied by sk_apply_meta() when the planes are
+ * written.  phase_known: the host's voice_phase is the voice's current phase (an upload); 0 when only
+ * parameters are being pushed and the phase lives on the device. */
+typedef struct {
+  uint8_t cls;          /* SKC_* */
+  int8_t mod_lane[4];   /* modulator lane inside the 64-voice group (fm, am, pan, cz) or -1 */
+  uint8_t escapes;      /* some modulator lies outside the voice's 64-voice group */
+  uint32_t features;    /* SKB_* this voice needs */
+} sk_voice_meta_t;
+
+int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int dst, int phase_known,
+                  sk_plane_t ro[SKP_COUNT], sk_plane_t rw[SKS_COUNT], sk_voice_meta_t *meta);
+void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *meta);
+void sk_queue_free(skred_bank_t *b);
+
+#endif

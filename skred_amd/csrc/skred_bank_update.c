@@ -1,0 +1,277 @@
+/*
+ * skred_bank_update.c -- block-granular parameter updates on device-resident voices, and the deferred
+ * queue that drives them (SURVEY 8f "next" #4; include/skred_amd.h: skred_bank_update / _defer / _run_queue).
+ *
+ * In the reference every control action -- typed, received over UDP, fired by a pattern step or by a deferred
+ * item (seq.c:164-213,243-257; wire.c:869-892) -- ends in a few stores into the per-voice arrays, and the
+ * audio callback sees them at its next block.  With the voices resident in HBM those stores have to travel:
+ * this file is the protocol.  The host view (skred_voice_bank_t, the reference's array names) stays the place
+ * control code writes to; it then names the voices it touched and WHICH KIND of field (SKRED_DIRTY_*), and
+ * only those voices' planes / words are rewritten on the device, by one scatter kernel per batch, ordered on
+ * the render stream before the next block.  Everything not named keeps the value the GPU last computed (a
+ * full skred_bank_upload would overwrite the running phase, filter memory and smoother with stale host copies).
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "skred_bank_priv.h"
+
+_Static_assert(SKU_PARAMS == SKRED_DIRTY_PARAMS && SKU_PHASE == SKRED_DIRTY_PHASE && SKU_ENV_STATE == SKRED_DIRTY_ENV_STATE &&
+               SKU_PAN == SKRED_DIRTY_PAN && SKU_FILTER_STATE == SKRED_DIRTY_FILTER_STATE && SKU_SMOOTHER == SKRED_DIRTY_SMOOTHER &&
+               SKU_HOLD == SKRED_DIRTY_HOLD && SKU_SAMPLE == SKRED_DIRTY_SAMPLE && SKU_STAMP_TRIGGER == SKRED_STAMP_TRIGGER &&
+               SKU_STAMP_RELEASE == SKRED_STAMP_RELEASE && SKU_ENV_CLOCK == SKRED_DIRTY_ENV_CLOCK, "device update bits must equal the public SKRED_DIRTY_* values");
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* ------------------------------------------------------------------ one voice -> planes */
+
+int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int dst, int phase_known,
+                  sk_plane_t ro[SKP_COUNT], sk_plane_t rw[SKS_COUNT], sk_voice_meta_t *meta) {
+  memset(ro, 0, SKP_COUNT * sizeof(sk_plane_t));
+  memset(rw, 0, SKS_COUNT * sizeof(sk_plane_t));
+  memset(meta, 0, sizeof(*meta));
+  const int size = h->voice_table_size[v];
+  const int64_t off = h->voice_table_offset[v];
+  const int noise = h->voice_wave_table_index[v] == SKRED_WAVE_TABLE_NOISE_ALT;
+  uint32_t flags = 0, features = 0;
+  int usable = 1;
+  if (!noise) {
+    if (size <= 0) usable = 0;   /* the reference would dereference a NULL/empty table here */
+    else if (off < 0 || (uint64_t)off + (uint64_t)size > b->table_floats)
+      return fail(SKRED_E_RANGE, "voice %d: table [%lld,+%d) outside pool of %zu floats", v, (long long)off, size, b->table_floats);
+  }
+  if (!usable) flags |= SKF_INERT;
+  const int windowed = h->voice_loop_enabled[v] && h->voice_loop_valid[v];   /* synth.c:235-238 */
+  const float lo = windowed ? h->voice_loop_start_f[v] : 0.0f;
+  const float hi = windowed ? h->voice_loop_end_f[v] : (float)size;
+  if (h->voice_one_shot[v]) flags |= SKF_ONE_SHOT;
+  if (h->voice_loop_enabled[v]) flags |= SKF_LOOPING;
+  if (h->voice_direction[v]) flags |= SKF_REVERSE;
+  if (h->voice_use_amp_envelope[v]) { flags |= SKF_USE_ENV; features |= SKB_ANY_ENV; }
+  if (h->voice_filter_mode[v]) { flags |= SKF_FILTER; features |= SKB_ANY_FILTER; }
+  if (h->voice_smoother_enable[v]) flags |= SKF_SMOOTH;
+  if (h->voice_disconnect[v]) flags |= SKF_MUTED;
+  if (noise) { flags |= SKF_NOISE; features |= SKB_ANY_NOISE; }
+  const int has_mod = h->voice_freq_mod_osc[v] >= 0 || h->voice_amp_mod_osc[v] >= 0 ||
+                      h->voice_pan_mod_osc[v] >= 0 || h->voice_cz_mode[v] != 0;
+  if (has_mod) { flags |= SKF_HAS_MOD; features |= SKB_ANY_MOD; }
+  int quant = h->voice_quantize[v], hold = h->voice_sample_hold_max[v];
+  if (quant < 0 || quant > 30) quant = quant < 0 ? 0 : 30;
+  if (hold < 0) hold = 0;
+  if (hold > 0xFFFFFF) hold = 0xFFFFFF;
+  if (quant || hold) features |= SKB_ANY_HOLDQ;
+  {
+    uint8_t c = 0;
+    if (usable || noise) c |= SKC_REAL;
+    if (h->voice_filter_mode[v]) c |= SKC_FILTER;
+    if (h->voice_use_amp_envelope[v]) c |= SKC_ENV;
+    const int stops = h->voice_one_shot[v] && !h->voice_loop_enabled[v];
+    /* a phase that lives on the device was finite when it was uploaded and the kernels keep it so */
+    const float ph = phase_known ? h->voice_phase[v] : 0.0f, pi = h->voice_phase_inc[v];
+    const int finite = (ph - ph == 0.0f) && (pi - pi == 0.0f) && (lo - lo == 0.0f) && (hi - hi == 0.0f) && hi > lo;
+    if (stops || noise || has_mod || quant || hold || h->voice_direction[v] || !h->voice_smoother_enable[v] || !finite)
+      c |= SKC_EXOTIC;
+    meta->cls = c;
+  }
+  meta->features = features;
+  const skred_envelope_t *e = &h->voice_amp_envelope[v];
+  const skred_mmf_t *f = &h->voice_filter[v];
+
+  ro[SKP_OSC].w[0] = f2u(h->voice_phase_inc[v]); ro[SKP_OSC].w[1] = f2u(usable ? lo : 0.0f);
+  ro[SKP_OSC].w[2] = f2u(usable ? hi : 1.0f);    ro[SKP_OSC].w[3] = f2u(h->voice_amp[v]);
+  ro[SKP_TAB].w[0] = (uint32_t)(int32_t)(usable && !noise ? off : 0);
+  ro[SKP_TAB].w[1] = (uint32_t)(usable && !noise ? size : 1); ro[SKP_TAB].w[2] = flags;
+  ro[SKP_TAB].w[3] = (uint32_t)quant | ((uint32_t)hold << 8);
+  ro[SKP_ENV_T].w[0] = f2u(e->attack_time);   ro[SKP_ENV_T].w[1] = f2u(e->decay_time);
+  ro[SKP_ENV_T].w[2] = f2u(e->sustain_level); ro[SKP_ENV_T].w[3] = f2u(e->release_time);
+  ro[SKP_ENV_S].w[0] = (uint32_t)(e->sample_start & 0xFFFFFFFFu);
+  ro[SKP_ENV_S].w[1] = (uint32_t)(e->sample_start >> 32);
+  ro[SKP_ENV_S].w[2] = (uint32_t)(e->sample_release & 0xFFFFFFFFu);
+  ro[SKP_ENV_S].w[3] = (uint32_t)(e->sample_release >> 32);
+  ro[SKP_GAIN].w[0] = f2u(e->velocity); ro[SKP_GAIN].w[1] = f2u(h->voice_smoother_smoothing[v]);
+  ro[SKP_GAIN].w[2] = f2u(f->b0);       ro[SKP_GAIN].w[3] = f2u(f->b1);
+  ro[SKP_FILT].w[0] = f2u(f->b2); ro[SKP_FILT].w[1] = f2u(f->a1);
+  ro[SKP_FILT].w[2] = f2u(f->a2); ro[SKP_FILT].w[3] = f2u(h->voice_cz_distortion[v]);
+  {
+    /* modulator indices: host index -> lane inside the carrier's 64-voice device group, -1 = unused
+     * (FM ignores a self reference, synth.c:549; the CZ source only matters with CZ on, synth.c:262) */
+    int src[4] = { h->voice_freq_mod_osc[v], h->voice_amp_mod_osc[v], h->voice_pan_mod_osc[v],
+                   h->voice_cz_mode[v] ? h->voice_cz_mod_osc[v] : -1 };
+    if (src[0] == v) src[0] = -1;
+    for (int k = 0; k < 4; k++) {
+      int lane_k = -1;
+      if (src[k] >= 0) {
+        const int md = src[k] + (dst - v);
+        if (md < 0 || md >= b->n_voices || (md >> 6) != (dst >> 6)) meta->escapes = 1;
+        else lane_k = md & 63;
+      }
+      meta->mod_lane[k] = (int8_t)lane_k;
+      ro[SKP_MODI].w[k] = (uint32_t)(int32_t)lane_k;
+    }
+  }
+  ro[SKP_MODF].w[0] = f2u(h->voice_freq_mod_depth[v]); ro[SKP_MODF].w[1] = f2u(h->voice_freq_scale[v]);
+  ro[SKP_MODF].w[2] = f2u(h->voice_amp_mod_depth[v]);  ro[SKP_MODF].w[3] = f2u(h->voice_pan_mod_depth[v]);
+  ro[SKP_MODX].w[0] = f2u(h->voice_cz_mod_depth[v]); ro[SKP_MODX].w[1] = (uint32_t)h->voice_cz_mode[v];
+
+  rw[SKS_OSC].w[0] = f2u(h->voice_phase[v]); rw[SKS_OSC].w[1] = f2u(h->voice_smoother_gain[v]);
+  rw[SKS_OSC].w[2] = f2u(f->x1);             rw[SKS_OSC].w[3] = f2u(f->x2);
+  rw[SKS_FILT].w[0] = f2u(f->y1); rw[SKS_FILT].w[1] = f2u(f->y2);
+  rw[SKS_FILT].w[2] = f2u(h->voice_sample[v]);
+  rw[SKS_FILT].w[3] = (h->voice_finished[v] ? SKR_FINISHED : 0u) | (e->is_active ? SKR_ENV_ACTIVE : 0u);
+  rw[SKS_MISC].w[0] = f2u(h->voice_sample_hold[v]); rw[SKS_MISC].w[1] = (uint32_t)h->voice_sample_hold_count[v];
+  rw[SKS_MISC].w[2] = f2u(h->voice_pan_left[v]);    rw[SKS_MISC].w[3] = f2u(h->voice_pan_right[v]);
+  return SKRED_OK;
+}
+
+/* what voice `dst` now means for kernel selection (counters instead of a scan: a bank has up to millions of voices) */
+void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m) {
+  const uint8_t old = b->h_class[dst], now = m->cls;
+  if (old != now) {
+    if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; }
+    if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; }
+    b->h_class[dst] = now;
+    b->class_dirty = 1;
+  }
+  for (int k = 0; k < 4; k++) {
+    int8_t *slot = &b->h_mod[(size_t)k * b->n_padded + dst];
+    if (*slot != m->mod_lane[k]) { *slot = m->mod_lane[k]; b->mod_dirty = 1; b->class_dirty = 1; }
+  }
+  if (m->escapes) b->mod_escapes = 1;
+  if ((b->features | m->features) != b->features) { b->features |= m->features; b->class_dirty = 1; b->mod_dirty = 1; }
+}
+
+/* ------------------------------------------------------------------ batches of voice updates */
+
+typedef struct sk_queue_item {
+  struct sk_queue_item *next;
+  uint64_t when;
+  int n;
+  sk_update_t *rec;          /* device-format records */
+  sk_voice_meta_t *meta;     /* NULL unless the batch carries SKRED_DIRTY_PARAMS */
+} sk_queue_item_t;
+
+static int build_batch(const skred_bank_t *b, const skred_voice_bank_t *h, const int32_t *voices, int n,
+                       uint32_t dirty, sk_update_t **rec_out, sk_voice_meta_t **meta_out) {
+  *rec_out = NULL;
+  *meta_out = NULL;
+  if ((dirty & ~(uint32_t)SKRED_DIRTY_VALID_MASK) || !dirty) return fail(SKRED_E_BAD_ARG, "update: dirty mask 0x%x", dirty);
+  sk_update_t *rec = (sk_update_t *)calloc((size_t)n, sizeof(sk_update_t));
+  sk_voice_meta_t *meta = (dirty & SKRED_DIRTY_PARAMS) ? (sk_voice_meta_t *)calloc((size_t)n, sizeof(sk_voice_meta_t)) : NULL;
+  if (!rec || ((dirty & SKRED_DIRTY_PARAMS) && !meta)) { free(rec); free(meta); return fail(SKRED_E_NO_MEM, "update staging"); }
+  for (int i = 0; i < n; i++) {
+    const int v = voices[i];
+    if (v < 0 || v >= b->n_voices || v >= h->n_voices) { free(rec); free(meta); return fail(SKRED_E_RANGE, "update: voice %d outside the bank", v); }
+    sk_voice_meta_t m;
+    const int rc = sk_pack_voice(b, h, v, v, (dirty & SKRED_DIRTY_PHASE) != 0, rec[i].ro, rec[i].rw, &m);
+    if (rc) { free(rec); free(meta); return rc; }
+    rec[i].voice = v;
+    rec[i].dirty = dirty;
+    if (meta) meta[i] = m;
+  }
+  *rec_out = rec;
+  *meta_out = meta;
+  return SKRED_OK;
+}
+
+/* push records to the device and scatter them; a voice named twice is applied in order (one launch per run
+ * of distinct voices) */
+static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_meta_t *meta, int n, hipStream_t s) {
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->ev_updates) HIP_TRY(hipEventCreateWithFlags(&b->ev_updates, hipEventDisableTiming));
+  /* the pinned staging buffer is free again once the previous batch's copy has run (normally long ago) */
+  else HIP_TRY(hipEventSynchronize(b->ev_updates));
+  if ((size_t)n > b->updates_cap) {
+    if (b->d_updates) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(b->d_updates); b->d_updates = NULL; }
+    if (b->h_updates) { (void)hipHostFree(b->h_updates); b->h_updates = NULL; }
+    b->updates_cap = 0;
+    size_t cap = 256;
+    while (cap < (size_t)n) cap *= 2;
+    HIP_TRY(hipMalloc(&b->d_updates, cap * sizeof(sk_update_t)));
+    HIP_TRY(hipHostMalloc(&b->h_updates, cap * sizeof(sk_update_t), hipHostMallocDefault));
+    b->updates_cap = cap;
+  }
+  memcpy(b->h_updates, rec, (size_t)n * sizeof(sk_update_t));
+  HIP_TRY(hipMemcpyAsync(b->d_updates, b->h_updates, (size_t)n * sizeof(sk_update_t), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipEventRecord(b->ev_updates, s));
+  int start = 0;
+  while (start < n) {
+    int end = start + 1;
+    for (; end < n; end++) {
+      int dup = 0;
+      for (int j = start; j < end && !dup; j++) dup = rec[j].voice == rec[end].voice;
+      if (dup) break;
+      if (end - start >= 64) { /* bound the quadratic scan: long batches are split, still in order */ end++; break; }
+    }
+    if (end > n) end = n;
+    const hipError_t e = (hipError_t)sk_launch_update((const sk_update_t *)b->d_updates + start, end - start, b->d_ro, b->d_rw,
+                                                      b->g.synth_sample_count, s);
+    if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "update launch -> %s", hipGetErrorString(e));
+    start = end;
+  }
+  if (meta) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i]);
+  return SKRED_OK;
+}
+
+int skred_bank_update(skred_bank_t *b, const skred_voice_bank_t *h, const int32_t *voices, int n_voices,
+                      uint32_t dirty, void *stream) {
+  if (!b || !h || !voices || n_voices < 0) return fail(SKRED_E_BAD_ARG, "update: bad arguments");
+  if (n_voices == 0) return SKRED_OK;
+  sk_update_t *rec;
+  sk_voice_meta_t *meta;
+  int rc = build_batch(b, h, voices, n_voices, dirty, &rec, &meta);
+  if (rc) return rc;
+  rc = apply_batch(b, rec, meta, n_voices, (hipStream_t)stream);
+  free(rec);
+  free(meta);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ the deferred queue (seq.c:243-257, 170-177) */
+
+int skred_bank_defer(skred_bank_t *b, uint64_t when, const skred_voice_bank_t *h, const int32_t *voices,
+                     int n_voices, uint32_t dirty) {
+  if (!b || !h || !voices || n_voices <= 0) return fail(SKRED_E_BAD_ARG, "defer: bad arguments");
+  if (b->queue_len >= SKRED_QUEUE_SIZE) return fail(SKRED_E_RANGE, "defer: queue full (%d items)", SKRED_QUEUE_SIZE);
+  sk_queue_item_t *it = (sk_queue_item_t *)calloc(1, sizeof(*it));
+  if (!it) return fail(SKRED_E_NO_MEM, "defer");
+  const int rc = build_batch(b, h, voices, n_voices, dirty, &it->rec, &it->meta);
+  if (rc) { free(it); return rc; }
+  it->when = when;
+  it->n = n_voices;
+  if (b->queue_tail) b->queue_tail->next = it; else b->queue = it;
+  b->queue_tail = it;
+  b->queue_len++;
+  return SKRED_OK;
+}
+
+int skred_bank_queue_pending(const skred_bank_t *b) { return b ? b->queue_len : 0; }
+
+int skred_bank_run_queue(skred_bank_t *b, int frame_count, void *stream) {
+  if (!b || frame_count < 0) return fail(SKRED_E_BAD_ARG, "run_queue: bad arguments");
+  const uint64_t horizon = b->g.synth_sample_count + (uint64_t)frame_count;      /* seq.c:173 */
+  int applied = 0;
+  sk_queue_item_t **link = &b->queue, *prev = NULL;
+  while (*link) {
+    sk_queue_item_t *it = *link;
+    if (it->when <= horizon) {
+      const int rc = apply_batch(b, it->rec, it->meta, it->n, (hipStream_t)stream);
+      if (rc) return rc;
+      *link = it->next;
+      if (b->queue_tail == it) b->queue_tail = prev;
+      free(it->rec); free(it->meta); free(it);
+      b->queue_len--;
+      applied++;
+    } else {
+      prev = it;
+      link = &it->next;
+    }
+  }
+  return applied;
+}
+
+void sk_queue_free(skred_bank_t *b) {
+  sk_queue_item_t *it = b->queue;
+  while (it) { sk_queue_item_t *n = it->next; free(it->rec); free(it->meta); free(it); it = n; }
+  b->queue = b->queue_tail = NULL;
+  b->queue_len = 0;
+}

@@ -84,6 +84,29 @@ typedef struct {
   uint32_t w[4];
 } sk_plane_t;
 
+/* ---- block-granular voice updates (skred_bank_update.c -> skred_update_kernels.hip) ----
+ * One record per touched voice: all planes as the host packed them, and which parts to write.  The bits equal
+ * SKRED_DIRTY_* of include/skred_amd.h (checked at compile time in skred_bank_update.c). */
+#define SKU_PARAMS        (1u << 0)   /* all read-only planes except SKP_ENV_S */
+#define SKU_PHASE         (1u << 1)   /* SKS_OSC.w0, SKR_FINISHED */
+#define SKU_ENV_STATE     (1u << 2)   /* SKR_ENV_ACTIVE */
+#define SKU_PAN           (1u << 3)   /* SKS_MISC.w2, w3 */
+#define SKU_FILTER_STATE  (1u << 4)   /* SKS_OSC.w2, w3; SKS_FILT.w0, w1 */
+#define SKU_SMOOTHER      (1u << 5)   /* SKS_OSC.w1 */
+#define SKU_HOLD          (1u << 6)   /* SKS_MISC.w0, w1 */
+#define SKU_SAMPLE        (1u << 7)   /* SKS_FILT.w2 */
+#define SKU_STAMP_TRIGGER (1u << 8)   /* envelope: sample_start = now, sample_release = 0, is_active = 1 (synth.c:383-388) */
+#define SKU_STAMP_RELEASE (1u << 9)   /* envelope: if is_active, sample_release = now (synth.c:391-395) */
+#define SKU_ENV_CLOCK     (1u << 10)  /* SKP_ENV_S: sample_start, sample_release as the host has them */
+
+typedef struct {
+  int32_t voice;
+  uint32_t dirty;
+  uint32_t pad[2];
+  sk_plane_t ro[SKP_COUNT];
+  sk_plane_t rw[SKS_COUNT];
+} sk_update_t;
+
 /* kernel arguments of the render kernel */
 typedef struct {
   const sk_plane_t *ro[SKP_COUNT];

@@ -6,6 +6,7 @@
  *   skred_render_fast.hip     sk_launch_render_fast
  *   skred_render_fast2.hip    sk_launch_render_fast2
  *   skred_mix_kernels.hip     sk_launch_reduce, sk_reduce_tmp_floats, sk_launch_master
+ *   skred_update_kernels.hip  sk_launch_update
  *   skred_rec_kernels.hip     sk_launch_rec_minmax, sk_rec_partial_floats, sk_launch_rec_convert
  *
  * Every launcher returns the hipError_t of the launch as an int.
@@ -40,6 +41,10 @@ int sk_launch_reduce(const float *partial, float *tmp, float *out, int W, int nc
 int sk_reduce_tmp_floats(int ncols);
 int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels, float target, float k,
                      float *gain_state, hipStream_t stream);
+
+/* scatter n voice updates into the planes; `now` = synth_sample_count for the STAMP bits */
+int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[SKP_COUNT], sk_plane_t *const rw[SKS_COUNT],
+                     uint64_t now, hipStream_t stream);
 
 /* stem recorder (skred_recorder.c): min/max partials of rec[n_floats]; selected voices -> int16 pairs */
 int sk_rec_partial_floats(void);

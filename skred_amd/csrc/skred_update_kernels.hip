@@ -1,0 +1,64 @@
+// skred_update_kernels.hip -- scatter a batch of voice updates into the device planes (gfx950 / CDNA4).
+//
+// One thread per record (a batch is the handful of voices a control action touched in one audio block; the
+// launch is latency, not bandwidth).  Parameter planes are overwritten whole; state planes are patched word by
+// word so that whatever the update does not name keeps the value the render kernels last stored.  Records of one
+// launch name distinct voices (the host splits batches), so there are no write conflicts.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "skred_launch.h"
+
+struct sk_plane_ptrs_t {
+  sk_plane_t *ro[SKP_COUNT];
+  sk_plane_t *rw[SKS_COUNT];
+};
+
+__global__ __launch_bounds__(64) void sk_update_kernel(const sk_update_t *__restrict__ u, int n, sk_plane_ptrs_t p,
+                                                      uint64_t now) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const sk_update_t r = u[i];
+  const int v = r.voice;
+  const uint32_t d = r.dirty;
+  if (d & SKU_PARAMS) {
+#pragma unroll
+    for (int k = 0; k < SKP_COUNT; ++k)     // the envelope clock plane is its own kind: a stamped note-off must survive
+      if (k != SKP_ENV_S) *reinterpret_cast<uint4 *>(&p.ro[k][v]) = *reinterpret_cast<const uint4 *>(&r.ro[k]);
+  }
+  if (d & SKU_ENV_CLOCK) *reinterpret_cast<uint4 *>(&p.ro[SKP_ENV_S][v]) = *reinterpret_cast<const uint4 *>(&r.ro[SKP_ENV_S]);
+  uint4 s0 = *reinterpret_cast<const uint4 *>(&p.rw[SKS_OSC][v]);
+  uint4 s1 = *reinterpret_cast<const uint4 *>(&p.rw[SKS_FILT][v]);
+  uint4 s2 = *reinterpret_cast<const uint4 *>(&p.rw[SKS_MISC][v]);
+  if (d & SKU_PHASE) { s0.x = r.rw[SKS_OSC].w[0]; s1.w = (s1.w & ~SKR_FINISHED) | (r.rw[SKS_FILT].w[3] & SKR_FINISHED); }
+  if (d & SKU_ENV_STATE) s1.w = (s1.w & ~SKR_ENV_ACTIVE) | (r.rw[SKS_FILT].w[3] & SKR_ENV_ACTIVE);
+  if (d & SKU_PAN) { s2.z = r.rw[SKS_MISC].w[2]; s2.w = r.rw[SKS_MISC].w[3]; }
+  if (d & SKU_FILTER_STATE) { s0.z = r.rw[SKS_OSC].w[2]; s0.w = r.rw[SKS_OSC].w[3]; s1.x = r.rw[SKS_FILT].w[0]; s1.y = r.rw[SKS_FILT].w[1]; }
+  if (d & SKU_SMOOTHER) s0.y = r.rw[SKS_OSC].w[1];
+  if (d & SKU_HOLD) { s2.x = r.rw[SKS_MISC].w[0]; s2.y = r.rw[SKS_MISC].w[1]; }
+  if (d & SKU_SAMPLE) s1.z = r.rw[SKS_FILT].w[2];
+  if (d & (SKU_STAMP_TRIGGER | SKU_STAMP_RELEASE)) {
+    uint4 es = *reinterpret_cast<const uint4 *>(&p.ro[SKP_ENV_S][v]);   // after the ENV_CLOCK write above, if any
+    if (d & SKU_STAMP_TRIGGER) {        // amp_envelope_trigger (velocity travels with the parameters)
+      es.x = (uint32_t)now; es.y = (uint32_t)(now >> 32); es.z = 0; es.w = 0;
+      s1.w |= SKR_ENV_ACTIVE;
+    }
+    if ((d & SKU_STAMP_RELEASE) && (s1.w & SKR_ENV_ACTIVE)) {           // amp_envelope_release
+      es.z = (uint32_t)now; es.w = (uint32_t)(now >> 32);
+    }
+    *reinterpret_cast<uint4 *>(&p.ro[SKP_ENV_S][v]) = es;
+  }
+  *reinterpret_cast<uint4 *>(&p.rw[SKS_OSC][v]) = s0;
+  *reinterpret_cast<uint4 *>(&p.rw[SKS_FILT][v]) = s1;
+  *reinterpret_cast<uint4 *>(&p.rw[SKS_MISC][v]) = s2;
+}
+
+extern "C" int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[SKP_COUNT],
+                                sk_plane_t *const rw[SKS_COUNT], uint64_t now, hipStream_t stream) {
+  if (n <= 0) return 0;
+  sk_plane_ptrs_t p;
+  for (int k = 0; k < SKP_COUNT; ++k) p.ro[k] = ro[k];
+  for (int k = 0; k < SKS_COUNT; ++k) p.rw[k] = rw[k];
+  hipLaunchKernelGGL(sk_update_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_updates, n, p, now);
+  return (int)hipGetLastError();
+}

@@ -25,7 +25,13 @@ ABI_SYMBOLS = [
     "skred_bank_render", "skred_bank_master", "skred_bank_render_host",
     "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
     "skred_bank_set_option", "skred_bank_last_kernel",
+    "skred_bank_update", "skred_bank_defer", "skred_bank_run_queue", "skred_bank_queue_pending",
 ]
+
+# SKRED_DIRTY_* / SKRED_STAMP_* of include/skred_amd.h
+DIRTY_PARAMS, DIRTY_PHASE, DIRTY_ENV_STATE, DIRTY_PAN = 1, 2, 4, 8
+DIRTY_FILTER_STATE, DIRTY_SMOOTHER, DIRTY_HOLD, DIRTY_SAMPLE = 16, 32, 64, 128
+STAMP_TRIGGER, STAMP_RELEASE, DIRTY_ENV_CLOCK = 256, 512, 1024
 
 _lib: Optional[C.CDLL] = None
 
@@ -66,6 +72,10 @@ def load() -> C.CDLL:
     L.skred_bank_timing_reset.argtypes = [vp]
     L.skred_bank_timing_reset.restype = None
     L.skred_bank_timing_summary.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]
+    L.skred_bank_update.argtypes = [vp, C.POINTER(VoiceBankC), vp, i32, C.c_uint32, vp]
+    L.skred_bank_defer.argtypes = [vp, C.c_uint64, C.POINTER(VoiceBankC), vp, i32, C.c_uint32]
+    L.skred_bank_run_queue.argtypes = [vp, i32, vp]
+    L.skred_bank_queue_pending.argtypes = [vp]
     _lib = L
     return L
 
@@ -135,6 +145,27 @@ class DeviceBank:
         _check(self.L.skred_bank_render_host(self.h, buf.ctypes.data, frames, channels, interp,
                                              stems.ctypes.data if want_stems else None), "skred_bank_render_host")
         return buf, stems
+
+    # ---- block-granular updates (include/skred_amd.h: skred_bank_update / _defer / _run_queue) ----
+    def update(self, bank: VoiceBank, voices, dirty: int, stream: int = 0):
+        """Push the `dirty` parts (DIRTY_* | STAMP_*) of the listed voices from the host view."""
+        v = np.ascontiguousarray(voices, np.int32)
+        _check(self.L.skred_bank_update(self.h, C.byref(bank.as_c()), v.ctypes.data, len(v), dirty, stream),
+               "skred_bank_update")
+
+    def defer(self, when: int, bank: VoiceBank, voices, dirty: int):
+        v = np.ascontiguousarray(voices, np.int32)
+        _check(self.L.skred_bank_defer(self.h, when, C.byref(bank.as_c()), v.ctypes.data, len(v), dirty),
+               "skred_bank_defer")
+
+    def run_queue(self, frame_count: int, stream: int = 0) -> int:
+        n = self.L.skred_bank_run_queue(self.h, frame_count, stream)
+        if n < 0:
+            _check(n, "skred_bank_run_queue")
+        return n
+
+    def queue_pending(self) -> int:
+        return self.L.skred_bank_queue_pending(self.h)
 
     def force_generic(self, on: bool = True):
         _check(self.L.skred_bank_set_option(self.h, 1, int(on)), "skred_bank_set_option")

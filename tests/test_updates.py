@@ -1,0 +1,278 @@
+"""SURVEY 8f "next" #4: block-granular parameter updates on device-resident voices, and the deferred queue.
+
+The voices live in HBM for the whole test: after the initial upload the host NEVER downloads state and never
+re-uploads the bank.  Control actions are applied to a host mirror of the PARAMETERS (whose state fields go stale
+at once) and pushed with skred_bank_update / skred_bank_defer naming only what they touched.  Truth is the oracle
+rendering the same blocks from a bank to which the same actions are applied as plain array stores -- the way the
+reference's control path does it (wire.c:606-716 -> synth.c setters) -- with its own, true, state."""
+import numpy as np
+import pytest
+
+from oracle import cpuref
+from skred_amd import banks
+
+pytestmark = pytest.mark.gpu
+
+F = 256
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from skred_amd import device
+    assert device.load().skred_amd_device_count() > 0, "no GPU visible"
+    return device
+
+
+def rel_rms(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-30))
+
+
+class Action:
+    """One control action: stores into a bank's arrays (run on the oracle's bank AND on the GPU's host mirror) plus
+    the dirty mask that describes them.  `now` is synth_sample_count when the action runs."""
+
+    def __init__(self, voices, dirty, store):
+        self.voices, self.dirty, self.store = np.asarray(voices, np.int32), dirty, store
+
+    def apply_to(self, bank, now, true_state=None):
+        self.store(bank, self.voices, now, true_state if true_state is not None else bank)
+
+
+def actions_for_block(k, n, rng, D):
+    """A seeded mix of the reference's control actions for block k."""
+    out = []
+    v = rng.choice(n, 7, replace=False)
+
+    def set_freq(b, vs, now, st):                               # freq_set -> osc_set_freq (synth.c:125-137)
+        b["voice_phase_inc"][vs] = (b["voice_phase_inc"][vs] * np.float32(1.0 + 0.1 * ((k % 5) - 2))).astype(np.float32)
+    out.append(Action(v[:2], D.DIRTY_PARAMS, set_freq))
+
+    def set_amp(b, vs, now, st):                                # amp_set (synth.c:826-836)
+        b["voice_amp"][vs] = np.float32(0.25 + 0.5 * ((k * 7) % 4))
+    out.append(Action(v[2:3], D.DIRTY_PARAMS, set_amp))
+
+    def set_pan(b, vs, now, st):                                # pan_set (synth.c:838-847)
+        p = np.float32(-0.9 + 0.3 * (k % 7))
+        b["voice_pan_left"][vs] = (np.float32(1.0) - p) / np.float32(2.0)
+        b["voice_pan_right"][vs] = (np.float32(1.0) + p) / np.float32(2.0)
+    out.append(Action(v[3:4], D.DIRTY_PAN, set_pan))
+
+    def set_filter(b, vs, now, st):                             # mmf_set_freq -> mmf_set_params (synth.c:929-1008)
+        c = banks.biquad_coeffs(b["voice_filter_mode"][vs], np.full(len(vs), 300.0 + 400.0 * (k % 9), np.float32),
+                                np.full(len(vs), 0.9, np.float32), 48000)
+        f = b["voice_filter"]
+        for name in ("b0", "b1", "b2", "a1", "a2"):
+            f[name][vs] = c[name]
+    out.append(Action(v[4:5], D.DIRTY_PARAMS, set_filter))
+
+    def trigger(b, vs, now, st):                                # voice_trigger: osc_trigger + amp_envelope_trigger
+        b["voice_finished"][vs] = 0
+        b["voice_phase"][vs] = np.where(b["voice_loop_enabled"][vs] != 0, b["voice_loop_start_f"][vs], np.float32(0.0))
+        e = b["voice_amp_envelope"]
+        e["sample_start"][vs] = now
+        e["sample_release"][vs] = 0
+        e["velocity"][vs] = np.float32(0.5 + 0.1 * (k % 5))
+        e["is_active"][vs] = 1
+    out.append(Action(v[5:6], D.DIRTY_PHASE | D.DIRTY_PARAMS | D.STAMP_TRIGGER, trigger))
+
+    def release(b, vs, now, st):                                # amp_envelope_release: reads the TRUE is_active
+        e = b["voice_amp_envelope"]
+        act = st["voice_amp_envelope"]["is_active"][vs] != 0
+        e["sample_release"][vs[act]] = now
+    out.append(Action(v[6:7], D.STAMP_RELEASE, release))
+    return out
+
+
+def test_updates_without_ever_downloading(dev):
+    """40 blocks of mixed control actions on a 3000-voice filtered bank (specialised kernel); at block 12 a voice turns
+    to reverse playback (the bank needs the generic kernel), at block 20 it turns back."""
+    D = dev
+    n = 3000
+    bank, tables, g = banks.bank_c2(n)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    mirror = bank.copy()            # GPU side: parameters current, state stale
+    truth, gl = bank.copy(), g.copy()
+    rng = np.random.default_rng(11)
+    mixes, refs, kernels = [], [], []
+    for k in range(40):
+        now = gl.synth_sample_count
+        acts = actions_for_block(k, n, rng, D)
+        if k in (12, 20):
+            def flip(b, vs, now_, st, on=(k == 12)):
+                b["voice_direction"][vs] = 1 if on else 0
+            acts.append(Action([77], D.DIRTY_PARAMS, flip))
+        for a in acts:
+            a.apply_to(truth, now)
+            a.apply_to(mirror, now, true_state=truth)    # the mirror cannot know is_active; the device does
+            db.update(mirror, a.voices, a.dirty)
+        m, _ = db.render_host(F, 2, 0)
+        mixes.append(m)
+        kernels.append(db.last_kernel())
+        r = cpuref.render(truth, gl, tables, F, 0)
+        refs.append(cpuref.master(gl, r["sum64"].astype(np.float32)))
+    got = bank.copy()
+    db.download(got)
+    db.close()
+    assert kernels[0] == 1 and set(kernels[12:20]) == {0} and kernels[-1] == 1, kernels
+    bad = got.rw_equal(truth)
+    assert not bad, bad
+    assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
+
+
+PARAM_FIELDS = ["voice_phase_inc", "voice_amp", "voice_table_offset", "voice_table_size", "voice_one_shot",
+                "voice_loop_enabled", "voice_loop_valid", "voice_loop_start_f", "voice_loop_end_f", "voice_direction",
+                "voice_wave_table_index", "voice_use_amp_envelope", "voice_filter_mode", "voice_smoother_enable",
+                "voice_smoother_smoothing", "voice_disconnect", "voice_quantize", "voice_sample_hold_max"]
+
+
+def apply_captured(dst, snap, vs, dirty, now, D):
+    """The update protocol restated on numpy banks: what skred_bank_update does to the device, done to `dst`."""
+    if dirty & D.DIRTY_PARAMS:
+        for name in PARAM_FIELDS:
+            dst[name][vs] = snap[name][vs]
+        for sub in ("a", "d", "s", "r", "attack_time", "decay_time", "sustain_level", "release_time", "velocity"):
+            dst["voice_amp_envelope"][sub][vs] = snap["voice_amp_envelope"][sub][vs]
+        for sub in ("b0", "b1", "b2", "a1", "a2"):
+            dst["voice_filter"][sub][vs] = snap["voice_filter"][sub][vs]
+    if dirty & D.DIRTY_PHASE:
+        dst["voice_phase"][vs] = snap["voice_phase"][vs]
+        dst["voice_finished"][vs] = snap["voice_finished"][vs]
+    if dirty & D.DIRTY_PAN:
+        dst["voice_pan_left"][vs] = snap["voice_pan_left"][vs]
+        dst["voice_pan_right"][vs] = snap["voice_pan_right"][vs]
+    e = dst["voice_amp_envelope"]
+    if dirty & D.DIRTY_ENV_CLOCK:
+        e["sample_start"][vs] = snap["voice_amp_envelope"]["sample_start"][vs]
+        e["sample_release"][vs] = snap["voice_amp_envelope"]["sample_release"][vs]
+    if dirty & D.STAMP_TRIGGER:
+        e["sample_start"][vs] = now
+        e["sample_release"][vs] = 0
+        e["is_active"][vs] = 1
+    if dirty & D.STAMP_RELEASE:
+        act = e["is_active"][vs] != 0
+        e["sample_release"][vs[act]] = now
+
+
+def test_deferred_queue_follows_seq_rule(dev):
+    """Items queued with a sample time take effect at the start of the block that contains it: seq() after block k
+    runs every item with when <= synth_sample_count + frame_count (seq.c:173).  Values are captured when the item is
+    queued; trigger / release stamps read the clock when they RUN, as amp_envelope_trigger / _release read the
+    global (synth.c:384,393)."""
+    D = dev
+    n = 1024
+    bank, tables, g = banks.bank_c1(n)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    mirror, truth, gl = bank.copy(), bank.copy(), g.copy()
+    t0 = gl.synth_sample_count
+    rng = np.random.default_rng(3)
+    pending = []                                     # (when, snapshot, voices, dirty) in arrival order
+    for i in range(30):
+        when = t0 + int(rng.integers(0, 20 * F))
+        acts = actions_for_block(i, n, rng, D)
+        a = acts[int(rng.integers(0, len(acts)))]
+        a.apply_to(mirror, 0, true_state=truth)      # control code stores into the host view ...
+        snap = mirror.copy()
+        db.defer(when, snap, a.voices, a.dirty)      # ... and queues what it touched
+        pending.append((when, snap, a.voices, a.dirty))
+    assert db.queue_pending() == 30
+    mixes, refs, applied_total = [], [], 0
+    for k in range(24):
+        horizon = gl.synth_sample_count + F
+        applied_total += db.run_queue(F)
+        due = [it for it in pending if it[0] <= horizon]
+        pending = [it for it in pending if it[0] > horizon]
+        for _, snap, vs, dirty in due:
+            apply_captured(truth, snap, vs, dirty, gl.synth_sample_count, D)
+        m, _ = db.render_host(F, 2, 0)
+        mixes.append(m)
+        r = cpuref.render(truth, gl, tables, F, 0)
+        refs.append(cpuref.master(gl, r["sum64"].astype(np.float32)))
+    assert applied_total == 30 and db.queue_pending() == 0 and not pending
+    got = bank.copy()
+    db.download(got)
+    db.close()
+    bad = got.rw_equal(truth)
+    assert not bad, bad
+    assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
+
+
+def test_stamped_note_off_survives_a_later_parameter_update(dev):
+    """`release` stamps sample_release on the device; the host mirror still holds 0.  A later PARAMS update of the
+    same voice must not bring that 0 back (the envelope clock is its own dirty kind)."""
+    D = dev
+    n = 512
+    bank, tables, g = banks.bank_c1(n)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    mirror, truth, gl = bank.copy(), bank.copy(), g.copy()
+    vs = np.array([3, 200], np.int32)
+    mixes, refs = [], []
+    for k in range(6):
+        if k == 1:
+            db.update(mirror, vs, D.STAMP_RELEASE)
+            apply_captured(truth, mirror, vs, D.STAMP_RELEASE, gl.synth_sample_count, D)
+        if k == 2:
+            mirror["voice_amp"][vs] = np.float32(0.5)
+            db.update(mirror, vs, D.DIRTY_PARAMS)
+            truth["voice_amp"][vs] = np.float32(0.5)
+        m, _ = db.render_host(4800, 2, 0)
+        mixes.append(m)
+        r = cpuref.render(truth, gl, tables, 4800, 0)
+        refs.append(cpuref.master(gl, r["sum64"].astype(np.float32)))
+    got = bank.copy()
+    db.download(got)
+    db.close()
+    assert (truth["voice_amp_envelope"]["is_active"][vs] == 0).all()     # the release ran out (0.2 s)
+    assert not got.rw_equal(truth), got.rw_equal(truth)
+    assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
+
+
+def test_update_argument_checks(dev):
+    n = 256
+    bank, tables, g = banks.bank_c1(n)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    with pytest.raises(dev.SkredAmdError):
+        db.update(bank, [n], dev.DIRTY_PARAMS)                 # voice outside the bank
+    with pytest.raises(dev.SkredAmdError):
+        db.update(bank, [0], 0)                                # nothing named
+    with pytest.raises(dev.SkredAmdError):
+        db.update(bank, [0], 1 << 12)                          # unknown bit
+    db.update(bank, [], dev.DIRTY_PARAMS)                      # empty batch is fine
+    db.update(bank, [5, 5, 5], dev.DIRTY_PARAMS)               # repeated voice: applied in order
+    db.close()
+
+
+def test_million_voice_bank_takes_small_updates(dev):
+    """2^20 voices resident; 64 voices change per block.  The per-block cost of the update path must not scale with
+    the bank (classification is incremental, only the touched records travel)."""
+    import time
+    n = 1 << 20
+    bank, tables, g = banks.bank_c2(n)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    db.render_host(64, 2, 0)
+    rng = np.random.default_rng(5)
+    t = []
+    for k in range(20):
+        vs = rng.choice(n, 64, replace=False).astype(np.int32)
+        bank["voice_amp"][vs] = np.float32(0.5)
+        t0 = time.perf_counter()
+        db.update(bank, vs, dev.DIRTY_PARAMS)
+        t.append(time.perf_counter() - t0)
+        db.render_host(64, 2, 0)
+        assert db.last_kernel() == 3
+    db.close()
+    assert np.median(t) < 2e-3, t                              # a full re-upload of this bank takes ~100 ms

@@ -243,10 +243,14 @@ def main():
                 for _ in range(n):
                     sh.step_overlapped(render_partial, master, out)
                 sh.drain(master, out)                       # leaves the pair of buffers in place
-        else:
+        elif world > 1:
             def run(n):
                 for _ in range(n):
-                    sh.step(render_partial, master, red, out)   # render -> (RCCL reduce, N>1) -> master on rank 0
+                    sh.step(render_partial, master, red, out)   # render -> RCCL reduce -> master on rank 0
+        else:
+            def run(n):                                         # one GPU: render + (last reduction stage fused with) master
+                for _ in range(n):
+                    db.render_mix(frames, out.data_ptr(), 2, 0, interp, stream)
         run(warmup)
         fence()
         db.timing_reset()

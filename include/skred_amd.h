@@ -200,6 +200,12 @@ int  skred_bank_render(skred_bank_t *bank, int num_frames, int interp,
 int  skred_bank_master(skred_bank_t *bank, const float *d_sum, int num_frames,
                        int num_channels, float *d_out, void *stream);
 
+/* Single-GPU form of render + master: the last stage of the partial-mix reduction and the master stage run
+ * as one kernel (one launch fewer per block; same samples as skred_bank_render + skred_bank_master).
+ * `d_out` as for skred_bank_master.  Asynchronous. */
+int  skred_bank_render_mix(skred_bank_t *bank, int num_frames, int interp, float *d_out, int num_channels,
+                           float *d_stems_or_null, void *stream);
+
 /* Whole synth() contract on host buffers: render + master + D2H (+ stems). Synchronous. */
 int  skred_bank_render_host(skred_bank_t *bank, float *buffer, int num_frames,
                             int num_channels, int interp, float *stems_or_null);

@@ -125,6 +125,8 @@ void skred_bank_destroy(skred_bank_t *b) {
   sk_queue_free(b);
   if (b->d_updates) hipFree(b->d_updates);
   if (b->h_updates) hipHostFree(b->h_updates);
+  if (b->h_quiet) hipHostFree(b->h_quiet);
+  for (int i = 0; i < SK_QUIET_RING; i++) if (b->quiet_ev[i]) hipEventDestroy(b->quiet_ev[i]);
   if (b->ev_updates) hipEventDestroy(b->ev_updates);
   if (b->d_level) hipFree(b->d_level);
   if (b->d_group_flag) hipFree(b->d_group_flag);
@@ -184,6 +186,7 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
   if (dst_first == 0 && count == b->n_voices) { b->features = 0; b->mod_escapes = 0; }   /* whole bank replaced */
   for (int i = 0; i < count; i++) sk_apply_meta(b, dst_first + i, &meta[i]);
   free(meta);
+  sk_control_changed(b);
   return SKRED_OK;
 }
 
@@ -273,7 +276,8 @@ int skred_bank_set_globals(skred_bank_t *b, const skred_globals_t *g) {
   if (!b || !g) return fail(SKRED_E_BAD_ARG, "set_globals");
   HIP_TRY(hipSetDevice(b->device));
   b->g = *g;
-  HIP_TRY(hipMemcpy(b->d_gain_state, &g->volume_smoother_gain, sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_gain_state + b->gain_slot, &g->volume_smoother_gain, sizeof(float), hipMemcpyHostToDevice));
+  sk_control_changed(b);              /* the clock may have moved: envelope stages are a function of it */
   return SKRED_OK;
 }
 
@@ -281,22 +285,34 @@ int skred_bank_get_globals(skred_bank_t *b, skred_globals_t *g) {
   if (!b || !g) return fail(SKRED_E_BAD_ARG, "get_globals");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(&b->g.volume_smoother_gain, b->d_gain_state, sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&b->g.volume_smoother_gain, b->d_gain_state + b->gain_slot, sizeof(float), hipMemcpyDeviceToHost));
   *g = b->g;
   return SKRED_OK;
 }
 
 /* ------------------------------------------------------------------ render */
 
-int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_partial, float *d_stems, void *stream) {
-  if (!b || !d_partial || num_frames <= 0) return fail(SKRED_E_BAD_ARG, "render: bad arguments");
+/* Did the launch whose result sits in quiet ring slot `i` flag any group for sk_render_env2_kernel? */
+static void poll_env_quiet(skred_bank_t *b) {
+  while (b->quiet_pending > 0) {
+    const int i = b->quiet_tail % SK_QUIET_RING;
+    if (hipEventQuery(b->quiet_ev[i]) != hipSuccess) return;         /* that launch has not finished yet */
+    /* the kernel stores its launch ticket into the slot when it defers a group: an older ticket = none deferred;
+     * the answer only holds if no control action reached the bank since that launch was issued */
+    if (b->h_quiet[i] != b->quiet_ticket[i] && b->quiet_epoch[i] == b->control_epoch) b->env_quiet = 1;
+    b->quiet_tail++;
+    b->quiet_pending--;
+  }
+}
+
+/* everything up to the per-workgroup partial rows: picks and launches the render kernels, advances the timeline */
+static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_stems, hipStream_t s, int *n_wg_out) {
   if (interp != SKRED_INTERP_TRUNCATE && interp != SKRED_INTERP_LINEAR) return fail(SKRED_E_BAD_ARG, "render: interp %d", interp);
   if (!b->d_tables) return fail(SKRED_E_BAD_ARG, "render: no table pool set");
   if ((b->features & SKB_ANY_MOD) && b->mod_escapes)
     return fail(SKRED_E_UNSUPPORTED, "a voice is modulated by a voice outside its aligned 64-voice group: "
                                      "keep modulator and carrier in the same group (SURVEY 8e)");
   HIP_TRY(hipSetDevice(b->device));
-  hipStream_t s = (hipStream_t)stream;
   const int modulated = (b->features & SKB_ANY_MOD) != 0;
   int n_wg = modulated ? b->n_padded / 64 : (b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS);
   int rc = grow(&b->d_partial, &b->partial_cap, (size_t)n_wg * (size_t)num_frames * 2);
@@ -330,6 +346,13 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
   if (!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) {
     n_wg = b->n_groups / 2 < SK_MAX_WORKGROUPS ? b->n_groups / 2 : SK_MAX_WORKGROUPS;
   }
+  /* two-per-lane banks with envelopes: sk_render_fast2_kernel hands groups with envelopes in motion to
+   * sk_render_env2_kernel.  Envelope stages only move towards a constant level on their own, so once a launch
+   * has deferred no group, none will be deferred until a control action arrives: the second launch is skipped. */
+  const int two_env = !modulated && (a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
+  if (two_env) poll_env_quiet(b);
+  a.launch_ticket = ++b->launch_ticket;
+  a.skip_env2 = two_env && b->env_quiet;
   HIP_TRY(hipEventRecord(b->ev0[slot], s));
   hipError_t e;
   if (modulated) {
@@ -341,14 +364,51 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "render launch -> %s", hipGetErrorString(e));
   HIP_TRY(hipEventRecord(b->ev1[slot], s));
   b->n_timed++;
-  e = (hipError_t)sk_launch_reduce(b->d_partial, b->d_redtmp, d_partial, n_wg, 2 * num_frames, s);
-  if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "reduce launch -> %s", hipGetErrorString(e));
+  if (two_env && !b->env_quiet && b->quiet_pending < SK_QUIET_RING) {
+    /* ask (asynchronously) whether this launch deferred any group */
+    const int i = b->quiet_head % SK_QUIET_RING;
+    if (!b->h_quiet) HIP_TRY(hipHostMalloc((void **)&b->h_quiet, SK_QUIET_RING * sizeof(uint32_t), hipHostMallocDefault));
+    if (!b->quiet_ev[i]) HIP_TRY(hipEventCreateWithFlags(&b->quiet_ev[i], hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(&b->h_quiet[i], b->d_group_flag + b->n_groups / 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(b->quiet_ev[i], s));
+    b->quiet_ticket[i] = a.launch_ticket;
+    b->quiet_epoch[i] = b->control_epoch;
+    b->quiet_head++;
+    b->quiet_pending++;
+  }
 
   /* advance the timeline exactly as synth.c:521,525 do: one count and one LCG draw per frame */
   b->g.synth_sample_count += (uint64_t)num_frames;
   uint64_t r = b->g.noise_rng;
   for (int i = 0; i < num_frames; i++) r = r * 6364136223846793005ULL + 1442695040888963407ULL;
   b->g.noise_rng = r;
+  *n_wg_out = n_wg;
+  return SKRED_OK;
+}
+
+int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_partial, float *d_stems, void *stream) {
+  if (!b || !d_partial || num_frames <= 0) return fail(SKRED_E_BAD_ARG, "render: bad arguments");
+  int n_wg = 0;
+  const int rc = render_rows(b, num_frames, interp, d_stems, (hipStream_t)stream, &n_wg);
+  if (rc) return rc;
+  const hipError_t e = (hipError_t)sk_launch_reduce(b->d_partial, b->d_redtmp, d_partial, n_wg, 2 * num_frames, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "reduce launch -> %s", hipGetErrorString(e));
+  return SKRED_OK;
+}
+
+int skred_bank_render_mix(skred_bank_t *b, int num_frames, int interp, float *d_out, int num_channels,
+                          float *d_stems, void *stream) {
+  if (!b || !d_out || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "render_mix: bad arguments");
+  int n_wg = 0;
+  const int rc = render_rows(b, num_frames, interp, d_stems, (hipStream_t)stream, &n_wg);
+  if (rc) return rc;
+  /* the carried master gain alternates between two device slots (see sk_reduce_master_kernel) */
+  const hipError_t e = (hipError_t)sk_launch_reduce_master(b->d_partial, b->d_redtmp, n_wg, d_out, num_frames, num_channels,
+                                                           b->g.volume_final, b->g.volume_smoother_smoothing,
+                                                           b->d_gain_state + b->gain_slot, b->d_gain_state + (b->gain_slot ^ 1),
+                                                           (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "reduce+master launch -> %s", hipGetErrorString(e));
+  b->gain_slot ^= 1;
   return SKRED_OK;
 }
 
@@ -356,7 +416,7 @@ int skred_bank_master(skred_bank_t *b, const float *d_sum, int num_frames, int n
   if (!b || !d_sum || !d_out || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "master: bad arguments");
   HIP_TRY(hipSetDevice(b->device));
   hipError_t e = (hipError_t)sk_launch_master(d_sum, d_out, num_frames, num_channels, b->g.volume_final,
-                                              b->g.volume_smoother_smoothing, b->d_gain_state, (hipStream_t)stream);
+                                              b->g.volume_smoother_smoothing, b->d_gain_state + b->gain_slot, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "master launch -> %s", hipGetErrorString(e));
   return SKRED_OK;
 }
@@ -365,13 +425,11 @@ int skred_bank_render_host(skred_bank_t *b, float *buffer, int num_frames, int n
   if (!b || !buffer || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "render_host: bad arguments");
   HIP_TRY(hipSetDevice(b->device));
   int rc;
-  if ((rc = grow(&b->d_sum, &b->sum_cap, (size_t)num_frames * 2))) return rc;
   if ((rc = grow(&b->d_out, &b->out_cap, (size_t)num_frames * (size_t)num_channels))) return rc;
   const size_t stem_floats = (size_t)num_frames * (size_t)b->n_voices * 2;
   if (stems && (rc = grow(&b->d_stems, &b->stems_cap, stem_floats))) return rc;
   if (num_channels > 2) HIP_TRY(hipMemsetAsync(b->d_out, 0, (size_t)num_frames * num_channels * sizeof(float), NULL));
-  if ((rc = skred_bank_render(b, num_frames, interp, b->d_sum, stems ? b->d_stems : NULL, NULL))) return rc;
-  if ((rc = skred_bank_master(b, b->d_sum, num_frames, num_channels, b->d_out, NULL))) return rc;
+  if ((rc = skred_bank_render_mix(b, num_frames, interp, b->d_out, num_channels, stems ? b->d_stems : NULL, NULL))) return rc;
   HIP_TRY(hipMemcpy(buffer, b->d_out, (size_t)num_frames * num_channels * sizeof(float), hipMemcpyDeviceToHost));
   if (stems) HIP_TRY(hipMemcpy(stems, b->d_stems, stem_floats * sizeof(float), hipMemcpyDeviceToHost));
   return SKRED_OK;

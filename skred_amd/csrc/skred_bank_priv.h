@@ -15,6 +15,7 @@
 #include "skred_launch.h"
 
 #define SK_TIMING_RING 256
+#define SK_QUIET_RING 8
 #define SK_FAST2_MIN_VOICES 131072   /* banks at least this large use two voices per lane (measured crossover) */
 
 struct skred_bank {
@@ -27,7 +28,8 @@ struct skred_bank {
   size_t table_floats_padded; /* rounded up to 4      */
   float *d_partial;           /* [n_wg][F][2]         */
   size_t partial_cap;         /* floats               */
-  float *d_gain_state;        /* master smoother gain */
+  float *d_gain_state;        /* master smoother gain: two slots, gain_slot is the current one */
+  int gain_slot;
   float *d_redtmp;            /* second-stage scratch of the partial-mix reduction */
   size_t redtmp_cap;
   float *d_sum, *d_out, *d_stems; /* scratch of skred_bank_render_host */
@@ -50,6 +52,14 @@ struct skred_bank {
   uint32_t features;
   hipEvent_t ev0[SK_TIMING_RING], ev1[SK_TIMING_RING]; /* around the render kernel of each call */
   int n_timed;                /* render calls since the last timing reset */
+  /* "no group has an envelope in motion" (see render_rows): asynchronous read-back ring of the kernel's answer */
+  uint32_t launch_ticket;     /* one per render launch */
+  uint32_t control_epoch;     /* bumped by every upload / update / globals change */
+  int env_quiet;              /* the last answered launch deferred no group and nothing changed since */
+  uint32_t *h_quiet;          /* pinned: SK_QUIET_RING tickets read back from d_group_flag[n_groups/2] */
+  hipEvent_t quiet_ev[SK_QUIET_RING];
+  uint32_t quiet_ticket[SK_QUIET_RING], quiet_epoch[SK_QUIET_RING];
+  int quiet_head, quiet_tail, quiet_pending;
   struct sk_queue_item *queue;  /* deferred updates (skred_bank_update.c), singly linked in arrival order */
   struct sk_queue_item *queue_tail;
   int queue_len;
@@ -90,5 +100,7 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
                   sk_plane_t ro[SKP_COUNT], sk_plane_t rw[SKS_COUNT], sk_voice_meta_t *meta);
 void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *meta);
 void sk_queue_free(skred_bank_t *b);
+/* a control action reached the bank: what earlier launches reported about envelope activity no longer holds */
+static inline void sk_control_changed(skred_bank_t *b) { b->control_epoch++; b->env_quiet = 0; }
 
 #endif

@@ -209,6 +209,7 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
     start = end;
   }
   if (meta) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i]);
+  sk_control_changed(b);
   return SKRED_OK;
 }
 

@@ -114,7 +114,8 @@ typedef struct {
   const float *tables;     /* HBM pool */
   float *partial;          /* [n_workgroups][num_frames][2] pre-master partial sums */
   float *stems;            /* [num_frames][n_voices][2] or NULL */
-  int32_t *group_flag;     /* [n_groups/2]: 1 = this 512-voice group has envelopes in motion (fast2 -> env2 hand-over) */
+  int32_t *group_flag;     /* [n_groups/2]: 1 = this 512-voice group has envelopes in motion (fast2 -> env2 hand-over);
+                              [n_groups/2] (one more): ticket of the last launch that deferred any group */
   uint64_t count0;         /* synth_sample_count before the first frame */
   uint64_t rng0;           /* noise LCG state before the first frame */
   int32_t n_voices;        /* real voices (stems indexing) */
@@ -125,6 +126,8 @@ typedef struct {
   int32_t interp;
   uint32_t features;       /* SKB_* */
   uint32_t fast_mode;      /* SKM_* : which specialised kernel the host picked */
+  uint32_t launch_ticket;  /* this launch's number (see group_flag) */
+  uint32_t skip_env2;      /* host knows no group can be deferred: sk_render_env2_kernel is not launched */
 } sk_render_args_t;
 
 #endif

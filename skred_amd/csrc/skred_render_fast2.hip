@@ -544,7 +544,10 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST2_MIN_WAVES) void sk_render_fast2_
         if (!dead[c] && code == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;                   // synth.c:429
       }
       const int group_ok = __syncthreads_and(ok ? 1 : 0);
-      if (tid == 0) a.group_flag[g] = group_ok ? 0 : 1;
+      if (tid == 0) {
+        a.group_flag[g] = group_ok ? 0 : 1;
+        if (!group_ok) a.group_flag[n_groups2] = (int32_t)a.launch_ticket;   // "this launch deferred something"
+      }
       if (!group_ok) continue;                          // sk_render_env2_kernel renders this group
     }
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
@@ -663,7 +666,8 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
     hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I>), grid, block, lds_bytes, stream, *args);    \
-    if (E) hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I>), grid, block, lds_bytes, stream, *args); \
+    if (E && !args->skip_env2)                                                                          \
+      hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I>), grid, block, lds_bytes, stream, *args);      \
     break;
   switch (key) {
     SK_FAST2_CASE(0, false, false, false, 0) SK_FAST2_CASE(1, false, false, false, 1)

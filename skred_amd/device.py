@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "skred_bank_create", "skred_bank_destroy", "skred_bank_n_voices",
     "skred_bank_set_tables_f32", "skred_bank_upload", "skred_bank_download",
     "skred_bank_set_globals", "skred_bank_get_globals",
-    "skred_bank_render", "skred_bank_master", "skred_bank_render_host",
+    "skred_bank_render", "skred_bank_master", "skred_bank_render_mix", "skred_bank_render_host",
     "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
     "skred_bank_set_option", "skred_bank_last_kernel",
     "skred_bank_update", "skred_bank_defer", "skred_bank_run_queue", "skred_bank_queue_pending",
@@ -64,6 +64,7 @@ def load() -> C.CDLL:
     L.skred_bank_get_globals.argtypes = [vp, C.POINTER(GlobalsC)]
     L.skred_bank_render.argtypes = [vp, i32, i32, vp, vp, vp]
     L.skred_bank_master.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.skred_bank_render_mix.argtypes = [vp, i32, i32, vp, i32, vp, vp]
     L.skred_bank_render_host.argtypes = [vp, vp, i32, i32, i32, vp]
     L.skred_bank_last_render_ms.argtypes = [vp]
     L.skred_bank_last_render_ms.restype = C.c_float
@@ -134,6 +135,11 @@ class DeviceBank:
         """Asynchronous render into device pointers (ints), e.g. torch tensor .data_ptr()."""
         _check(self.L.skred_bank_render(self.h, frames, interp, d_partial, d_stems or None, stream or None),
                "skred_bank_render")
+
+    def render_mix(self, frames: int, d_out: int, channels: int = 2, d_stems: int = 0, interp: int = 0, stream: int = 0):
+        """Single-GPU render + master with the last reduction stage fused into the master kernel."""
+        _check(self.L.skred_bank_render_mix(self.h, frames, interp, d_out, channels, d_stems, stream),
+               "skred_bank_render_mix")
 
     def master(self, d_sum: int, frames: int, d_out: int, channels: int = 2, stream: int = 0):
         _check(self.L.skred_bank_master(self.h, d_sum, frames, channels, d_out, stream or None), "skred_bank_master")

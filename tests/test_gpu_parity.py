@@ -143,6 +143,32 @@ def test_mix_is_linear_in_voices(dev):
     assert rel_rms(parts, whole) <= 1e-5
 
 
+def test_fused_mix_equals_render_plus_master(dev):
+    """skred_bank_render_mix (last reduction stage fused into the master kernel) against skred_bank_render +
+    skred_bank_master on the same bank: same samples, bit for bit, for small and large workgroup counts."""
+    import torch
+    for n, frames in ((300, 77), (40000, 512), (300000, 1500)):
+        bank, tables, g = banks.bank_c2(n)
+        outs = []
+        for fused in (False, True):
+            db = dev.DeviceBank(n)
+            db.set_tables(tables)
+            db.upload(bank)
+            db.set_globals(g)
+            out = torch.zeros(frames, 2, device="cuda")
+            part = torch.zeros(frames, 2, device="cuda")
+            for _ in range(2):
+                if fused:
+                    db.render_mix(frames, out.data_ptr(), 2)
+                else:
+                    db.render(frames, part.data_ptr())
+                    db.master(part.data_ptr(), frames, out.data_ptr(), 2)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy())
+            db.close()
+        assert gio.bits_equal(outs[0], outs[1]), (n, frames)
+
+
 def test_determinism(dev):
     """No atomics, fixed reduction order: two runs give identical bytes."""
     bank, tables, g = banks.bank_c2(10000)

@@ -236,6 +236,42 @@ def test_stamped_note_off_survives_a_later_parameter_update(dev):
     assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
 
 
+def test_quiet_two_per_lane_bank_wakes_up_on_control(dev):
+    """Two-per-lane kernels: once a launch has deferred no group to sk_render_env2_kernel the host stops launching
+    it; a stamped trigger / release (or any other control action) must bring it back for the very next block."""
+    D = dev
+    n = 4096
+    bank, tables, g = banks.bank_c2(n)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    db.fast2_min_voices(0)
+    mirror, truth, gl = bank.copy(), bank.copy(), g.copy()
+    mixes, refs = [], []
+    plan = {30: (np.arange(5, n, 97, dtype=np.int32), D.STAMP_RELEASE),
+            34: (np.arange(9, n, 211, dtype=np.int32), D.STAMP_TRIGGER | D.DIRTY_PHASE),
+            60: (np.arange(2, n, 301, dtype=np.int32), D.STAMP_RELEASE)}
+    for k in range(70):                                  # 0.11 s of attack/decay, then long quiet stretches
+        if k in plan:
+            vs, dirty = plan[k]
+            if dirty & D.DIRTY_PHASE:
+                mirror["voice_phase"][vs] = 0.0
+                mirror["voice_finished"][vs] = 0
+            db.update(mirror, vs, dirty)
+            apply_captured(truth, mirror, vs, dirty, gl.synth_sample_count, D)
+        m, _ = db.render_host(F, 2, 0)
+        assert db.last_kernel() == 3
+        mixes.append(m)
+        r = cpuref.render(truth, gl, tables, F, 0)
+        refs.append(cpuref.master(gl, r["sum64"].astype(np.float32)))
+    got = bank.copy()
+    db.download(got)
+    db.close()
+    assert not got.rw_equal(truth), got.rw_equal(truth)
+    assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
+
+
 def test_update_argument_checks(dev):
     n = 256
     bank, tables, g = banks.bank_c1(n)

@@ -125,6 +125,11 @@ def pmc_traffic(workload, voices, frames):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result: libraries that chat on fd 1 (RCCL prints a version banner
+    # when the first communicator is created) are sent to stderr for the whole run
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -138,6 +143,9 @@ def main():
     ap.add_argument("--no-low-latency", action="store_true", help="skip the secondary F=64 measurement")
     ap.add_argument("--no-recipe-warmup", action="store_true",
                     help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="with one process: still create a (1-rank) process group and run the N>1 code path through it "
+                         "(exercises the RCCL calls on a single-GPU box)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N>1: wait for each launch's reduce before rendering the next block (default: double-buffered, "
                          "reduce k overlaps render k+1)")
@@ -168,8 +176,12 @@ def main():
     local = local % ndev                       # gloo rehearsal: ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or a.rehearse_dist       # the N>1 code path (collectives, barrier, max-over-ranks timing)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -179,7 +191,7 @@ def main():
     if a.voices:
         bank_voices = a.voices
     total = bank_voices * world if a.scaling == "weak" else bank_voices
-    sh = ShardedRender(total, rank, world)
+    sh = ShardedRender(total, rank, world, always_reduce=a.rehearse_dist)
     F = a.frames
 
     # seeded banks: weak scaling gives every rank its own bank of the workload size (seed + rank);
@@ -202,7 +214,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -216,7 +228,7 @@ def main():
         def master(p, o):
             db.master(p.data_ptr(), frames, o.data_ptr(), 2, stream)
 
-        if world > 1 and a.backend == "gloo":     # rehearsal only: reduce through host memory
+        if use_dist and a.backend == "gloo":     # rehearsal only: reduce through host memory
             host = torch.zeros(frames, 2, dtype=torch.float32)
             dev_render = render_partial
 
@@ -234,7 +246,7 @@ def main():
             red = host
         else:
             red = partial
-        if world > 1 and not a.no_overlap:
+        if use_dist and not a.no_overlap:
             # double-buffered: the reduce of block k (RCCL, its own stream) overlaps the render of block k+1;
             # every block is still rendered, reduced and mastered inside the region it is counted in (drain)
             sh.begin([red, torch.zeros_like(red)])
@@ -243,7 +255,7 @@ def main():
                 for _ in range(n):
                     sh.step_overlapped(render_partial, master, out)
                 sh.drain(master, out)                       # leaves the pair of buffers in place
-        elif world > 1:
+        elif use_dist:
             def run(n):
                 for _ in range(n):
                     sh.step(render_partial, master, red, out)   # render -> RCCL reduce -> master on rank 0
@@ -258,7 +270,7 @@ def main():
         run(steps)
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -327,9 +339,9 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(recipe, interp)
-        print(json.dumps(res), flush=True)
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
     db.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -36,8 +36,9 @@ def modulation_components_ok(bank, lo: int, hi: int) -> bool:
 
 
 class ShardedRender:
-    def __init__(self, total_voices: int, rank: int = 0, world: int = 1, root: int = 0):
+    def __init__(self, total_voices: int, rank: int = 0, world: int = 1, root: int = 0, always_reduce: bool = False):
         self.total, self.rank, self.world, self.root = total_voices, rank, world, root
+        self.reduce = world > 1 or always_reduce        # always_reduce: rehearse the collective with one rank
         self.lo, self.hi = partition(total_voices, world, rank)
         self._bufs: Optional[Sequence[torch.Tensor]] = None
         self._work: List[Optional[object]] = [None, None]
@@ -52,7 +53,7 @@ class ShardedRender:
              partial: torch.Tensor, out: torch.Tensor) -> None:
         """One pass of the hot path: local render -> (sum over ranks) -> master on the root."""
         render_partial(partial)
-        if self.world > 1:
+        if self.reduce:
             dist.reduce(partial, dst=self.root, op=dist.ReduceOp.SUM)
         if self.rank == self.root:
             master(partial, out)
@@ -84,7 +85,7 @@ class ShardedRender:
             self._work[i].wait()
             self._work[i] = None
         render_partial(self._bufs[i])
-        if self.world > 1:
+        if self.reduce:
             self._work[i] = dist.reduce(self._bufs[i], dst=self.root, op=dist.ReduceOp.SUM, async_op=True)
         delivered = self._k > 0
         if delivered:

@@ -79,6 +79,7 @@ def main():
             r["state_out"] = bank_out.rw_equal(gio.expected_out_bank(seg))
             r["count_out_equal"] = bool(ref.globals().synth_sample_count == seg.g_out.synth_sample_count)
             self.k += 1
+            return mix, stems
 
         def extra(self, name, value):
             # case-specific data: what the replay produced (decoded tables, slot fields, the recorder's

@@ -187,6 +187,7 @@ class Case:
                                       "mix_rms": float(np.sqrt((mix.astype(np.float64) ** 2).mean())),
                                       "mix_peak": float(np.abs(mix).max())})
         self.k += 1
+        return mix, stems
 
     def extra(self, name, value):
         """Case-specific data next to the segments (input files, expected files); `x_` prefix in the npz."""
@@ -524,6 +525,45 @@ def case_wav_samples(ref, Case):
     c.save()
 
 
+def bank256_lines(part):
+    """The 64 voice lines of part `part` (0..3) of the bank256_sum case: same tables per voice index in every part
+    (so that all four snapshots share one table pool), everything else different."""
+    lines = []
+    for i in range(64):
+        n = part * 64 + i
+        f = 55.0 * 2.0 ** (n / 40.0)
+        pan = -0.95 + 1.9 * ((n * 37) % 256) / 255.0
+        k = 200.0 + 30.0 * i + 500.0 * part
+        lines.append(f"v{i} w{[0, 4, 1][i % 3]} f{f:.5f} a{0.5 + 0.01 * i:.2f} p{pan:.4f} "
+                     f"J{1 + (n % 4)} K{k:.2f} Q{0.6 + 0.05 * (n % 9):.2f} t0.01,0.1,0.7,0.2 l{0.5 + 0.125 * (n % 5):.3f}")
+    return lines
+
+
+def case_bank256_sum(ref, Case):
+    """N > 64 pinned to the reference itself (SURVEY 8c "N > 64"): the reference renders four different 64-voice
+    banks, one after the other; a build that renders all 256 voices at once must produce, per voice, the same
+    stems, and as its pre-master sum the sum of the four runs' stems (accumulated here in f64)."""
+    c = Case("bank256_sum", "4 x 64 voices (sine/triangle/square, biquad modes 1-4, ADSR in attack/decay): per-part "
+                            "fixtures + the f64 sum of all 256 voices' stems over the same 1024 frames")
+    frames = 1024
+    total = np.zeros((frames, 2), np.float64)
+    h = hashlib.sha256()
+    parts = []
+    for part in range(4):
+        for ln in bank256_lines(part):
+            ref.wire(ln)
+        r = c.segment(ref, frames, 512, note=f"voices {part * 64}..{part * 64 + 63} of the 256-voice bank")
+        if r is None:
+            return                                   # control-path replay stops at the first segment
+        _, stems = r
+        total += stems.astype(np.float64).sum(axis=1)
+        parts.append(stems)
+    all_stems = np.ascontiguousarray(np.concatenate(parts, axis=1))          # [F][256][2]
+    c.extra("sum64", total)
+    c.extra("stems256_sha256", np.frombuffer(hashlib.sha256(all_stems.tobytes()).digest(), np.uint8))
+    c.save()
+
+
 CASES = {
     "c0_0sk": case_c0_0sk,
     "c1_sine_adsr64": case_c1_sine_adsr,
@@ -533,6 +573,7 @@ CASES = {
     "edge_basic": case_edge_basic,
     "edge_mod": case_edge_mod,
     "wav_samples": case_wav_samples,
+    "bank256_sum": case_bank256_sum,
 }
 
 

@@ -13,10 +13,10 @@ from skred_amd.bank import RW_FIELDS, GlobalsC, VoiceBank, globals_from_json
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["c0_0sk", "c1_sine_adsr64", "c2_mixed_filter64", "c2_notamy64", "c4_pcm_oneshot",
-         "edge_basic", "edge_mod", "wav_samples"]
+         "edge_basic", "edge_mod", "wav_samples", "bank256_sum"]
 # cases whose voices are independent (no FM/AM/pan/CZ modulators)
 MOD_FREE_CASES = ["c1_sine_adsr64", "c2_mixed_filter64", "c2_notamy64", "c4_pcm_oneshot", "edge_basic",
-                  "wav_samples"]
+                  "wav_samples", "bank256_sum"]
 
 
 @dataclass
@@ -77,3 +77,27 @@ def bits_equal(a: np.ndarray, b: np.ndarray) -> bool:
     a = np.ascontiguousarray(a, np.float32)
     b = np.ascontiguousarray(b, np.float32)
     return a.shape == b.shape and bool((a.view(np.uint32) == b.view(np.uint32)).all())
+
+
+def bank256_from_parts(g: "Golden"):
+    """The 256-voice bank of the bank256_sum case: its four 64-voice snapshots side by side on ONE time base (the
+    reference rendered them one after the other, so part k's envelope clocks are shifted back by count_k - count_0).
+    Returns (bank, globals at count_0)."""
+    segs = g.segments
+    n = sum(s.bank_in.n for s in segs)
+    b = VoiceBank(n)
+    for name in segs[0].bank_in.a:
+        b.a[name] = np.ascontiguousarray(np.concatenate([s.bank_in.a[name] for s in segs]))
+    c0 = segs[0].g_in.synth_sample_count
+    e = b.a["voice_amp_envelope"]
+    p = 0
+    for s in segs:
+        shift = s.g_in.synth_sample_count - c0
+        sl = slice(p, p + s.bank_in.n)
+        for f in ("sample_start", "sample_release"):
+            v = e[f][sl]
+            e[f][sl] = np.where(v != 0, v - np.uint64(shift), v)
+        p += s.bank_in.n
+    gl = segs[0].g_in
+    return b, GlobalsC(gl.synth_sample_count, gl.noise_rng, gl.volume_final, gl.volume_smoother_gain,
+                       gl.volume_smoother_smoothing, 0.0)

@@ -143,6 +143,34 @@ def test_mix_is_linear_in_voices(dev):
     assert rel_rms(parts, whole) <= 1e-5
 
 
+def test_256_voices_against_four_reference_runs(dev):
+    """N > 64 pinned to the reference itself: the 256-voice bank in one launch against the reference's four 64-voice
+    runs -- per-voice stems bit for bit (generic kernel), and the pre-master sum of the specialised kernel against
+    the f64 sum of the reference's stems."""
+    import hashlib
+    import torch
+    g = gio.load("bank256_sum")
+    bank, gl = gio.bank256_from_parts(g)
+    frames = g.segments[0].frames
+    db = dev.DeviceBank(bank.n)
+    db.set_tables(g.tables)
+    db.upload(bank)
+    db.set_globals(gl)
+    _, stems = db.render_host(frames, 2, 0, want_stems=True)
+    sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(stems).tobytes()).digest(), np.uint8)
+    assert (sha == g.extras["stems256_sha256"]).all()
+    for fast2 in (False, True):
+        db.upload(bank)
+        db.set_globals(gl)
+        db.fast2_min_voices(0 if fast2 else 1 << 30)
+        part = torch.zeros(frames, 2, device="cuda")
+        db.render(frames, part.data_ptr())
+        torch.cuda.synchronize()
+        assert db.last_kernel() == (3 if fast2 else 1)
+        assert rel_rms(part.cpu().numpy(), g.extras["sum64"]) <= 1e-5
+    db.close()
+
+
 def test_fused_mix_equals_render_plus_master(dev):
     """skred_bank_render_mix (last reduction stage fused into the master kernel) against skred_bank_render +
     skred_bank_master on the same bank: same samples, bit for bit, for small and large workgroup counts."""

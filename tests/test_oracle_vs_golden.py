@@ -61,3 +61,16 @@ def test_f64_sum_close_to_f32_sum():
     r = cpuref.render(seg.bank_in.copy(), seg.g_in.copy(), g.tables, 1024)
     err = np.sqrt(np.mean((r["sum32"].astype(np.float64) - r["sum64"]) ** 2))
     assert err < 1e-5
+
+
+def test_oracle_at_256_voices_against_four_reference_runs():
+    """N > 64 pinned to the reference: the oracle renders the 256-voice bank in one go; per voice it must
+    reproduce the reference's stems of the four 64-voice runs bit for bit, hence (f64) their sum."""
+    import hashlib
+    g = gio.load("bank256_sum")
+    bank, gl = gio.bank256_from_parts(g)
+    r = cpuref.render(bank, gl, g.tables, g.segments[0].frames, 0, want_stems=True)
+    sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(r["stems"]).tobytes()).digest(), np.uint8)
+    assert (sha == g.extras["stems256_sha256"]).all()
+    want = g.extras["sum64"]
+    assert np.abs(r["sum64"] - want).max() <= 1e-12 * max(1.0, np.abs(want).max())

@@ -58,7 +58,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   if (!b) return fail(SKRED_E_NO_MEM, "calloc");
   b->device = device;
   b->n_voices = n_voices;
-  b->n_groups = ((n_voices + 2 * SK_GROUP - 1) / (2 * SK_GROUP)) * 2;   /* even: the two-per-lane kernel takes 512 voices per pass */
+  b->n_groups = ((n_voices + 4 * SK_GROUP - 1) / (4 * SK_GROUP)) * 4;   /* multiple of 4: the two-per-lane kernel takes up to 1024 voices per pass */
   b->fast2_min_voices = SK_FAST2_MIN_VOICES;
   b->n_padded = b->n_groups * SK_GROUP;
   const size_t plane_bytes = (size_t)b->n_padded * sizeof(sk_plane_t);
@@ -344,7 +344,9 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
 
   const int slot = b->n_timed % SK_TIMING_RING;
   if (!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) {
-    n_wg = b->n_groups / 2 < SK_MAX_WORKGROUPS ? b->n_groups / 2 : SK_MAX_WORKGROUPS;
+    /* passes of sk_render_fast2_kernel: 1024 voices each for LDS-table banks, 512 otherwise (skred_render_fast2.hip) */
+    const int passes = a.lds_table_floats > 0 ? b->n_groups / 4 : b->n_groups / 2;
+    n_wg = passes < SK_MAX_WORKGROUPS ? passes : SK_MAX_WORKGROUPS;
   }
   /* two-per-lane banks with envelopes: sk_render_fast2_kernel hands groups with envelopes in motion to
    * sk_render_env2_kernel.  Envelope stages only move towards a constant level on their own, so once a launch

@@ -397,22 +397,20 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
   if (tid < 2 * cn) {                                                           \
     const float *w_ = reinterpret_cast<const float *>(wsum);                    \
     float s_ = w_[0 * 2 * SK_CHUNK + tid];                                      \
-    s_ += w_[1 * 2 * SK_CHUNK + tid];                                           \
-    s_ += w_[2 * 2 * SK_CHUNK + tid];                                           \
-    s_ += w_[3 * 2 * SK_CHUNK + tid];                                           \
+    _Pragma("unroll") for (int w2_ = 1; w2_ < NW; ++w2_) s_ += w_[w2_ * 2 * SK_CHUNK + tid]; \
     float *p_ = a.partial + part_base + (size_t)c0 * 2 + tid;                   \
     if (ACCUM_) *p_ += s_; else *p_ = s_;                                       \
   }                                                                             \
   __syncthreads();
 
-// load the two voices of this lane for workgroup pass g; returns whether the wave is tame
+// load the two voices of this lane (vbase + lane, vbase + 64 + lane); returns whether the wave is tame
 template <bool FILTER, bool ENV>
-__device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int g, int wave, int lane, Fast2Regs &r,
+__device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase, int lane, Fast2Regs &r,
                                            Env2Regs &e, bool dead[2], bool silent[2], bool released[2],
                                            uint64_t t_start[2], uint64_t t_release[2], int vidx[2]) {
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    const int v = g * (2 * SK_GROUP) + wave * 128 + c * 64 + lane;
+    const int v = vbase + c * 64 + lane;            // vbase: first voice of this wave's 128-voice slice
     vidx[c] = v;
     const uint4 osc = *reinterpret_cast<const uint4 *>(&a.ro[SKP_OSC][v]);
     const uint4 tab = *reinterpret_cast<const uint4 *>(&a.ro[SKP_TAB][v]);
@@ -493,43 +491,52 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
   }
 }
 
+// NW (a constexpr in scope): wavefronts per workgroup = 128-voice slices per workgroup pass
 #define SK_FAST2_PROLOGUE()                                                                          \
   extern __shared__ float lds[];                                                                     \
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));               \
   const char *lds_tab = reinterpret_cast<const char *>(lds);                                         \
   const char *glb_tab = reinterpret_cast<const char *>(a.tables);                                    \
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                     \
-  float2 *xp = wsum + 4 * SK_CHUNK + wave * (8 * 65 + 64);   /* wave-private: tile [8][65] then xq [64] */ \
+  float2 *xp = wsum + NW * SK_CHUNK + wave * (8 * 65 + 64);  /* wave-private: tile [8][65] then xq [64] */ \
   float2 *xq = xp + 8 * 65;                                                                          \
   /* global-table banks: the same LDS holds the wave's table windows instead (2 voices x SK_WIN x 64 lanes) */ \
-  float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (2 * SK_WIN * 64);            \
+  float *win = reinterpret_cast<float *>(wsum + NW * SK_CHUNK) + wave * (2 * SK_WIN * 64);           \
   (void)xp; (void)xq; (void)win;                                                                     \
   if (TAB_LDS) {                                                                                     \
     const int n4 = a.lds_table_floats >> 2;                                                          \
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);                                 \
     float4 *dst4 = reinterpret_cast<float4 *>(lds);                                                  \
-    for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];                                      \
+    for (int i = tid; i < n4; i += NW * 64) dst4[i] = src4[i];                                       \
     __syncthreads();                                                                                 \
   }                                                                                                  \
   const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;                            \
-  const int n_groups2 = a.n_groups >> 1;   /* 512 voices per workgroup pass (host pads to 512) */
+  const int n_groups2 = a.n_groups >> 1;   /* 512-voice groups: the unit of the fast2 -> env2 hand-over */ \
+  const int n_pass = (a.n_groups * SK_GROUP) / (NW * 128);   /* workgroup passes over the (padded) bank */
 
 #ifndef SK_FAST2_MIN_WAVES
 #define SK_FAST2_MIN_WAVES 4     /* <= 128 VGPRs */
 #endif
 
 // Constant-level groups.  ENV: the bank uses envelopes, so every group is classified first.
+// Workgroup shape: LDS-table banks run 8 wavefronts per workgroup (1024 voices per pass) so that two workgroups --
+// 16 waves, 4 per SIMD -- share a CU's LDS with ONE copy of the tables each (four per SIMD needs <= 40 KB per
+// 256-thread workgroup otherwise, and tables + tiles take ~46 KB); global-table banks keep 4 (their table windows
+// scale with the wave count).
+template <bool TAB_LDS> struct Fast2Shape { static constexpr int NW = TAB_LDS ? 8 : 4; };
+
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
-__global__ __launch_bounds__(SK_GROUP, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
+__global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
+  constexpr int NW = Fast2Shape<TAB_LDS>::NW;
   SK_FAST2_PROLOGUE()
   bool first_pass = true;
-  for (int g = blockIdx.x; g < n_groups2; g += gridDim.x) {
+  for (int g = blockIdx.x; g < n_pass; g += gridDim.x) {
     Fast2Regs r;
     Env2Regs e;
     bool dead[2], silent[2], released[2];
     uint64_t t_start[2], t_release[2];
     int vidx[2];
-    const bool tame = fast2_load<FILTER, ENV>(a, g, wave, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    const bool tame = fast2_load<FILTER, ENV>(a, g * (NW * 128) + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
     if (ENV) {
       // constant envelope level on the first frame of the launch <=> for the whole launch (absorbing codes)
       bool ok = true;
@@ -545,7 +552,8 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST2_MIN_WAVES) void sk_render_fast2_
       }
       const int group_ok = __syncthreads_and(ok ? 1 : 0);
       if (tid == 0) {
-        a.group_flag[g] = group_ok ? 0 : 1;
+#pragma unroll
+        for (int j = 0; j < NW / 4; ++j) a.group_flag[g * (NW / 4) + j] = group_ok ? 0 : 1;   // per 512-voice group
         if (!group_ok) a.group_flag[n_groups2] = (int32_t)a.launch_ticket;   // "this launch deferred something"
       }
       if (!group_ok) continue;                          // sk_render_env2_kernel renders this group
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST2_MIN_WAVES) void sk_render_fast2_
     first_pass = false;
   }
   if (first_pass) {   // every group of this workgroup was deferred: its partial-mix row must still exist
-    for (int i = tid; i < 2 * a.num_frames; i += SK_GROUP) a.partial[part_base + i] = 0.0f;
+    for (int i = tid; i < 2 * a.num_frames; i += NW * 64) a.partial[part_base + i] = 0.0f;
   }
 }
 
@@ -569,7 +577,9 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST2_MIN_WAVES) void sk_render_fast2_
 #endif
 template <bool TAB_LDS, bool FILTER, int INTERP>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
+  constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
   SK_FAST2_PROLOGUE()
+  (void)n_pass;
   for (int g = blockIdx.x; g < n_groups2; g += gridDim.x) {
     if (a.group_flag[g] == 0) continue;
     Fast2Regs r;
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
     bool dead[2], silent[2], released[2];
     uint64_t t_start[2], t_release[2];
     int vidx[2];
-    const bool tame = fast2_load<FILTER, true>(a, g, wave, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    const bool tame = fast2_load<FILTER, true>(a, g * 512 + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
     bool all_const_from_here = false;
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
@@ -658,16 +668,23 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
 extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
                                       hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
-  // per wave: the transposition tile + row sums (LDS-table banks) or the table windows (global-table banks)
-  lds_bytes += tab_lds ? (size_t)4 * (8 * 65 + 64) * sizeof(float2) : (size_t)4 * (2 * SK_WIN * 64) * sizeof(float);
-  dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
+  (void)lds_bytes;
+  // LDS: [tables] + wsum[NW][SK_CHUNK] + per wave the transposition tile and row sums (LDS-table banks) or the table
+  // windows (global-table banks).  n_workgroups = partial rows = passes of sk_render_fast2_kernel; the env2 kernel
+  // (4 waves per workgroup) walks its 512-voice groups with the same grid and adds into the same rows.
+  const size_t tab_bytes = (size_t)(tab_lds ? args->lds_table_floats : 0) * sizeof(float);
+  const size_t per_wave = tab_lds ? (size_t)(8 * 65 + 64) * sizeof(float2) : (size_t)(2 * SK_WIN * 64) * sizeof(float);
+  const int nw = tab_lds ? Fast2Shape<true>::NW : Fast2Shape<false>::NW;
+  const size_t lds_fast2 = tab_bytes + (size_t)nw * (SK_CHUNK * sizeof(float2) + per_wave);
+  const size_t lds_env2 = tab_bytes + (size_t)4 * (SK_CHUNK * sizeof(float2) + per_wave);
+  dim3 grid((unsigned)n_workgroups), block((unsigned)nw * 64), block_env(SK_GROUP);
   const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
-    hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I>), grid, block, lds_bytes, stream, *args);    \
+    hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I>), grid, block, lds_fast2, stream, *args);    \
     if (E && !args->skip_env2)                                                                          \
-      hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I>), grid, block, lds_bytes, stream, *args);      \
+      hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I>), grid, block_env, lds_env2, stream, *args);   \
     break;
   switch (key) {
     SK_FAST2_CASE(0, false, false, false, 0) SK_FAST2_CASE(1, false, false, false, 1)

@@ -131,11 +131,13 @@ __device__ __forceinline__ float fast2_env_general(Fast2Regs &r, Env2Regs &e, in
 // EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
 // with the short exact division; 2 general.  TAME: see fast_frame.
 // Oscillator half of a frame: advance both phases, wrap, fetch the two table samples.
-template <bool TAB_LDS, bool TAME, int INTERP>
+// LOZ: every lane of the wave has lo == 0 (no loop window: the plain LUT case).  Then ph0 - lo == ph0 and
+// lo + y == y exactly, so the wrapped phase lo + ((ph0 - lo) - span) is ph0 - span: one packed add instead of three.
+template <bool TAB_LDS, bool TAME, int INTERP, bool LOZ = false>
 __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, const char *__restrict__ glb_tab) {
   const v2f ph0 = r.phase + r.inc;
-  const v2f x = ph0 - r.lo;
-  const v2f phw = r.lo + (x - r.span);
+  const v2f x = LOZ ? ph0 : ph0 - r.lo;
+  const v2f phw = LOZ ? x - r.span : r.lo + (x - r.span);
   v2f ph;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -326,16 +328,16 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#define SK_FAST2_LDS_BLOCK(J, EM_)                                                                       \
+#define SK_FAST2_LDS_BLOCK_Z(J, EM_, LOZ_)                                                                       \
   {                                                                                                      \
     /* software pipeline: the table gather of the NEXT frame is issued before the biquad/gain chain of the   \
        current one (the source order matters: the compiler may not move an LDS read above the tile write) */  \
-    v2f s0_ = fast2_osc<TAB_LDS, true, INTERP>(r, lds_tab, glb_tab);                                      \
+    v2f s0_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                                      \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
-      const v2f s1_ = fast2_osc<TAB_LDS, true, INTERP>(r, lds_tab, glb_tab);                              \
+      const v2f s1_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                              \
       fast2_post<FILTER, EM_, true>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
-      if (q_ < 6) s0_ = fast2_osc<TAB_LDS, true, INTERP>(r, lds_tab, glb_tab);                            \
+      if (q_ < 6) s0_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                            \
       fast2_post<FILTER, EM_, true>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
       xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
       xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
@@ -355,6 +357,9 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
     }                                                                                                    \
     SK_WAVE_SYNC()                                                                                       \
   }
+// `loz` (wave-uniform, set once per pass): see fast2_osc
+#define SK_FAST2_LDS_BLOCK(J, EM_)                                                                       \
+  { if (loz) SK_FAST2_LDS_BLOCK_Z(J, EM_, true) else SK_FAST2_LDS_BLOCK_Z(J, EM_, false) }
 // Eight frames (J..J+7) of a tame wave of a global-table bank through the table windows; DPP pair reductions.
 #define SK_FAST2_WIN_BLOCK(J, EM_)                                                                       \
   {                                                                                                      \
@@ -537,6 +542,8 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     uint64_t t_start[2], t_release[2];
     int vidx[2];
     const bool tame = fast2_load<FILTER, ENV>(a, g * (NW * 128) + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
+    (void)loz;
     if (ENV) {
       // constant envelope level on the first frame of the launch <=> for the whole launch (absorbing codes)
       bool ok = true;
@@ -588,6 +595,8 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
     uint64_t t_start[2], t_release[2];
     int vidx[2];
     const bool tame = fast2_load<FILTER, true>(a, g * 512 + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
+    (void)loz;
     bool all_const_from_here = false;
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);

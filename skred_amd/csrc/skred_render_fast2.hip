@@ -29,7 +29,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 struct Fast2Regs {
   v2f inc, lo, hi, span, span2;
   int toff4[2], tsize_m1[2];
-  v2f k, b0, b1, b2, a1, a2, pan_l, pan_r, gain_const;   // gain_const: gain of a constant-level lane
+  v2f k, b0, b1, b2, a1, a2, gain_const;   // gain_const: gain of a constant-level lane
+  v2f pan_lr[2];                           // (pan_left, pan_right) of voice 0 / voice 1: packed by channel, not by voice
   v2f phase, sgain, x1, x2, y1, y2, sample;
   uint32_t rw[2];
 };
@@ -208,10 +209,12 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
     so.x = silent0 ? 0.0f : s.x;
     so.y = silent1 ? 0.0f : s.y;
   }
-  const v2f l2 = so * r.pan_l;
-  const v2f r2 = so * r.pan_r;
-  out_l = l2.x + l2.y;
-  out_r = r2.x + r2.y;
+  // (L, R) of the lane's two voices with the pan gains packed by channel: two packed multiplies by a broadcast
+  // sample and one packed add give (out_l, out_r) ready for the tile store -- the same products and the same
+  // single add per channel as l = s0*pl0 + s1*pl1, r = s0*pr0 + s1*pr1
+  const v2f lr = r.pan_lr[0] * (v2f){so.x, so.x} + r.pan_lr[1] * (v2f){so.y, so.y};
+  out_l = lr.x;
+  out_r = lr.y;
 }
 
 template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP>
@@ -434,7 +437,7 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase,
     r.x1[c] = __uint_as_float(s0.z);    r.x2[c] = __uint_as_float(s0.w);
     r.y1[c] = __uint_as_float(s1.x);    r.y2[c] = __uint_as_float(s1.y);
     r.sample[c] = __uint_as_float(s1.z); r.rw[c] = s1.w;
-    r.pan_l[c] = __uint_as_float(s2.z); r.pan_r[c] = __uint_as_float(s2.w);
+    r.pan_lr[c].x = __uint_as_float(s2.z); r.pan_lr[c].y = __uint_as_float(s2.w);
     r.b2[c] = 0.0f; r.a1[c] = 0.0f; r.a2[c] = 0.0f;
     if (FILTER) {
       const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
@@ -463,7 +466,7 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase,
       r.k[c] = 0.0f; r.sgain[c] = 0.0f; e.ampv[c] = 0.0f; r.gain_const[c] = 0.0f;
       r.b0[c] = r.b1[c] = r.b2[c] = r.a1[c] = r.a2[c] = 0.0f;
       r.x1[c] = r.x2[c] = r.y1[c] = r.y2[c] = 0.0f;
-      r.pan_l[c] = r.pan_r[c] = 0.0f; r.rw[c] &= ~SKR_ENV_ACTIVE;
+      r.pan_lr[c] = (v2f){0.0f, 0.0f}; r.rw[c] &= ~SKR_ENV_ACTIVE;
     }
   }
   r.span = r.hi - r.lo;

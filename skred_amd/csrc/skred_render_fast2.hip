@@ -163,7 +163,8 @@ __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, cons
 
 // The rest of the frame: biquad, envelope/gain, smoother, pan, lane-local sum of the two voices.
 // EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
-// with the short exact division; 2 general.  TAME: see fast_frame.
+// with the short exact division; 2 general; 3 constant gain AND the amp smoother has stalled in every lane
+// (fast2_smoother_stalled: its update no longer changes it, so it is skipped).  TAME: see fast_frame.
 template <bool FILTER, int EM, bool TAME>
 __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
                                            const bool rel0, const bool rel1, const bool silent0,
@@ -181,7 +182,7 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
   }
   // ---- gain ----
   v2f gain;
-  if (EM == 0) {
+  if (EM == 0 || EM == 3) {
     gain = r.gain_const;
   } else if (EM == 1) {
     e.clk = e.clk + 1.0f;                              // exact: clocks stay below 2^24 in this mode
@@ -200,7 +201,7 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
     gain.x = fast2_env_general(r, e, 0, rel0);
     gain.y = fast2_env_general(r, e, 1, rel1);
   }
-  r.sgain = r.sgain + r.k * (gain - r.sgain);
+  if (EM != 3) r.sgain = r.sgain + r.k * (gain - r.sgain);
   s = s * r.sgain;
   r.sample = s;
   // ---- pan, lane-local sum of the two voices ----
@@ -215,6 +216,15 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
   const v2f lr = r.pan_lr[0] * (v2f){so.x, so.x} + r.pan_lr[1] * (v2f){so.y, so.y};
   out_l = lr.x;
   out_r = lr.y;
+}
+
+// The one-pole amp smoother g += k*(gain - g) (synth.c:588-593) towards a CONSTANT gain stops moving after a
+// few hundred frames: once k*(gain - g) is below half an ulp of g the sum rounds back to g, and with the same
+// inputs it does so on every later frame.  Wave-uniform test of exactly that (the very expression fast2_post
+// evaluates, compared bitwise), made once per 64-frame chunk of a constant-gain wave.
+__device__ __forceinline__ bool fast2_smoother_stalled(const Fast2Regs &r) {
+  const v2f nxt = r.sgain + r.k * (r.gain_const - r.sgain);
+  return __all(__float_as_uint(nxt.x) == __float_as_uint(r.sgain.x) && __float_as_uint(nxt.y) == __float_as_uint(r.sgain.y));
 }
 
 template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP>
@@ -382,7 +392,8 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
 #define SK_FAST2_CHUNK(EM_)                                                     \
   {                                                                             \
     int j = 0;                                                                  \
-    if (tame) { if (TAB_LDS) for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK(j, EM_) \
+    if (tame) { if (TAB_LDS) { if ((EM_) == 0 && fast2_smoother_stalled(r)) for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK(j, (EM_) == 0 ? 3 : (EM_)) \
+                               else for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK(j, EM_) } \
                 else for (; j + 8 <= cn; j += 8) SK_FAST2_WIN_BLOCK(j, EM_)     \
                 for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, true)          \
                 if (j < cn) SK_FAST2_ONE(j, EM_, true) }                        \

@@ -410,7 +410,10 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
                 if (j < cn) SK_FAST2_ONE(j, EM_, false) }                       \
   }
 #endif
-// wave sums of the chunk -> this workgroup's partial-mix row (ACCUM_: add to what is there)
+// wave sums of the chunk -> this workgroup's partial-mix row (ACCUM_: add to what is there).  wsum is double
+// buffered: the waves go on writing the next chunk into the other half while the first 2*cn threads drain this
+// one, so one barrier per chunk is enough (a wave can only reach the half being drained after the NEXT barrier,
+// which the draining threads reach after their reads).
 #define SK_FAST2_FLUSH(ACCUM_)                                                   \
   __syncthreads();                                                              \
   if (tid < 2 * cn) {                                                           \
@@ -420,7 +423,7 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
     float *p_ = a.partial + part_base + (size_t)c0 * 2 + tid;                   \
     if (ACCUM_) *p_ += s_; else *p_ = s_;                                       \
   }                                                                             \
-  __syncthreads();
+  wsum = (wsum == wsum0) ? wsum0 + NW * SK_CHUNK : wsum0;
 
 // load the two voices of this lane (vbase + lane, vbase + 64 + lane); returns whether the wave is tame
 template <bool FILTER, bool ENV>
@@ -513,14 +516,15 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
 // NW (a constexpr in scope): wavefronts per workgroup = 128-voice slices per workgroup pass
 #define SK_FAST2_PROLOGUE()                                                                          \
   extern __shared__ float lds[];                                                                     \
-  float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));               \
+  float2 *const wsum0 = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));        \
+  float2 *wsum = wsum0;                      /* [2][NW][SK_CHUNK]: see SK_FAST2_FLUSH */              \
   const char *lds_tab = reinterpret_cast<const char *>(lds);                                         \
   const char *glb_tab = reinterpret_cast<const char *>(a.tables);                                    \
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                     \
-  float2 *xp = wsum + NW * SK_CHUNK + wave * (8 * 65 + 64);  /* wave-private: tile [8][65] then xq [64] */ \
+  float2 *xp = wsum0 + 2 * NW * SK_CHUNK + wave * (8 * 65 + 64);  /* wave-private: tile [8][65] then xq [64] */ \
   float2 *xq = xp + 8 * 65;                                                                          \
   /* global-table banks: the same LDS holds the wave's table windows instead (2 voices x SK_WIN x 64 lanes) */ \
-  float *win = reinterpret_cast<float *>(wsum + NW * SK_CHUNK) + wave * (2 * SK_WIN * 64);           \
+  float *win = reinterpret_cast<float *>(wsum0 + 2 * NW * SK_CHUNK) + wave * (2 * SK_WIN * 64);      \
   (void)xp; (void)xq; (void)win;                                                                     \
   if (TAB_LDS) {                                                                                     \
     const int n4 = a.lds_table_floats >> 2;                                                          \
@@ -692,14 +696,14 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
                                       hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
   (void)lds_bytes;
-  // LDS: [tables] + wsum[NW][SK_CHUNK] + per wave the transposition tile and row sums (LDS-table banks) or the table
+  // LDS: [tables] + wsum[2][NW][SK_CHUNK] + per wave the transposition tile and row sums (LDS-table banks) or the table
   // windows (global-table banks).  n_workgroups = partial rows = passes of sk_render_fast2_kernel; the env2 kernel
   // (4 waves per workgroup) walks its 512-voice groups with the same grid and adds into the same rows.
   const size_t tab_bytes = (size_t)(tab_lds ? args->lds_table_floats : 0) * sizeof(float);
   const size_t per_wave = tab_lds ? (size_t)(8 * 65 + 64) * sizeof(float2) : (size_t)(2 * SK_WIN * 64) * sizeof(float);
   const int nw = tab_lds ? Fast2Shape<true>::NW : Fast2Shape<false>::NW;
-  const size_t lds_fast2 = tab_bytes + (size_t)nw * (SK_CHUNK * sizeof(float2) + per_wave);
-  const size_t lds_env2 = tab_bytes + (size_t)4 * (SK_CHUNK * sizeof(float2) + per_wave);
+  const size_t lds_fast2 = tab_bytes + (size_t)nw * (2 * SK_CHUNK * sizeof(float2) + per_wave);
+  const size_t lds_env2 = tab_bytes + (size_t)4 * (2 * SK_CHUNK * sizeof(float2) + per_wave);
   dim3 grid((unsigned)n_workgroups), block((unsigned)nw * 64), block_env(SK_GROUP);
   const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);

@@ -45,6 +45,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process.  PyTorch bundles its own libamdhip64 and asks for it by the unversioned name,
+    # which the loader does not match against an already loaded /opt/rocm copy (same SONAME, different request):
+    # if this library came first, torch would bring a second runtime that finds no GPU.  Loading torch first makes
+    # this library resolve its libamdhip64.so.7 to the copy torch loaded.  (C hosts link one runtime and never see this.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise SkredAmdError(f"{LIB_PATH} is missing: build it with `make -C skred_amd/csrc` "
                             "(there is no CPU fallback for the render path)")

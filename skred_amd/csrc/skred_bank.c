@@ -229,7 +229,7 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
   if (!b) return fail(SKRED_E_BAD_ARG, "set_option");
   switch (option) {
     case SKRED_OPT_FORCE_GENERIC: b->force_generic = value != 0; return SKRED_OK;
-    case SKRED_OPT_FAST2_MIN_VOICES: b->fast2_min_voices = value; return SKRED_OK;
+    case SKRED_OPT_FAST2_MIN_VOICES: b->fast2_min_voices = value; b->fast2_min_user = 1; return SKRED_OK;
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
 }
@@ -337,7 +337,11 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   a.features = b->features;
   classify(b);
   a.fast_mode = (b->force_generic || d_stems) ? 0u : b->fast_mode;
-  if ((a.fast_mode & SKM_FAST) && b->n_voices >= b->fast2_min_voices) a.fast_mode |= SKM_TWO_PER_LANE;
+  /* two voices per lane pay off for large LDS-table banks (packed fp32); banks whose tables stay in L2 / HBM do
+   * better with one voice per lane at every size measured (2^16 .. 2^20: twice the waves to hide the window
+   * refills behind) unless the caller set the threshold explicitly */
+  if ((a.fast_mode & SKM_FAST) && b->n_voices >= b->fast2_min_voices && (a.lds_table_floats > 0 || b->fast2_min_user))
+    a.fast_mode |= SKM_TWO_PER_LANE;
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
   if ((rc = grow(&b->d_redtmp, &b->redtmp_cap, (size_t)sk_reduce_tmp_floats(2 * num_frames)))) return rc;

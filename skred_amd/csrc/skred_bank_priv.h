@@ -47,6 +47,7 @@ struct skred_bank {
   uint32_t fast_mode;         /* SKM_* from classify() */
   int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
   int fast2_min_voices;       /* SKRED_OPT_FAST2_MIN_VOICES */
+  int fast2_min_user;         /* ... was set by the caller (then it also applies to global-table banks) */
   int last_kernel;            /* SKRED_KERNEL_* used by the most recent render */
   skred_globals_t g;
   uint32_t features;

@@ -65,11 +65,9 @@ __device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__r
 // caller has set r.tf / r.trf to this frame's envelope clocks.
 // TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
 // by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
-template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP>
-__device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
-                                           const bool released, const char *lds_tab,
-                                           const char *__restrict__ glb_tab, float &out_l, float &out_r) {
-  // ---- oscillator (osc_next, synth.c:217-275) ----
+// Oscillator half of a frame (osc_next, synth.c:217-275): advance and wrap the phase.
+template <bool TAME>
+__device__ __forceinline__ float fast_advance(FastRegs &r) {
   const float ph0 = r.phase + r.inc;
   const float x = ph0 - r.lo;
   const bool over = ph0 >= r.hi;
@@ -83,7 +81,13 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     if (!(in_range || simple)) ph = slow_wrap(ph0, r.lo, r.hi, r.span);
   }
   r.phase = ph;
-  float s = fast_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r, ph);
+  return ph;
+}
+
+// The rest of the frame: biquad, envelope / gain, smoother, pan.
+template <bool FILTER, bool ENV, bool STEADY>
+__device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float &xo, float &yn, float &yo,
+                                          const bool released, float &out_l, float &out_r) {
   // ---- biquad (mmf_process, synth.c:349-364) ----
   if (FILTER) {
     // xn/yn: newest delay-line entries, xo/yo: the older ones.  The new values overwrite the OLD
@@ -131,6 +135,67 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
   out_r = s * r.pan_r;
 }
 
+// One voice, one frame.  STEADY: every lane of the wave sits in its sustain stage.  When !STEADY the
+// caller has set r.tf / r.trf to this frame's envelope clocks.
+// TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
+// by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
+template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP>
+__device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
+                                           const bool released, const char *lds_tab,
+                                           const char *__restrict__ glb_tab, float &out_l, float &out_r) {
+  const float ph = fast_advance<TAME>(r);
+  const float s = fast_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r, ph);
+  fast_post<FILTER, ENV, STEADY>(r, s, xn, xo, yn, yo, released, out_l, out_r);
+}
+
+// ---- table windows for pools that do not fit in LDS (see skred_render_fast2.hip for the reasoning) ----
+// One voice per lane: every 8 frames the lane copies the SK_WIN table samples its voice is about to cross into
+// win[row][lane]; a voice that could wrap, fold its second tap or outrun the window in this block takes the
+// ordinary gather.  Used for PCM banks too small to fill the machine with two voices per lane.
+typedef float fwin4_t __attribute__((ext_vector_type(4), aligned(4)));
+
+struct FastWin {
+  int base;
+  bool direct, any_direct;
+};
+
+__device__ __forceinline__ void fast_win_fill(const FastRegs &r, bool dead, FastWin &w, float *win, int lane,
+                                              const char *__restrict__ glb_tab) {
+  const float d8 = 8.0f * r.inc;
+  const bool fits = d8 <= (float)(SK_WIN - 3) + 0.5f && r.phase + d8 + 2.0f < r.hi;
+  w.direct = !dead && !fits;
+  w.base = (int)r.phase;
+  if (!w.direct) {
+    const char *src = glb_tab + (r.toff4 + (w.base << 2));
+    float *dst = win + lane;
+#pragma unroll
+    for (int k = 0; k < SK_WIN / 4; ++k) {
+      const fwin4_t t = *reinterpret_cast<const fwin4_t *>(src + 16 * k);
+      dst[(4 * k + 0) * 64] = t.x; dst[(4 * k + 1) * 64] = t.y;
+      dst[(4 * k + 2) * 64] = t.z; dst[(4 * k + 3) * 64] = t.w;
+    }
+  }
+  w.any_direct = __any(w.direct);
+}
+
+template <int INTERP>
+__device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin &w, const float *win, int lane,
+                                                const char *__restrict__ glb_tab, float p) {
+  const int idx = (int)p;
+  const int rel = w.direct ? 0 : idx - w.base;
+  const float *src = win + rel * 64 + lane;
+  const float ta = src[0];
+  float s = ta;
+  if (INTERP != 0) {
+    const float tb = src[64];
+    s = ta + (p - (float)idx) * (tb - ta);
+  }
+  if (w.any_direct) {
+    if (w.direct) s = fast_fetch<false, INTERP, true>(nullptr, glb_tab, r, p);
+  }
+  return s;
+}
+
 // one frame of the chunk loop: STEADY_ selects the envelope mode, A/B the delay-line roles
 #define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO)                                                        \
   {                                                                                                      \
@@ -148,16 +213,33 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
+// eight steady frames of a tame wave of a global-table bank through the table window
+#define SK_FAST_WIN_BLOCK(J)                                                                             \
+  {                                                                                                      \
+    FastWin w_;                                                                                          \
+    fast_win_fill(r, dead, w_, win, lane, glb_tab);                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      float l0, r0, l1, r1;                                                                              \
+      const float s0_ = fast_fetch_win<INTERP>(r, w_, win, lane, glb_tab, fast_advance<true>(r));         \
+      fast_post<FILTER, ENV, true>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);                    \
+      const float s1_ = fast_fetch_win<INTERP>(r, w_, win, lane, glb_tab, fast_advance<true>(r));         \
+      fast_post<FILTER, ENV, true>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);                    \
+      { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
+    }                                                                                                    \
+  }
 #define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2)
 #define SK_FAST_ODD(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1)
 #define SK_FAST_FIX_ODD_TAIL()                                                     \
   { float t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }
 
+#ifndef SK_FAST_WIN_MIN_WAVES
+#define SK_FAST_WIN_MIN_WAVES 4  /* global-table banks: the window refill wants ~20 more registers (6: 12 B of scratch) */
+#endif
 #ifndef SK_FAST_MIN_WAVES
 #define SK_FAST_MIN_WAVES 6      /* waves per SIMD the register allocator must leave room for */
 #endif
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
-__global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
+__global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
   const char *lds_tab = reinterpret_cast<const char *>(lds);
@@ -166,6 +248,8 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_ke
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (SK_WIN * 64);   // global-table banks only
+  (void)win;
 
   if (TAB_LDS) {
     const int n4 = a.lds_table_floats >> 2;           // padded to a multiple of 4 by the host
@@ -257,6 +341,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_ke
       }
       if ((!ENV || steady) && tame) {
         int j = 0;
+        if (!TAB_LDS) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j)
         for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (!ENV || steady) {
@@ -315,6 +400,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_FAST_MIN_WAVES) void sk_render_fast_ke
 extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
                                      hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
+  if (!tab_lds) lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);   // one table window per wave
   dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
   const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);

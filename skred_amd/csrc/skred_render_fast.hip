@@ -85,7 +85,8 @@ __device__ __forceinline__ float fast_advance(FastRegs &r) {
 }
 
 // The rest of the frame: biquad, envelope / gain, smoother, pan.
-template <bool FILTER, bool ENV, bool STEADY>
+// STALL (steady waves only): the smoother no longer moves in any lane (fast_smoother_stalled) and is skipped.
+template <bool FILTER, bool ENV, bool STEADY, bool STALL = false>
 __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float &xo, float &yn, float &yo,
                                           const bool released, float &out_l, float &out_r) {
   // ---- biquad (mmf_process, synth.c:349-364) ----
@@ -128,11 +129,20 @@ __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float
     gain = r.amp * (e * r.vel);
   }
   // ---- smoother + apply (synth.c:589-593), pan (synth.c:603-604) ----
-  r.sgain += r.k * (gain - r.sgain);
+  if (!STALL) r.sgain += r.k * (gain - r.sgain);
   s *= r.sgain;
   r.sample = s;
   out_l = s * r.pan_l;
   out_r = s * r.pan_r;
+}
+
+// A one-pole smoother towards a constant gain stops moving once k*(gain - g) rounds away (see
+// skred_render_fast2.hip: fast2_smoother_stalled); wave-uniform, tested on the expression fast_post evaluates.
+template <bool ENV>
+__device__ __forceinline__ bool fast_smoother_stalled(const FastRegs &r) {
+  const float gain = ENV ? r.gain_sustain : r.amp;
+  const float nxt = r.sgain + r.k * (gain - r.sgain);
+  return __all(__float_as_uint(nxt) == __float_as_uint(r.sgain));
 }
 
 // One voice, one frame.  STEADY: every lane of the wave sits in its sustain stage.  When !STEADY the
@@ -214,16 +224,16 @@ __device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
 // eight steady frames of a tame wave of a global-table bank through the table window
-#define SK_FAST_WIN_BLOCK(J)                                                                             \
+#define SK_FAST_WIN_BLOCK(J, STALL_)                                                                     \
   {                                                                                                      \
     FastWin w_;                                                                                          \
     fast_win_fill(r, dead, w_, win, lane, glb_tab);                                                      \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP>(r, w_, win, lane, glb_tab, fast_advance<true>(r));         \
-      fast_post<FILTER, ENV, true>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);                    \
+      fast_post<FILTER, ENV, true, STALL_>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);            \
       const float s1_ = fast_fetch_win<INTERP>(r, w_, win, lane, glb_tab, fast_advance<true>(r));         \
-      fast_post<FILTER, ENV, true>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);                    \
+      fast_post<FILTER, ENV, true, STALL_>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
       { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
     }                                                                                                    \
   }
@@ -341,7 +351,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       }
       if ((!ENV || steady) && tame) {
         int j = 0;
-        if (!TAB_LDS) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j)
+        if (!TAB_LDS) {
+          if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
+          else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
+        }
         for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (!ENV || steady) {

@@ -440,21 +440,23 @@ def test_table_window_edges(dev, interp, fast2):
     assert rel_rms(fast_mix, ref_mix) <= 1e-5
 
 
-def test_stalled_smoother_is_skipped_exactly(dev):
-    """Held notes: after ~1000 frames of constant gain the one-pole amp smoother stops moving and the two-per-lane
-    kernel stops evaluating it (per 64-frame chunk, when every voice of the wave has stalled).  State and samples
+@pytest.mark.parametrize("recipe,interp,fast2", [("c2", 0, True), ("c4", 1, False)])
+def test_stalled_smoother_is_skipped_exactly(dev, recipe, interp, fast2):
+    """Held notes: after ~1000 frames of constant gain the one-pole amp smoother stops moving and the specialised
+    kernels (two-per-lane LDS blocks; one-per-lane table-window blocks) stop evaluating it (per 64-frame chunk, when
+    every voice of the wave has stalled).  State and samples
     must stay those of the oracle through the stall, through an amplitude change that un-stalls it, and through the
     tail of released notes decaying to zero gain."""
     n = 4096
-    bank, tables, g = banks.bank_c2(n)
+    bank, tables, g = banks.RECIPES[recipe](n)
 
     def louder(host, now):
         host["voice_amp"][::3] *= np.float32(1.5)
 
     segs = [(6400, None), (512, None), (640, louder), (2048, None), (512, _release_odd_voices), (16000, None), (512, None)]
-    mix, state, k = _run_scenario(dev, bank, tables, g, 0, segs, force_generic=False, fast2=True)
-    ref_mix, ref_state = _oracle_scenario(bank, tables, g, 0, segs)
-    assert k == [3] * len(segs), k
+    mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False, fast2=fast2)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert k == [3 if fast2 else 1] * len(segs), k
     assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
     assert rel_rms(mix, ref_mix) <= 1e-5
 

@@ -143,6 +143,11 @@ def main():
     ap.add_argument("--no-low-latency", action="store_true", help="skip the secondary F=64 measurement")
     ap.add_argument("--no-recipe-warmup", action="store_true",
                     help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="bracket the render kernels of every n-th launch with HIP events (kernel duration for the roofline)")
+    ap.add_argument("--no-tail-overlap", action="store_true",
+                    help="one GPU: keep every block's reduction + master stage on the render stream instead of overlapping "
+                         "them with the next block's render (SKRED_OPT_OVERLAP_TAIL)")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="with one process: still create a (1-rank) process group and run the N>1 code path through it "
                          "(exercises the RCCL calls on a single-GPU box)")
@@ -209,6 +214,11 @@ def main():
     db.set_globals(g)
     if a.fast2_min_voices >= 0:
         db.fast2_min_voices(a.fast2_min_voices)
+    # the render kernels of every 8th launch are bracketed by an event pair (roofline.kernel_ms_*): a pair costs ~6 us
+    # of stream time, so bracketing every launch would tax the very throughput being measured
+    db.kernel_timing(max(1, min(a.time_every, a.steps)))
+    if world == 1 and not a.rehearse_dist and not a.no_tail_overlap:
+        db.overlap_tail(True)          # block k's reduction + master overlap block k+1's render (all inside the timed region)
 
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -263,6 +273,7 @@ def main():
             def run(n):                                         # one GPU: render + (last reduction stage fused with) master
                 for _ in range(n):
                     db.render_mix(frames, out.data_ptr(), 2, 0, interp, stream)
+                db.wait_mix(stream)                             # the last block's tail joins the stream before the fence
         run(warmup)
         fence()
         db.timing_reset()

@@ -206,6 +206,12 @@ int  skred_bank_master(skred_bank_t *bank, const float *d_sum, int num_frames,
 int  skred_bank_render_mix(skred_bank_t *bank, int num_frames, int interp, float *d_out, int num_channels,
                            float *d_stems_or_null, void *stream);
 
+/* With SKRED_OPT_OVERLAP_TAIL set, skred_bank_render_mix returns with the block's last two kernels queued on an
+ * internal stream: block k+1 (which needs block k's voice state, not its mix) renders while block k's rows are
+ * reduced and scaled -- the way an audio pipeline consumes block k while k+1 is computed.  Before `d_out` of the
+ * most recent block is read on `stream` (or by the host after synchronising `stream`), make it wait: */
+int  skred_bank_wait_mix(skred_bank_t *bank, void *stream);
+
 /* Whole synth() contract on host buffers: render + master + D2H (+ stems). Synchronous. */
 int  skred_bank_render_host(skred_bank_t *bank, float *buffer, int num_frames,
                             int num_channels, int interp, float *stems_or_null);
@@ -261,7 +267,12 @@ int  skred_bank_queue_pending(const skred_bank_t *bank);
 /* Options.  Two kernels implement the render loop: a generic one (every synth() feature the path
  * supports) and a specialised one chosen automatically for "clean" banks; their per-voice results are
  * bit-identical.  FORCE_GENERIC pins the generic kernel (used by the parity tests to cross-check). */
-enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size from which the two-voices-per-lane kernel is used */ };
+enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size from which the two-voices-per-lane kernel is used */,
+       SKRED_OPT_KERNEL_TIMING = 4 /* n: an event pair brackets the render kernels of every n-th launch (default 1: every
+                                      launch; 0: none).  skred_bank_last_render_ms / _timing_summary report the bracketed
+                                      launches; an event pair costs ~6 us of stream time on an MI355X, hence the knob */,
+       SKRED_OPT_OVERLAP_TAIL = 3 /* skred_bank_render_mix: run the block's reduction + master stage on an internal
+                                     stream so that the next block's render overlaps it (see skred_bank_wait_mix) */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */

@@ -60,6 +60,8 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   b->n_voices = n_voices;
   b->n_groups = ((n_voices + 4 * SK_GROUP - 1) / (4 * SK_GROUP)) * 4;   /* multiple of 4: the two-per-lane kernel takes up to 1024 voices per pass */
   b->fast2_min_voices = SK_FAST2_MIN_VOICES;
+  b->last_tail = -1;
+  b->timing_every = 1;
   b->n_padded = b->n_groups * SK_GROUP;
   const size_t plane_bytes = (size_t)b->n_padded * sizeof(sk_plane_t);
   for (int p = 0; p < SKP_COUNT; p++) {
@@ -115,7 +117,12 @@ void skred_bank_destroy(skred_bank_t *b) {
   for (int p = 0; p < SKP_COUNT; p++) if (b->d_ro[p]) hipFree(b->d_ro[p]);
   for (int p = 0; p < SKS_COUNT; p++) if (b->d_rw[p]) hipFree(b->d_rw[p]);
   if (b->d_tables) hipFree(b->d_tables);
-  if (b->d_partial) hipFree(b->d_partial);
+  for (int i = 0; i < 2; i++) {
+    if (b->d_partial_buf[i]) hipFree(b->d_partial_buf[i]);
+    if (b->ev_rows[i]) hipEventDestroy(b->ev_rows[i]);
+    if (b->ev_tail[i]) hipEventDestroy(b->ev_tail[i]);
+  }
+  if (b->aux) hipStreamDestroy(b->aux);
   if (b->d_gain_state) hipFree(b->d_gain_state);
   if (b->d_sum) hipFree(b->d_sum);
   if (b->d_out) hipFree(b->d_out);
@@ -230,6 +237,11 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
   switch (option) {
     case SKRED_OPT_FORCE_GENERIC: b->force_generic = value != 0; return SKRED_OK;
     case SKRED_OPT_FAST2_MIN_VOICES: b->fast2_min_voices = value; b->fast2_min_user = 1; return SKRED_OK;
+    case SKRED_OPT_KERNEL_TIMING: b->timing_every = value < 0 ? 0 : value; return SKRED_OK;
+    case SKRED_OPT_OVERLAP_TAIL:
+      if (hipSetDevice(b->device) == hipSuccess) (void)hipDeviceSynchronize();   /* no tail in flight across the switch */
+      b->overlap_tail = value != 0;
+      return SKRED_OK;
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
 }
@@ -315,8 +327,15 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   HIP_TRY(hipSetDevice(b->device));
   const int modulated = (b->features & SKB_ANY_MOD) != 0;
   int n_wg = modulated ? b->n_padded / 64 : (b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS);
-  int rc = grow(&b->d_partial, &b->partial_cap, (size_t)n_wg * (size_t)num_frames * 2);
+  /* partial rows: alternate between two buffers (only the overlapped tail needs it; harmless otherwise) */
+  const int slot = b->partial_slot;
+  int rc = grow(&b->d_partial_buf[slot], &b->partial_buf_cap[slot], (size_t)n_wg * (size_t)num_frames * 2);
   if (rc) return rc;
+  b->d_partial = b->d_partial_buf[slot];
+  if (b->tail_pending[slot]) {            /* the tail of two blocks ago may still be reading this buffer */
+    HIP_TRY(hipStreamWaitEvent(s, b->ev_tail[slot], 0));
+    b->tail_pending[slot] = 0;
+  }
 
   sk_render_args_t a;
   memset(&a, 0, sizeof(a));
@@ -346,7 +365,7 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
   if ((rc = grow(&b->d_redtmp, &b->redtmp_cap, (size_t)sk_reduce_tmp_floats(2 * num_frames)))) return rc;
 
-  const int slot = b->n_timed % SK_TIMING_RING;
+  const int tslot = b->n_timed % SK_TIMING_RING;
   if (!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) {
     /* passes of sk_render_fast2_kernel: 1024 voices each for LDS-table banks, 512 otherwise (skred_render_fast2.hip) */
     const int passes = a.lds_table_floats > 0 ? b->n_groups / 4 : b->n_groups / 2;
@@ -359,7 +378,8 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   if (two_env) poll_env_quiet(b);
   a.launch_ticket = ++b->launch_ticket;
   a.skip_env2 = two_env && b->env_quiet;
-  HIP_TRY(hipEventRecord(b->ev0[slot], s));
+  const int timed = b->timing_every > 0 && (b->launch_ticket % (uint32_t)b->timing_every) == 0;
+  if (timed) HIP_TRY(hipEventRecord(b->ev0[tslot], s));
   hipError_t e;
   if (modulated) {
     b->last_kernel = SKRED_KERNEL_MODULATED;
@@ -368,8 +388,10 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
     e = (hipError_t)sk_launch_render(&a, n_wg, s);
   }
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "render launch -> %s", hipGetErrorString(e));
-  HIP_TRY(hipEventRecord(b->ev1[slot], s));
-  b->n_timed++;
+  if (timed) {
+    HIP_TRY(hipEventRecord(b->ev1[tslot], s));
+    b->n_timed++;
+  }
   if (two_env && !b->env_quiet && b->quiet_pending < SK_QUIET_RING) {
     /* ask (asynchronously) whether this launch deferred any group */
     const int i = b->quiet_head % SK_QUIET_RING;
@@ -397,6 +419,8 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
   int n_wg = 0;
   const int rc = render_rows(b, num_frames, interp, d_stems, (hipStream_t)stream, &n_wg);
   if (rc) return rc;
+  if (b->last_tail >= 0 && b->tail_pending[b->last_tail])      /* an overlapped tail may still use the reduction scratch */
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, b->ev_tail[b->last_tail], 0));
   const hipError_t e = (hipError_t)sk_launch_reduce(b->d_partial, b->d_redtmp, d_partial, n_wg, 2 * num_frames, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "reduce launch -> %s", hipGetErrorString(e));
   return SKRED_OK;
@@ -405,16 +429,45 @@ int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_part
 int skred_bank_render_mix(skred_bank_t *b, int num_frames, int interp, float *d_out, int num_channels,
                           float *d_stems, void *stream) {
   if (!b || !d_out || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "render_mix: bad arguments");
+  hipStream_t s = (hipStream_t)stream, tail = s;
   int n_wg = 0;
-  const int rc = render_rows(b, num_frames, interp, d_stems, (hipStream_t)stream, &n_wg);
+  const int rc = render_rows(b, num_frames, interp, d_stems, s, &n_wg);
   if (rc) return rc;
+  const int slot = b->partial_slot;
+  if (b->overlap_tail) {
+    /* the tail only depends on this block's rows: hand it to the auxiliary stream so that the next block's
+     * render (which depends on this block's voice state, not on its mix) starts right behind this one */
+    if (!b->aux) HIP_TRY(hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      if (!b->ev_rows[i]) HIP_TRY(hipEventCreateWithFlags(&b->ev_rows[i], hipEventDisableTiming));
+      if (!b->ev_tail[i]) HIP_TRY(hipEventCreateWithFlags(&b->ev_tail[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(b->ev_rows[slot], s));
+    HIP_TRY(hipStreamWaitEvent(b->aux, b->ev_rows[slot], 0));
+    tail = b->aux;
+  }
   /* the carried master gain alternates between two device slots (see sk_reduce_master_kernel) */
   const hipError_t e = (hipError_t)sk_launch_reduce_master(b->d_partial, b->d_redtmp, n_wg, d_out, num_frames, num_channels,
                                                            b->g.volume_final, b->g.volume_smoother_smoothing,
                                                            b->d_gain_state + b->gain_slot, b->d_gain_state + (b->gain_slot ^ 1),
-                                                           (hipStream_t)stream);
+                                                           tail);
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "reduce+master launch -> %s", hipGetErrorString(e));
   b->gain_slot ^= 1;
+  if (b->overlap_tail) {
+    HIP_TRY(hipEventRecord(b->ev_tail[slot], b->aux));
+    b->tail_pending[slot] = 1;
+    b->last_tail = slot;
+    b->partial_slot ^= 1;
+  }
+  return SKRED_OK;
+}
+
+int skred_bank_wait_mix(skred_bank_t *b, void *stream) {
+  if (!b) return fail(SKRED_E_BAD_ARG, "wait_mix");
+  if (b->overlap_tail && b->last_tail >= 0 && b->ev_tail[b->last_tail]) {
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, b->ev_tail[b->last_tail], 0));
+  }
   return SKRED_OK;
 }
 

@@ -26,7 +26,16 @@ struct skred_bank {
   float *d_tables;
   size_t table_floats;        /* real pool size       */
   size_t table_floats_padded; /* rounded up to 4      */
-  float *d_partial;           /* [n_wg][F][2]         */
+  float *d_partial;           /* [n_wg][F][2]: the rows the current launch writes (one of d_partial_buf) */
+  float *d_partial_buf[2];    /* two row buffers: with SKRED_OPT_OVERLAP_TAIL block k+1 renders while block k's rows are reduced */
+  size_t partial_buf_cap[2];
+  int partial_slot;
+  int overlap_tail;           /* SKRED_OPT_OVERLAP_TAIL */
+  int timing_every;           /* SKRED_OPT_KERNEL_TIMING: bracket every n-th launch's render kernels with an event pair (0: none) */
+  hipStream_t aux;            /* the tail (reduction + master) of skred_bank_render_mix runs here when overlapping */
+  hipEvent_t ev_rows[2], ev_tail[2];
+  int tail_pending[2];        /* ev_tail[i] has been recorded and not yet waited for by a render into buffer i */
+  int last_tail;              /* buffer whose tail was issued last (-1: none) */
   size_t partial_cap;         /* floats               */
   float *d_gain_state;        /* master smoother gain: two slots, gain_slot is the current one */
   int gain_slot;

@@ -197,6 +197,33 @@ def test_fused_mix_equals_render_plus_master(dev):
         assert gio.bits_equal(outs[0], outs[1]), (n, frames)
 
 
+def test_overlapped_tail_gives_the_same_blocks(dev):
+    """SKRED_OPT_OVERLAP_TAIL: the reduction + master stage of block k runs on an internal stream while block k+1
+    renders.  Six consecutive blocks, each into its own buffer: same bytes as the in-order path."""
+    import torch
+    n, frames, blocks = 70000, 300, 6
+    bank, tables, g = banks.bank_c2(n)
+    res = []
+    for overlap in (False, True):
+        db = dev.DeviceBank(n)
+        db.set_tables(tables)
+        db.upload(bank)
+        db.set_globals(g)
+        db.overlap_tail(overlap)
+        outs = [torch.zeros(frames, 2, device="cuda") for _ in range(blocks)]
+        for o in outs:
+            db.render_mix(frames, o.data_ptr(), 2)
+        db.wait_mix(0)
+        torch.cuda.synchronize()
+        res.append(np.concatenate([o.cpu().numpy() for o in outs]))
+        got = bank.copy()
+        db.download(got)
+        res.append(got)
+        db.close()
+    assert gio.bits_equal(res[0], res[2])
+    assert not res[1].rw_equal(res[3])
+
+
 def test_determinism(dev):
     """No atomics, fixed reduction order: two runs give identical bytes."""
     bank, tables, g = banks.bank_c2(10000)

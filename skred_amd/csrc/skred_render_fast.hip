@@ -214,12 +214,17 @@ __device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
     SK_REDUCE_AND_STORE(J)                                                                               \
   }
-// two steady frames (J even, J+1): delay-line roles swap in between, one 4-chain reduction, one 16-byte store
+// two steady frames (J even, J+1): delay-line roles swap in between, one 4-chain reduction, one 16-byte store.
+// Both oscillator halves run first (the phase recurrence does not depend on the samples): the two table reads are
+// in flight together and the second frame's read latency hides behind the first frame's biquad / gain chain -- a
+// small bank has one wave per SIMD and nothing else to hide it behind.
 #define SK_FAST_PAIR_STEADY(J, TAME_) /* TAME_ loops run only when no live lane is muted: no output select */ \
   {                                                                                                      \
     float l0, r0, l1, r1;                                                                                \
-    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x1, r.x2, r.y1, r.y2, released, lds_tab, glb_tab, l0, r0); \
-    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP>(r, r.x2, r.x1, r.y2, r.y1, released, lds_tab, glb_tab, l1, r1); \
+    const float sa_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
+    const float sb_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
+    fast_post<FILTER, ENV, true>(r, sa_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);                      \
+    fast_post<FILTER, ENV, true>(r, sb_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);                      \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }

@@ -209,6 +209,7 @@ static void classify(skred_bank_t *b) {
     m = SKM_FAST;
     if (filt) m |= SKM_FILTER_ALL;
     if (env) m |= SKM_ENV_ALL;
+    if (b->cnt_stops) m |= SKM_STOPS;
   }
   b->fast_mode = m;
   b->class_dirty = 0;
@@ -359,8 +360,9 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   /* two voices per lane pay off for large LDS-table banks (packed fp32); banks whose tables stay in L2 / HBM do
    * better with one voice per lane at every size measured (2^16 .. 2^20: twice the waves to hide the window
    * refills behind) unless the caller set the threshold explicitly */
-  if ((a.fast_mode & SKM_FAST) && b->n_voices >= b->fast2_min_voices && (a.lds_table_floats > 0 || b->fast2_min_user))
-    a.fast_mode |= SKM_TWO_PER_LANE;
+  if ((a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_STOPS) && b->n_voices >= b->fast2_min_voices &&
+      (a.lds_table_floats > 0 || b->fast2_min_user))
+    a.fast_mode |= SKM_TWO_PER_LANE;        /* (voices that finish mid-launch are handled by the one-per-lane kernel only) */
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
   if ((rc = grow(&b->d_redtmp, &b->redtmp_cap, (size_t)sk_reduce_tmp_floats(2 * num_frames)))) return rc;

@@ -66,10 +66,12 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
     if (h->voice_filter_mode[v]) c |= SKC_FILTER;
     if (h->voice_use_amp_envelope[v]) c |= SKC_ENV;
     const int stops = h->voice_one_shot[v] && !h->voice_loop_enabled[v];
+    /* a forward one-shot that plays to its end is still a "clean" voice for the one-per-lane kernel */
+    if (stops && !h->voice_direction[v]) c |= SKC_STOPS;
     /* a phase that lives on the device was finite when it was uploaded and the kernels keep it so */
     const float ph = phase_known ? h->voice_phase[v] : 0.0f, pi = h->voice_phase_inc[v];
     const int finite = (ph - ph == 0.0f) && (pi - pi == 0.0f) && (lo - lo == 0.0f) && (hi - hi == 0.0f) && hi > lo;
-    if (stops || noise || has_mod || quant || hold || h->voice_direction[v] || !h->voice_smoother_enable[v] || !finite)
+    if (noise || has_mod || quant || hold || h->voice_direction[v] || !h->voice_smoother_enable[v] || !finite)
       c |= SKC_EXOTIC;
     meta->cls = c;
   }
@@ -127,8 +129,8 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
 void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m) {
   const uint8_t old = b->h_class[dst], now = m->cls;
   if (old != now) {
-    if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; }
-    if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; }
+    if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; if (old & SKC_STOPS) b->cnt_stops--; }
+    if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; if (now & SKC_STOPS) b->cnt_stops++; }
     b->h_class[dst] = now;
     b->class_dirty = 1;
   }

@@ -70,6 +70,7 @@ enum {
 #define SKM_FILTER_ALL  (1u << 1)  /* every live voice runs the biquad (else: none does) */
 #define SKM_ENV_ALL     (1u << 2)  /* every live voice uses the amp envelope (else: none does) */
 #define SKM_TWO_PER_LANE (1u << 3) /* large bank: sk_render_fast2_kernel (two voices per lane, packed fp32) */
+#define SKM_STOPS       (1u << 4)  /* some voice is a forward one-shot that finishes at its table end (sk_render_fast_kernel<STOPS>) */
 
 #define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */
 #define SK_CHUNK 64                /* frames between two workgroup-level mix flushes */

@@ -33,6 +33,10 @@ struct FastRegs {
   float phase, sgain, x1, x2, y1, y2, sample;
   float tf, trf;                // frames since note-on / note-off for the CURRENT frame
   uint32_t rw;
+  // STOPS kernels: forward one-shots without loop play to the table end and finish (synth.c:242-244)
+  bool stop;                    // this voice stops instead of wrapping
+  bool fin;                     // ... and did so on the frame just advanced
+  float hi_stop;                // loop_end - 1e-6f, the phase it is left at
 };
 
 // NOCLAMP: the caller guarantees 0 <= lo <= pos < hi <= table_size (TAME loops), so the reference's
@@ -52,7 +56,7 @@ __device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__r
   const float a = pr.a;
   float b = pr.b;
   int nxt = idx + 1;
-  bool special = (float)nxt >= r.hi;
+  bool special = !r.stop && (float)nxt >= r.hi;      // a stopping voice does not fold: its neighbour clamps below
   if (special) nxt = (int)r.lo;
   if (!NOCLAMP) { const int c = max(min(nxt, r.tsize_m1), 0); special = special || (c != nxt); nxt = c; }
   if (special) b = *reinterpret_cast<const float *>(tab + (r.toff4 + (nxt << 2)));
@@ -66,7 +70,7 @@ __device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__r
 // TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
 // by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
 // Oscillator half of a frame (osc_next, synth.c:217-275): advance and wrap the phase.
-template <bool TAME>
+template <bool TAME, bool STOPS = false>
 __device__ __forceinline__ float fast_advance(FastRegs &r) {
   const float ph0 = r.phase + r.inc;
   const float x = ph0 - r.lo;
@@ -79,6 +83,11 @@ __device__ __forceinline__ float fast_advance(FastRegs &r) {
     const bool in_range = (ph0 >= r.lo) && !over;
     ph = simple ? r.lo + (x - r.span) : ph0;
     if (!(in_range || simple)) ph = slow_wrap(ph0, r.lo, r.hi, r.span);
+  }
+  if (STOPS) {                                          // synth.c:242-244,248-250: clamp and finish instead of wrapping
+    const bool under = ph0 < r.lo;
+    r.fin = r.stop && (over || under);
+    if (r.stop) ph = over ? r.hi_stop : (under ? r.lo : ph0);
   }
   r.phase = ph;
   return ph;
@@ -149,12 +158,12 @@ __device__ __forceinline__ bool fast_smoother_stalled(const FastRegs &r) {
 // caller has set r.tf / r.trf to this frame's envelope clocks.
 // TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
 // by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
-template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP>
+template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false>
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r) {
-  const float ph = fast_advance<TAME>(r);
-  const float s = fast_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r, ph);
+  const float ph = fast_advance<TAME, STOPS>(r);
+  const float s = fast_fetch<TAB_LDS, INTERP, TAME && !STOPS>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
   fast_post<FILTER, ENV, STEADY>(r, s, xn, xo, yn, yo, released, out_l, out_r);
 }
 
@@ -188,7 +197,7 @@ __device__ __forceinline__ void fast_win_fill(const FastRegs &r, bool dead, Fast
   w.any_direct = __any(w.direct);
 }
 
-template <int INTERP>
+template <int INTERP, bool STOPS = false>
 __device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin &w, const float *win, int lane,
                                                 const char *__restrict__ glb_tab, float p) {
   const int idx = (int)p;
@@ -201,17 +210,43 @@ __device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin
     s = ta + (p - (float)idx) * (tb - ta);
   }
   if (w.any_direct) {
-    if (w.direct) s = fast_fetch<false, INTERP, true>(nullptr, glb_tab, r, p);
+    if (w.direct) s = fast_fetch<false, INTERP, !STOPS>(nullptr, glb_tab, r, p);   // a finishing phase needs the clamps
   }
   return s;
 }
 
+// A voice reached its table end on the frame just rendered (r.fin): from the next frame on the reference skips it
+// (synth.c:531-535: voice_sample = 0, nothing advances).  Its state is final now, so it is stored here -- delay
+// line in the reference's order whatever role the registers play at this point of the pair -- and the lane turns
+// into a skipped one for the rest of the launch (exact zeros, never stored again).
+__device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs &r, int v, bool &dead, bool &silent,
+                                            bool &sample_final, bool swapped, bool last_frame) {
+  if (r.fin) {
+    uint4 s0, s1;
+    s0.x = __float_as_uint(r.phase); s0.y = __float_as_uint(r.sgain);
+    s0.z = __float_as_uint(swapped ? r.x2 : r.x1); s0.w = __float_as_uint(swapped ? r.x1 : r.x2);
+    s1.x = __float_as_uint(swapped ? r.y2 : r.y1); s1.y = __float_as_uint(swapped ? r.y1 : r.y2);
+    s1.z = last_frame ? __float_as_uint(r.sample) : 0u;    // a later frame of this launch would have zeroed it
+    s1.w = r.rw | SKR_FINISHED;
+    *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
+    *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;
+    dead = true; silent = true; sample_final = true;
+    r.inc = 0.0f; r.lo = 0.0f; r.hi = 1.0f; r.span = 1.0f; r.span2 = 2.0f; r.phase = 0.0f;
+    r.toff4 = 0; r.tsize_m1 = 0;
+    r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
+    r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
+    r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
+    r.stop = false; r.fin = false; r.hi_stop = 0.0f;
+  }
+}
+
 // one frame of the chunk loop: STEADY_ selects the envelope mode, A/B the delay-line roles
-#define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO)                                                        \
+#define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO, SWAPPED_)                                              \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr); \
+    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
+    if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (J) == a.num_frames - 1); \
     SK_REDUCE_AND_STORE(J)                                                                               \
   }
 // two steady frames (J even, J+1): delay-line roles swap in between, one 4-chain reduction, one 16-byte store.
@@ -235,15 +270,18 @@ __device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin
     fast_win_fill(r, dead, w_, win, lane, glb_tab);                                                      \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
-      const float s0_ = fast_fetch_win<INTERP>(r, w_, win, lane, glb_tab, fast_advance<true>(r));         \
+      const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
       fast_post<FILTER, ENV, true, STALL_>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);            \
-      const float s1_ = fast_fetch_win<INTERP>(r, w_, win, lane, glb_tab, fast_advance<true>(r));         \
+      if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, true, false);          \
+      const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
       fast_post<FILTER, ENV, true, STALL_>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
+      if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1); \
       { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
     }                                                                                                    \
   }
-#define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2)
-#define SK_FAST_ODD(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1)
+// after an EVEN frame the newest delay-line entries sit in x2 / y2 (roles swapped), after an ODD one in x1 / y1
+#define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2, true)
+#define SK_FAST_ODD(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1, false)
 #define SK_FAST_FIX_ODD_TAIL()                                                     \
   { float t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }
 
@@ -253,7 +291,9 @@ __device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin
 #ifndef SK_FAST_MIN_WAVES
 #define SK_FAST_MIN_WAVES 6      /* waves per SIMD the register allocator must leave room for */
 #endif
-template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
+// STOPS: the bank holds forward one-shots that play to their table end and finish (checked frame by frame;
+// such banks run the plain frame loop: no frame pairs, no table windows).
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS>
 __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
@@ -321,7 +361,11 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       }
       dead = (r.rw & SKR_FINISHED) || r.amp == 0.0f || (flags & SKF_INERT);
       silent = dead || (flags & SKF_MUTED);
+      r.stop = STOPS && (flags & SKF_ONE_SHOT) && !(flags & SKF_LOOPING);
+      r.fin = false;
+      r.hi_stop = r.hi - 1e-6f;                       // synth.c:243
     }
+    bool sample_final = false;                         // (STOPS) the voice finished in this launch: its planes are final
     // wrap can only ever be the simple one (see fast_frame<TAME>): decided once per pass
     if (dead) {
       // a skipped voice is never stored back (see the end of the pass): give its lane inert numbers
@@ -331,6 +375,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
       r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
       r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
+      r.stop = false;
     }
     // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
     // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>
@@ -354,7 +399,15 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
         const float tf_first = (float)(d_on + 1);
         steady = __all(dead || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
       }
-      if ((!ENV || steady) && tame) {
+      if (STOPS && (!ENV || steady)) {
+        int j = 0;
+        if (!TAB_LDS && tame) {       // a voice about to finish is `direct` in its window block; the block checks per frame
+          if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
+          else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
+        }
+        for (; j + 1 < cn; j += 2) { SK_FAST_EVEN(j, true) SK_FAST_ODD(j + 1, true) }
+        if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
+      } else if ((!ENV || steady) && tame) {
         int j = 0;
         if (!TAB_LDS) {
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
@@ -405,7 +458,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       s1.z = __float_as_uint(r.sample); s1.w = r.rw;
       *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
       *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;
-    } else {
+    } else if (!sample_final) {
       reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][v])[2] = 0u;
     }
     first_pass = false;
@@ -420,10 +473,11 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
   const bool tab_lds = args->lds_table_floats > 0;
   if (!tab_lds) lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);   // one table window per wave
   dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
-  const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
+  const int key = ((args->fast_mode & SKM_STOPS) ? 16 : 0) | (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
-#define SK_FAST_CASE(K, T, F, E, I) \
-  case K: hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I>), grid, block, lds_bytes, stream, *args); break;
+#define SK_FAST_CASE(K, T, F, E, I)                                                                                        \
+  case K: hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false>), grid, block, lds_bytes, stream, *args); break;     \
+  case 16 + K: hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, true>), grid, block, lds_bytes, stream, *args); break;
   switch (key) {
     SK_FAST_CASE(0, false, false, false, 0) SK_FAST_CASE(1, false, false, false, 1)
     SK_FAST_CASE(2, false, false, true, 0)  SK_FAST_CASE(3, false, false, true, 1)

@@ -392,6 +392,45 @@ def test_fast_kernel_big_increments(dev):
     assert rel_rms(fast_mix, ref_mix) <= 1e-5
 
 
+@pytest.mark.parametrize("recipe,interp", [("c4", 0), ("c4", 1), ("c2", 0)])
+def test_stopping_one_shots_on_the_specialised_kernel(dev, recipe, interp):
+    """Forward one-shots without loop (a sampler's drums): each plays to its table end, is audible on the frame it
+    finishes (clamped index, second tap clamped, not folded), then freezes with voice_sample = 0.  The one-per-lane
+    kernel keeps such banks: finishing is checked frame by frame, the voice's planes are stored at that moment (delay
+    line in reference order, whichever half of a frame pair it happens in) and the lane goes inert.  Voices finish in
+    the middle of launches, on the last frame of a launch, before the first launch; note-offs and a re-trigger of
+    finished voices come in between."""
+    n = 3000
+    bank, tables, g = banks.RECIPES[recipe](n)
+    stop = np.arange(n) % 3 != 0
+    bank["voice_one_shot"][stop] = 1
+    bank["voice_loop_enabled"][stop] = 0
+    size = bank["voice_table_size"].astype(np.float32)
+    # spread the remaining play time: some finish within tens of frames, some never in this test
+    left = (np.float32(5.0) + np.float32(40.0) * (np.arange(n) % 211)).astype(np.float32)
+    inc = np.maximum(bank["voice_phase_inc"], np.float32(0.25))
+    bank["voice_phase_inc"][stop] = inc[stop]
+    bank["voice_phase"][stop] = np.maximum(size[stop] - left[stop] * inc[stop], np.float32(0.0))
+    sel = np.where(stop)[0]
+    bank["voice_phase"][sel[0]] = size[sel[0]] - np.float32(200.0) * bank["voice_phase_inc"][sel[0]] + np.float32(0.5)  # frame 200 = last frame of launch 1
+    bank["voice_finished"][sel[1]] = 1                                       # finished before the first launch
+
+    def retrigger(host, now):                                                # osc_trigger on every 5th stopping voice
+        vs = sel[::5]
+        host["voice_finished"][vs] = 0
+        host["voice_phase"][vs] = 0.0
+
+    segs = [(200, None), (333, _release_odd_voices), (512, None), (64, retrigger), (1500, None)]
+    mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False)
+    gen_mix, gen_state, kg = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=True)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert k == [1] * len(segs) and kg == [0] * len(segs), (k, kg)
+    assert int(ref_state["voice_finished"].sum()) > 500                      # the scenario does finish voices
+    assert not gen_state.rw_equal(ref_state), gen_state.rw_equal(ref_state)
+    assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
+    assert rel_rms(mix, ref_mix) <= 1e-5
+
+
 def test_exotic_voice_forces_generic_kernel(dev):
     bank, tables, g = banks.bank_c2(512)
     bank["voice_sample_hold_max"][5] = 3

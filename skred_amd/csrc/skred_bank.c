@@ -381,7 +381,11 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   a.launch_ticket = ++b->launch_ticket;
   a.skip_env2 = two_env && b->env_quiet;
   const int timed = b->timing_every > 0 && (b->launch_ticket % (uint32_t)b->timing_every) == 0;
-  if (timed) HIP_TRY(hipEventRecord(b->ev0[tslot], s));
+  if (timed) {
+    /* a bracketed launch is measured alone: the previous block's overlapped tail (if any) finishes first */
+    if (b->last_tail >= 0 && b->tail_pending[b->last_tail]) HIP_TRY(hipStreamWaitEvent(s, b->ev_tail[b->last_tail], 0));
+    HIP_TRY(hipEventRecord(b->ev0[tslot], s));
+  }
   hipError_t e;
   if (modulated) {
     b->last_kernel = SKRED_KERNEL_MODULATED;

@@ -431,6 +431,68 @@ def test_stopping_one_shots_on_the_specialised_kernel(dev, recipe, interp):
     assert rel_rms(mix, ref_mix) <= 1e-5
 
 
+def _clean_fuzz_bank(rng):
+    """A random bank of the specialised kernels' family: LDS or L2 tables, filter for all or none, envelope for all
+    or none, optionally forward one-shots that stop, tame and wild increments, mutes, zero amps, odd sizes."""
+    recipe = ["c2", "c4"][int(rng.integers(0, 2))]
+    n = int(rng.integers(130, 2200))
+    bank, tables, g = banks.RECIPES[recipe](n)
+    if rng.random() < 0.5:
+        bank["voice_filter_mode"][:] = 0
+    elif recipe == "c4":
+        bank["voice_filter_mode"][:] = 1 + (np.arange(n) % 4)
+        c = banks.biquad_coeffs(bank["voice_filter_mode"], 200.0 + 37.0 * (np.arange(n) % 150), np.full(n, 0.9, np.float32), 48000)
+        for k in ("b0", "b1", "b2", "a1", "a2"):
+            bank["voice_filter"][k] = c[k]
+    if rng.random() < 0.4:
+        bank["voice_use_amp_envelope"][:] = 0
+    stops = rng.random() < 0.5
+    if stops:
+        sel = rng.random(n) < 0.3
+        bank["voice_one_shot"][sel] = 1
+        bank["voice_loop_enabled"][sel] = 0
+        size = bank["voice_table_size"].astype(np.float32)
+        inc = np.maximum(bank["voice_phase_inc"], np.float32(0.125))
+        bank["voice_phase_inc"][sel] = inc[sel]
+        left = rng.integers(1, 3000, n).astype(np.float32)
+        bank["voice_phase"][sel] = np.maximum(size[sel] - left[sel] * inc[sel], np.float32(0.0))
+    wild = rng.random(n) < 0.05                       # increments of several loop lengths: the general wrap
+    span = np.where(bank["voice_loop_enabled"] & bank["voice_loop_valid"], bank["voice_loop_end_f"] - bank["voice_loop_start_f"],
+                    bank["voice_table_size"].astype(np.float32)).astype(np.float32)
+    if not stops:
+        bank["voice_phase_inc"][wild] = (span[wild] * np.float32(1.7)).astype(np.float32)
+    bank["voice_disconnect"][rng.random(n) < 0.03] = 1
+    bank["voice_amp"][rng.random(n) < 0.03] = 0.0
+    return recipe, bank, tables, g, stops
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_clean_family_fuzz_vs_oracle(dev, seed):
+    """Fuzz of the specialised kernels (one / two voices per lane, LDS tables / table windows, stopping one-shots):
+    random clean banks, random block lengths, note-offs and re-triggers in between; per-voice state bit-exact."""
+    rng = np.random.default_rng(1000 + seed)
+    recipe, bank, tables, g, stops = _clean_fuzz_bank(rng)
+    interp = int(rng.integers(0, 2))
+
+    def retrigger(host, now):
+        vs = np.arange(3, host.n, 17)
+        host["voice_finished"][vs] = 0
+        host["voice_phase"][vs] = np.where(host["voice_loop_enabled"][vs] != 0, host["voice_loop_start_f"][vs], np.float32(0.0))
+        e = host["voice_amp_envelope"]
+        e["sample_start"][vs] = now
+        e["sample_release"][vs] = 0
+        e["is_active"][vs] = 1
+
+    events = [None, _release_odd_voices, None, retrigger, None]
+    segs = [(int(rng.integers(1, 1400)), ev) for ev in events]
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    for fast2 in ((False,) if stops else (False, True)):
+        mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False, fast2=fast2)
+        assert set(k) == {3 if fast2 else 1}, (k, recipe, stops)
+        assert not state.rw_equal(ref_state), (state.rw_equal(ref_state), recipe, stops, fast2, interp)
+        assert rel_rms(mix, ref_mix) <= 1e-5
+
+
 def test_exotic_voice_forces_generic_kernel(dev):
     bank, tables, g = banks.bank_c2(512)
     bank["voice_sample_hold_max"][5] = 3

@@ -327,7 +327,7 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
                                      "keep modulator and carrier in the same group (SURVEY 8e)");
   HIP_TRY(hipSetDevice(b->device));
   const int modulated = (b->features & SKB_ANY_MOD) != 0;
-  int n_wg = modulated ? b->n_padded / 64 : (b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS);
+  int n_wg = b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS;   /* workgroups stride over 256-voice passes */
   /* partial rows: alternate between two buffers (only the overlapped tail needs it; harmless otherwise) */
   const int slot = b->partial_slot;
   int rc = grow(&b->d_partial_buf[slot], &b->partial_buf_cap[slot], (size_t)n_wg * (size_t)num_frames * 2);

@@ -29,8 +29,8 @@ extern "C" {
 
 /* picks the kernel family from args->fast_mode / args->stems and launches it on `stream` */
 int sk_launch_render(const sk_render_args_t *args, int n_workgroups, hipStream_t stream);
-/* banks with modulators: one 64-voice group per workgroup, dependency levels in `levels` */
-int sk_launch_render_mod(const sk_render_args_t *args, int n_groups64, const int *levels, int max_level,
+/* banks with modulators: one aligned 64-voice group per wavefront, dependency levels in `levels` */
+int sk_launch_render_mod(const sk_render_args_t *args, int n_workgroups, const int *levels, int max_level,
                          hipStream_t stream);
 /* the two specialised families (called by sk_launch_render only) */
 int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);

@@ -161,10 +161,11 @@ struct ModRegs {
 };
 
 // One voice, one frame, with modulation: synth.c:531-612.  `prev`/`cur` are the LDS exchange arrays.
+template <bool TAB_LDS>
 __device__ __forceinline__ void voice_frame_mod(VoiceRegs &r, const ModRegs &m, int lane,
                                                 const float *prev, float *cur, const float *incs,
-                                                const float *__restrict__ tab, uint64_t now, float white,
-                                                int interp, float &out_l, float &out_r) {
+                                                const float *lds_tab, const float *__restrict__ tab, uint64_t now,
+                                                float white, int interp, float &out_l, float &out_r) {
   auto other = [&](int src) -> float { return src < lane ? cur[src] : prev[src]; };
   out_l = 0.0f; out_r = 0.0f;
   float raw;
@@ -199,7 +200,7 @@ __device__ __forceinline__ void voice_frame_mod(VoiceRegs &r, const ModRegs &m, 
         const float dm = (m.cz >= 0) ? (m.cz == lane ? prev[lane] : other(m.cz)) * m.cz_depth : 1.0f;
         pos = cz_warp(m.cz_mode, ph, m.cz_dist + dm, r.tsize);
       }
-      raw = table_fetch<false>(nullptr, tab, r, pos, interp, !stops);
+      raw = table_fetch<TAB_LDS>(lds_tab, tab, r, pos, interp, !stops);
     }
   }
   if (r.hold_max) {
@@ -263,63 +264,102 @@ __device__ __forceinline__ void voice_frame_mod(VoiceRegs &r, const ModRegs &m, 
   }
 }
 
-template <bool STEMS>
-__global__ __launch_bounds__(64) void sk_render_mod_kernel(const sk_render_args_t a, const int *__restrict__ levels,
-                                                           int max_level) {
-  __shared__ float xch[2][64];
-  __shared__ float incs[64];
-  const int lane = threadIdx.x;
-  const int v = blockIdx.x * 64 + lane;
-  VoiceRegs r;
-  load_voice(a, v, r);
-  ModRegs m;
-  {
-    const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
-    const uint4 mf = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODF][v]);
-    const uint4 mx = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODX][v]);
-    const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
-    m.fm = (int)mi.x; m.am = (int)mi.y; m.pm = (int)mi.z; m.cz = (int)mi.w;
-    m.fm_depth = __uint_as_float(mf.x); m.freq_scale = __uint_as_float(mf.y);
-    m.am_depth = __uint_as_float(mf.z); m.pm_depth = __uint_as_float(mf.w);
-    m.cz_depth = __uint_as_float(mx.x); m.cz_mode = (int)mx.y;
-    m.cz_dist = __uint_as_float(fl.w);
-    m.level = levels[v];
-    m.inc_raw = (r.flags & SKF_REVERSE) ? -r.inc : r.inc;    // load_voice applied the direction sign
-  }
-  incs[lane] = m.inc_raw;
-  xch[0][lane] = r.sample;                                   // voice_sample[] as the last callback left it
-  __syncthreads();
-
-  uint64_t rng = a.rng0;
-  int cur_i = 1;
-  float *part = a.partial + (size_t)blockIdx.x * (size_t)a.num_frames * 2;
-  for (int i = 0; i < a.num_frames; ++i) {
-    const uint64_t now = a.count0 + (uint64_t)i + 1;
-    rng = rng * LCG_A + LCG_C;
-    const float white = (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f;
-    float *cur = xch[cur_i];
-    const float *prev = xch[cur_i ^ 1];
-    const bool live = !((r.rw & SKR_FINISHED) || r.amp == 0.0f || (r.flags & SKF_INERT));
-    if (!live) { r.sample = 0.0f; cur[lane] = 0.0f; }         // synth.c:531-542
+// Four wavefronts per workgroup, each rendering one aligned 64-voice group per pass; the workgroup strides over
+// the bank (grid <= SK_MAX_WORKGROUPS) so that the table pool is staged into LDS once per workgroup and the
+// partial mix has one row per workgroup.  Modulators live in their carrier's group (the host refuses anything
+// else), so the per-frame exchange of voice_sample between dependency levels never leaves a wavefront: the
+// arrays are wave-private and a wave barrier (LDS executes a wave's accesses in order) replaces the workgroup one.
+#define SK_MOD_WAVE_SYNC()                                  \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+  __builtin_amdgcn_wave_barrier();                          \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+template <bool TAB_LDS, bool STEMS>
+__global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render_args_t a, const int *__restrict__ levels,
+                                                                 int max_level) {
+  extern __shared__ float lds[];
+  const float *lds_tab = lds;
+  float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));   // [4][SK_CHUNK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *xch0 = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * 192;               // wave-private: xch[2][64], incs[64]
+  float *incs = xch0 + 128;
+  if (TAB_LDS) {
+    const int n4 = a.lds_table_floats >> 2;
+    const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);
+    float4 *dst4 = reinterpret_cast<float4 *>(lds);
+    for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];
     __syncthreads();
-    float l = 0.0f, rr = 0.0f;
-    for (int lev = 0; lev <= max_level; ++lev) {
-      if (live && m.level == lev) {
-        voice_frame_mod(r, m, lane, prev, cur, incs, a.tables, now, white, a.interp, l, rr);
-        cur[lane] = r.sample;
+  }
+  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;
+  const int n_pass = a.n_groups;                       // passes of 256 voices = 4 groups of 64
+  bool first_pass = true;
+  for (int g = blockIdx.x; g < n_pass; g += gridDim.x) {
+    const int v = g * SK_GROUP + tid;
+    VoiceRegs r;
+    load_voice(a, v, r);
+    ModRegs m;
+    {
+      const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
+      const uint4 mf = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODF][v]);
+      const uint4 mx = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODX][v]);
+      const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
+      m.fm = (int)mi.x; m.am = (int)mi.y; m.pm = (int)mi.z; m.cz = (int)mi.w;
+      m.fm_depth = __uint_as_float(mf.x); m.freq_scale = __uint_as_float(mf.y);
+      m.am_depth = __uint_as_float(mf.z); m.pm_depth = __uint_as_float(mf.w);
+      m.cz_depth = __uint_as_float(mx.x); m.cz_mode = (int)mx.y;
+      m.cz_dist = __uint_as_float(fl.w);
+      m.level = levels[v];
+      m.inc_raw = (r.flags & SKF_REVERSE) ? -r.inc : r.inc;    // load_voice applied the direction sign
+    }
+    incs[lane] = m.inc_raw;
+    xch0[lane] = r.sample;                                     // voice_sample[] as the last callback left it
+    SK_MOD_WAVE_SYNC()
+
+    uint64_t rng = a.rng0;
+    int cur_i = 1;
+    for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
+      const int cn = min(SK_CHUNK, a.num_frames - c0);
+      for (int j = 0; j < cn; ++j) {
+        const int i = c0 + j;
+        const uint64_t now = a.count0 + (uint64_t)i + 1;
+        rng = rng * LCG_A + LCG_C;
+        const float white = (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f;
+        float *cur = xch0 + cur_i * 64;
+        const float *prev = xch0 + (cur_i ^ 1) * 64;
+        const bool live = !((r.rw & SKR_FINISHED) || r.amp == 0.0f || (r.flags & SKF_INERT));
+        if (!live) { r.sample = 0.0f; cur[lane] = 0.0f; }         // synth.c:531-542
+        SK_MOD_WAVE_SYNC()
+        float l = 0.0f, rr = 0.0f;
+        for (int lev = 0; lev <= max_level; ++lev) {
+          if (live && m.level == lev) {
+            voice_frame_mod<TAB_LDS>(r, m, lane, prev, cur, incs, lds_tab, a.tables, now, white, a.interp, l, rr);
+            cur[lane] = r.sample;
+          }
+          SK_MOD_WAVE_SYNC()
+        }
+        if (STEMS) {
+          if (v < a.n_voices)
+            reinterpret_cast<float2 *>(a.stems)[(size_t)i * (size_t)a.n_voices + (size_t)v] = make_float2(l, rr);
+        }
+        float sl = l, sr = rr;
+        wave_sum2_to_lane63(sl, sr);
+        if (lane == 63) wsum[wave * SK_CHUNK + j] = make_float2(sl, sr);
+        cur_i ^= 1;
+      }
+      __syncthreads();
+      if (tid < 2 * cn) {
+        const float *w = reinterpret_cast<const float *>(wsum);
+        float s = w[0 * 2 * SK_CHUNK + tid];
+        s += w[1 * 2 * SK_CHUNK + tid];
+        s += w[2 * 2 * SK_CHUNK + tid];
+        s += w[3 * 2 * SK_CHUNK + tid];
+        float *p = a.partial + part_base + (size_t)c0 * 2 + tid;
+        if (first_pass) *p = s; else *p += s;
       }
       __syncthreads();
     }
-    if (STEMS) {
-      if (v < a.n_voices)
-        reinterpret_cast<float2 *>(a.stems)[(size_t)i * (size_t)a.n_voices + (size_t)v] = make_float2(l, rr);
-    }
-    float sl = l, sr = rr;
-    wave_sum2_to_lane63(sl, sr);
-    if (lane == 63) reinterpret_cast<float2 *>(part)[i] = make_float2(sl, sr);
-    cur_i ^= 1;
+    store_voice(a, v, r);
+    first_pass = false;
   }
-  store_voice(a, v, r);
 }
 // ---------------------------------------------------------------- launchers (C linkage)
 
@@ -343,10 +383,15 @@ extern "C" int sk_launch_render(const sk_render_args_t *args, int n_workgroups, 
   return (int)hipGetLastError();
 }
 
-extern "C" int sk_launch_render_mod(const sk_render_args_t *args, int n_groups64, const int *levels,
+extern "C" int sk_launch_render_mod(const sk_render_args_t *args, int n_workgroups, const int *levels,
                                     int max_level, hipStream_t stream) {
-  dim3 grid((unsigned)n_groups64), block(64);
-  if (args->stems) hipLaunchKernelGGL((sk_render_mod_kernel<true>), grid, block, 0, stream, *args, levels, max_level);
-  else             hipLaunchKernelGGL((sk_render_mod_kernel<false>), grid, block, 0, stream, *args, levels, max_level);
+  const bool tab_lds = args->lds_table_floats > 0;
+  const size_t lds_bytes = (size_t)(tab_lds ? args->lds_table_floats : 0) * sizeof(float) +
+                           (size_t)4 * SK_CHUNK * sizeof(float2) + (size_t)4 * 192 * sizeof(float);
+  dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
+#define SK_MOD_LAUNCH(T, S) hipLaunchKernelGGL((sk_render_mod_kernel<T, S>), grid, block, lds_bytes, stream, *args, levels, max_level)
+  if (tab_lds) { if (args->stems) SK_MOD_LAUNCH(true, true); else SK_MOD_LAUNCH(true, false); }
+  else         { if (args->stems) SK_MOD_LAUNCH(false, true); else SK_MOD_LAUNCH(false, false); }
+#undef SK_MOD_LAUNCH
   return (int)hipGetLastError();
 }

@@ -210,6 +210,7 @@ static void classify(skred_bank_t *b) {
     if (filt) m |= SKM_FILTER_ALL;
     if (env) m |= SKM_ENV_ALL;
     if (b->cnt_stops) m |= SKM_STOPS;
+    if (b->cnt_fm) m |= SKM_FM;
   }
   b->fast_mode = m;
   b->class_dirty = 0;
@@ -217,7 +218,7 @@ static void classify(skred_bank_t *b) {
   if (!b->mod_dirty) return;
   b->mod_dirty = 0;
   b->max_level = 0;
-  if (b->features & SKB_ANY_MOD) {
+  if (b->features & (SKB_ANY_MOD | SKB_ANY_FM)) {
     for (int g0 = 0; g0 < b->n_padded; g0 += 64) {
       for (int l = 0; l < 64; l++) {
         int lvl = 0;
@@ -322,11 +323,15 @@ static void poll_env_quiet(skred_bank_t *b) {
 static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_stems, hipStream_t s, int *n_wg_out) {
   if (interp != SKRED_INTERP_TRUNCATE && interp != SKRED_INTERP_LINEAR) return fail(SKRED_E_BAD_ARG, "render: interp %d", interp);
   if (!b->d_tables) return fail(SKRED_E_BAD_ARG, "render: no table pool set");
-  if ((b->features & SKB_ANY_MOD) && b->mod_escapes)
+  if ((b->features & (SKB_ANY_MOD | SKB_ANY_FM)) && b->mod_escapes)
     return fail(SKRED_E_UNSUPPORTED, "a voice is modulated by a voice outside its aligned 64-voice group: "
                                      "keep modulator and carrier in the same group (SURVEY 8e)");
   HIP_TRY(hipSetDevice(b->device));
-  const int modulated = (b->features & SKB_ANY_MOD) != 0;
+  classify(b);
+  /* the modulated kernel serves every kind of modulation; banks whose only modulation is previous-frame FM stay on
+   * the one-per-lane kernel when they are otherwise clean (and no stems are asked for) */
+  const int fast_ok = (b->fast_mode & SKM_FAST) && !b->force_generic && !d_stems;
+  const int modulated = (b->features & SKB_ANY_MOD) != 0 || ((b->features & SKB_ANY_FM) && b->cnt_fm > 0 && !fast_ok);
   int n_wg = b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS;   /* workgroups stride over 256-voice passes */
   /* partial rows: alternate between two buffers (only the overlapped tail needs it; harmless otherwise) */
   const int slot = b->partial_slot;
@@ -360,7 +365,7 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   /* two voices per lane pay off for large LDS-table banks (packed fp32); banks whose tables stay in L2 / HBM do
    * better with one voice per lane at every size measured (2^16 .. 2^20: twice the waves to hide the window
    * refills behind) unless the caller set the threshold explicitly */
-  if ((a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_STOPS) && b->n_voices >= b->fast2_min_voices &&
+  if ((a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_STOPS | SKM_FM)) && b->n_voices >= b->fast2_min_voices &&
       (a.lds_table_floats > 0 || b->fast2_min_user))
     a.fast_mode |= SKM_TWO_PER_LANE;        /* (voices that finish mid-launch are handled by the one-per-lane kernel only) */
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC

@@ -51,7 +51,7 @@ struct skred_bank {
   int max_level;
   int mod_escapes;            /* some modulator lies outside its carrier's 64-voice group */
   int class_dirty;
-  int cnt_real, cnt_filter, cnt_env, cnt_exotic, cnt_stops;   /* voices per SKC_* bit (kept incrementally) */
+  int cnt_real, cnt_filter, cnt_env, cnt_exotic, cnt_stops, cnt_fm;   /* voices per SKC_* bit (kept incrementally) */
   int mod_dirty;              /* modulator lanes changed: dependency levels must be recomputed */
   uint32_t fast_mode;         /* SKM_* from classify() */
   int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
@@ -84,6 +84,7 @@ struct skred_bank {
 #define SKC_FILTER 2u
 #define SKC_ENV    4u
 #define SKC_EXOTIC 8u   /* needs the generic kernel: see classify() */
+#define SKC_FM    32u   /* carrier of a higher-indexed modulator of its 64-voice group, nothing else modulated */
 #define SKC_STOPS 16u   /* forward one-shot without loop: plays to the table end and finishes (one voice per lane only) */
 
 

@@ -54,7 +54,17 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
   if (noise) { flags |= SKF_NOISE; features |= SKB_ANY_NOISE; }
   const int has_mod = h->voice_freq_mod_osc[v] >= 0 || h->voice_amp_mod_osc[v] >= 0 ||
                       h->voice_pan_mod_osc[v] >= 0 || h->voice_cz_mode[v] != 0;
-  if (has_mod) { flags |= SKF_HAS_MOD; features |= SKB_ANY_MOD; }
+  /* frequency modulation by a HIGHER-indexed voice of the same aligned 64-voice group, and nothing else: the carrier
+   * reads last frame's voice_sample of its modulator (synth.c:548-555 in index order), so no ordering inside a
+   * frame is involved and the one-per-lane kernel can serve it */
+  int fm_only = 0;
+  {
+    const int fm = h->voice_freq_mod_osc[v];
+    const int md = fm + (dst - v);
+    fm_only = fm >= 0 && fm != v && h->voice_amp_mod_osc[v] < 0 && h->voice_pan_mod_osc[v] < 0 && h->voice_cz_mode[v] == 0 &&
+              md >= 0 && md < b->n_voices && (md >> 6) == (dst >> 6) && md > dst;
+  }
+  if (has_mod) { flags |= SKF_HAS_MOD; features |= fm_only ? SKB_ANY_FM : SKB_ANY_MOD; }
   int quant = h->voice_quantize[v], hold = h->voice_sample_hold_max[v];
   if (quant < 0 || quant > 30) quant = quant < 0 ? 0 : 30;
   if (hold < 0) hold = 0;
@@ -71,8 +81,9 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
     /* a phase that lives on the device was finite when it was uploaded and the kernels keep it so */
     const float ph = phase_known ? h->voice_phase[v] : 0.0f, pi = h->voice_phase_inc[v];
     const int finite = (ph - ph == 0.0f) && (pi - pi == 0.0f) && (lo - lo == 0.0f) && (hi - hi == 0.0f) && hi > lo;
-    if (noise || has_mod || quant || hold || h->voice_direction[v] || !h->voice_smoother_enable[v] || !finite)
+    if (noise || (has_mod && !fm_only) || quant || hold || h->voice_direction[v] || !h->voice_smoother_enable[v] || !finite)
       c |= SKC_EXOTIC;
+    if (fm_only) c |= SKC_FM;
     meta->cls = c;
   }
   meta->features = features;
@@ -129,8 +140,8 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
 void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m) {
   const uint8_t old = b->h_class[dst], now = m->cls;
   if (old != now) {
-    if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; if (old & SKC_STOPS) b->cnt_stops--; }
-    if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; if (now & SKC_STOPS) b->cnt_stops++; }
+    if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; if (old & SKC_STOPS) b->cnt_stops--; if (old & SKC_FM) b->cnt_fm--; }
+    if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; if (now & SKC_STOPS) b->cnt_stops++; if (now & SKC_FM) b->cnt_fm++; }
     b->h_class[dst] = now;
     b->class_dirty = 1;
   }

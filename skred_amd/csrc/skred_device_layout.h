@@ -63,13 +63,17 @@ enum {
 #define SKB_ANY_FILTER (1u << 1)
 #define SKB_ANY_ENV    (1u << 2)
 #define SKB_ANY_HOLDQ  (1u << 3)   /* sample&hold or bit-crush somewhere */
-#define SKB_ANY_MOD    (1u << 4)
+#define SKB_ANY_MOD    (1u << 4)   /* modulation that needs sk_render_mod_kernel (same-frame dependencies, AM, pan, CZ) */
+#define SKB_ANY_FM     (1u << 5)   /* frequency modulation by a higher-indexed voice of the group only (previous-frame
+                                      semantics): the one-per-lane kernel can do it; sk_render_mod_kernel otherwise */
 
 /* fast_mode word (host -> launcher) */
 #define SKM_FAST        (1u << 0)  /* bank qualifies for sk_render_fast_kernel (see skred_bank.c:classify) */
 #define SKM_FILTER_ALL  (1u << 1)  /* every live voice runs the biquad (else: none does) */
 #define SKM_ENV_ALL     (1u << 2)  /* every live voice uses the amp envelope (else: none does) */
 #define SKM_TWO_PER_LANE (1u << 3) /* large bank: sk_render_fast2_kernel (two voices per lane, packed fp32) */
+#define SKM_FM          (1u << 5)  /* some voice is frequency-modulated by a higher-indexed voice of its 64-voice group and
+                                      nothing else is modulated (sk_render_fast_kernel<STOPS>: previous-frame exchange by ds_bpermute) */
 #define SKM_STOPS       (1u << 4)  /* some voice is a forward one-shot that finishes at its table end (sk_render_fast_kernel<STOPS>) */
 
 #define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */

@@ -37,6 +37,10 @@ struct FastRegs {
   bool stop;                    // this voice stops instead of wrapping
   bool fin;                     // ... and did so on the frame just advanced
   float hi_stop;                // loop_end - 1e-6f, the phase it is left at
+  // ... and frequency modulation by a higher-indexed voice of the same 64-voice group (synth.c:548-555: the
+  // carrier reads the modulator's voice_sample of the PREVIOUS frame, so no ordering inside a frame is needed)
+  int fm_addr;                  // modulator lane * 4 (ds_bpermute address), -1: none
+  float fm_k, fm_depth;         // voice_phase_inc[m] * voice_freq_scale[n];  voice_freq_mod_depth[n]
 };
 
 // NOCLAMP: the caller guarantees 0 <= lo <= pos < hi <= table_size (TAME loops), so the reference's
@@ -70,9 +74,14 @@ __device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__r
 // TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
 // by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
 // Oscillator half of a frame (osc_next, synth.c:217-275): advance and wrap the phase.
+template <bool TAME, bool STOPS>
+__device__ __forceinline__ float fast_advance(FastRegs &r, float inc);
 template <bool TAME, bool STOPS = false>
-__device__ __forceinline__ float fast_advance(FastRegs &r) {
-  const float ph0 = r.phase + r.inc;
+__device__ __forceinline__ float fast_advance(FastRegs &r) { return fast_advance<TAME, STOPS>(r, r.inc); }
+
+template <bool TAME, bool STOPS>
+__device__ __forceinline__ float fast_advance(FastRegs &r, float inc) {
+  const float ph0 = r.phase + inc;
   const float x = ph0 - r.lo;
   const bool over = ph0 >= r.hi;
   float ph;
@@ -161,8 +170,15 @@ __device__ __forceinline__ bool fast_smoother_stalled(const FastRegs &r) {
 template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false>
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
-                                           const char *__restrict__ glb_tab, float &out_l, float &out_r) {
-  const float ph = fast_advance<TAME, STOPS>(r);
+                                           const char *__restrict__ glb_tab, float &out_l, float &out_r,
+                                           const bool any_fm = false) {
+  float inc = r.inc;
+  if (STOPS && any_fm) {                                // wave-uniform: some lane of the wave is a carrier
+    // voice_sample[m] as the previous frame left it (a modulator that is skipped this frame holds exact zero)
+    const float ms = __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, __float_as_int(r.sample)));
+    if (r.fm_addr >= 0) inc = r.inc + r.fm_k * (ms * r.fm_depth);        // synth.c:551-554
+  }
+  const float ph = fast_advance<TAME, STOPS>(r, inc);
   const float s = fast_fetch<TAB_LDS, INTERP, TAME && !STOPS>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
   fast_post<FILTER, ENV, STEADY>(r, s, xn, xo, yn, yo, released, out_l, out_r);
 }
@@ -236,7 +252,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
     r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
     r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
-    r.stop = false; r.fin = false; r.hi_stop = 0.0f;
+    r.stop = false; r.fin = false; r.hi_stop = 0.0f; r.fm_addr = -1;
   }
 }
 
@@ -244,7 +260,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO, SWAPPED_)                                              \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr); \
+    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, any_fm); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
     if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (J) == a.num_frames - 1); \
     SK_REDUCE_AND_STORE(J)                                                                               \
@@ -291,8 +307,9 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #ifndef SK_FAST_MIN_WAVES
 #define SK_FAST_MIN_WAVES 6      /* waves per SIMD the register allocator must leave room for */
 #endif
-// STOPS: the bank holds forward one-shots that play to their table end and finish (checked frame by frame;
-// such banks run the plain frame loop: no frame pairs, no table windows).
+// STOPS (the "extended" instantiation): the bank holds forward one-shots that play to their table end and finish
+// (checked frame by frame) and / or carriers frequency-modulated by a higher-indexed voice of their 64-voice group.
+// Such banks run the plain frame loop (no frame pairs); table windows only in waves without carriers.
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS>
 __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
@@ -364,6 +381,19 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.stop = STOPS && (flags & SKF_ONE_SHOT) && !(flags & SKF_LOOPING);
       r.fin = false;
       r.hi_stop = r.hi - 1e-6f;                       // synth.c:243
+      r.fm_addr = -1; r.fm_k = 0.0f; r.fm_depth = 0.0f;
+      if (STOPS && (a.fast_mode & SKM_FM)) {
+        const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
+        const uint4 mf = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODF][v]);
+        const int fm_lane = (int)mi.x;
+        // voice_phase_inc[m], whatever m's own state is (read before a skipped lane's numbers are neutralised)
+        const float inc_m = __int_as_float(__builtin_amdgcn_ds_bpermute(max(fm_lane, 0) << 2, __float_as_int(r.inc)));
+        if (fm_lane >= 0) {
+          r.fm_addr = fm_lane << 2;
+          r.fm_k = inc_m * __uint_as_float(mf.y);
+          r.fm_depth = __uint_as_float(mf.x);
+        }
+      }
     }
     bool sample_final = false;                         // (STOPS) the voice finished in this launch: its planes are final
     // wrap can only ever be the simple one (see fast_frame<TAME>): decided once per pass
@@ -375,8 +405,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
       r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
       r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
-      r.stop = false;
+      r.stop = false; r.fm_addr = -1;
     }
+    const bool any_fm = STOPS && __any(r.fm_addr >= 0);     // carriers in this wave: no table windows, no tame shortcuts
+    (void)any_fm;
     // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
     // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>
     const bool tame = __all(dead || (r.inc >= 0.0f && r.inc <= 0.5f * r.span && r.phase >= r.lo && r.phase <= r.hi &&
@@ -401,7 +433,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       }
       if (STOPS && (!ENV || steady)) {
         int j = 0;
-        if (!TAB_LDS && tame) {       // a voice about to finish is `direct` in its window block; the block checks per frame
+        if (!TAB_LDS && tame && !any_fm) {   // a voice about to finish is `direct` in its window block; the block checks per frame
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
         }
@@ -473,7 +505,7 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
   const bool tab_lds = args->lds_table_floats > 0;
   if (!tab_lds) lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);   // one table window per wave
   dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
-  const int key = ((args->fast_mode & SKM_STOPS) ? 16 : 0) | (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
+  const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM)) ? 16 : 0) |   /* the extended instantiation: stops and / or FM */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
 #define SK_FAST_CASE(K, T, F, E, I)                                                                                        \
   case K: hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false>), grid, block, lds_bytes, stream, *args); break;     \

@@ -431,6 +431,44 @@ def test_stopping_one_shots_on_the_specialised_kernel(dev, recipe, interp):
     assert rel_rms(mix, ref_mix) <= 1e-5
 
 
+@pytest.mark.parametrize("recipe,interp", [("c2", 0), ("c4", 1)])
+def test_previous_frame_fm_on_the_specialised_kernel(dev, recipe, interp):
+    """Two-operator FM the way the reference's patches write it (`v0 ... F1,depth` / `v1 ... m1`): the modulator has
+    the higher index, so the carrier reads its voice_sample of the previous frame (synth.c:548-555 in index order).
+    The one-per-lane kernel serves such banks (ds_bpermute exchange inside the 64-voice group) -- against the oracle
+    and against the modulated kernel; deep modulation drives increments negative and beyond a loop length; some
+    carriers are stopping one-shots; a modulator is switched off (amp 0) between launches."""
+    n = 3072
+    bank, tables, g = banks.RECIPES[recipe](n)
+    car = np.arange(0, n, 2)
+    mod = car + 1
+    bank["voice_freq_mod_osc"][car] = mod
+    bank["voice_freq_mod_depth"][car] = (np.float32(0.05) * (1 + (car % 97))).astype(np.float32)     # up to ~5: wild
+    bank["voice_freq_scale"][car] = (np.float32(0.5) + np.float32(0.01) * (car % 50)).astype(np.float32)
+    bank["voice_disconnect"][mod] = 1                                                               # `m1`
+    far = car[car % 64 < 32][::9]                       # some modulators further up in the same group
+    bank["voice_freq_mod_osc"][far] = far + 31
+    stops = car[5::40]
+    bank["voice_one_shot"][stops] = 1
+    bank["voice_loop_enabled"][stops] = 0
+
+    def kill_some_modulators(host, now):
+        host["voice_amp"][mod[::7]] = 0.0
+
+    segs = [(300, None), (257, _release_odd_voices), (700, kill_some_modulators), (64, None)]
+    mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False)
+    mmix, mstate, km = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=True)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert k == [1] * len(segs) and km == [2] * len(segs), (k, km)
+    assert not mstate.rw_equal(ref_state), mstate.rw_equal(ref_state)
+    assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
+    assert rel_rms(mix, ref_mix) <= 1e-5
+    # a modulator BELOW its carrier is a same-frame dependency: the whole bank goes to the modulated kernel
+    bank["voice_freq_mod_osc"][10] = 3
+    _, _, k2 = _run_scenario(dev, bank, tables, g, interp, [(64, None)], force_generic=False)
+    assert k2 == [2]
+
+
 def _clean_fuzz_bank(rng):
     """A random bank of the specialised kernels' family: LDS or L2 tables, filter for all or none, envelope for all
     or none, optionally forward one-shots that stop, tame and wild increments, mutes, zero amps, odd sizes."""

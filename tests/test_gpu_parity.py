@@ -501,12 +501,23 @@ def _clean_fuzz_bank(rng):
         bank["voice_phase_inc"][wild] = (span[wild] * np.float32(1.7)).astype(np.float32)
     bank["voice_disconnect"][rng.random(n) < 0.03] = 1
     bank["voice_amp"][rng.random(n) < 0.03] = 0.0
-    return recipe, bank, tables, g, stops
+    fm = rng.random() < 0.4                           # previous-frame FM: modulator above its carrier, same 64-voice group
+    if fm:
+        v = np.arange(n)
+        car = v[(rng.random(n) < 0.35) & (v % 64 < 63)]
+        up = rng.integers(1, 64, len(car))
+        m = np.minimum(car + up, (car // 64) * 64 + 63)
+        m = np.minimum(m, n - 1)
+        ok = m > car
+        bank["voice_freq_mod_osc"][car[ok]] = m[ok]
+        bank["voice_freq_mod_depth"][car[ok]] = (rng.random(int(ok.sum())) * 3.0).astype(np.float32)
+        bank["voice_freq_scale"][car[ok]] = (0.25 + rng.random(int(ok.sum()))).astype(np.float32)
+    return recipe, bank, tables, g, stops or fm
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
 def test_clean_family_fuzz_vs_oracle(dev, seed):
-    """Fuzz of the specialised kernels (one / two voices per lane, LDS tables / table windows, stopping one-shots):
+    """Fuzz of the specialised kernels (one / two voices per lane, LDS tables / table windows, stopping one-shots, FM):
     random clean banks, random block lengths, note-offs and re-triggers in between; per-voice state bit-exact."""
     rng = np.random.default_rng(1000 + seed)
     recipe, bank, tables, g, stops = _clean_fuzz_bank(rng)

@@ -1,0 +1,31 @@
+"""The C ABI used from C: tests/c_abi_smoke.c is compiled against include/skred_amd.h, linked with
+libskred_amd.so and run (bank mode: create / tables / upload / update / defer / run_queue / render_host /
+download / error codes).  The compile-and-link half runs everywhere; running it needs the GPU."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def build(tmp_path):
+    exe = str(tmp_path / "c_abi_smoke")
+    cmd = ["gcc", "-O1", "-Wall", "-Werror", "-std=gnu11", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(HERE, "c_abi_smoke.c"), "-o", exe, "-L" + os.path.join(ROOT, "skred_amd"), "-lskred_amd", "-lm",
+           "-Wl,-rpath," + os.path.join(ROOT, "skred_amd")]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return exe
+
+
+def test_c_host_compiles_and_links_against_the_headers(tmp_path):
+    build(tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_host_runs(tmp_path):
+    out = subprocess.run([build(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
+    assert out.stdout.startswith("OK")

@@ -54,15 +54,20 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
   if (noise) { flags |= SKF_NOISE; features |= SKB_ANY_NOISE; }
   const int has_mod = h->voice_freq_mod_osc[v] >= 0 || h->voice_amp_mod_osc[v] >= 0 ||
                       h->voice_pan_mod_osc[v] >= 0 || h->voice_cz_mode[v] != 0;
-  /* frequency modulation by a HIGHER-indexed voice of the same aligned 64-voice group, and nothing else: the carrier
-   * reads last frame's voice_sample of its modulator (synth.c:548-555 in index order), so no ordering inside a
-   * frame is involved and the one-per-lane kernel can serve it */
+  /* Modulation the one-per-lane kernel can serve: FM / AM / pan by a HIGHER-indexed voice of the same aligned
+   * 64-voice group (the carrier then reads last frame's voice_sample of its modulator: synth.c:548-555,584-587,
+   * 597-602 in index order, so no ordering inside a frame is involved), AM / pan by the voice itself, no CZ. */
   int fm_only = 0;
-  {
-    const int fm = h->voice_freq_mod_osc[v];
-    const int md = fm + (dst - v);
-    fm_only = fm >= 0 && fm != v && h->voice_amp_mod_osc[v] < 0 && h->voice_pan_mod_osc[v] < 0 && h->voice_cz_mode[v] == 0 &&
-              md >= 0 && md < b->n_voices && (md >> 6) == (dst >> 6) && md > dst;
+  if (has_mod && h->voice_cz_mode[v] == 0) {
+    const int src[3] = { h->voice_freq_mod_osc[v] == v ? -1 : h->voice_freq_mod_osc[v], h->voice_amp_mod_osc[v], h->voice_pan_mod_osc[v] };
+    fm_only = 1;
+    for (int k = 0; k < 3; k++) {
+      if (src[k] < 0) continue;
+      const int md = src[k] + (dst - v);
+      const int above = md >= 0 && md < b->n_voices && (md >> 6) == (dst >> 6) && md > dst;
+      const int self_ok = k > 0 && md == dst;
+      if (!above && !self_ok) fm_only = 0;
+    }
   }
   if (has_mod) { flags |= SKF_HAS_MOD; features |= fm_only ? SKB_ANY_FM : SKB_ANY_MOD; }
   int quant = h->voice_quantize[v], hold = h->voice_sample_hold_max[v];

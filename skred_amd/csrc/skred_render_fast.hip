@@ -41,6 +41,12 @@ struct FastRegs {
   // carrier reads the modulator's voice_sample of the PREVIOUS frame, so no ordering inside a frame is needed)
   int fm_addr;                  // modulator lane * 4 (ds_bpermute address), -1: none
   float fm_k, fm_depth;         // voice_phase_inc[m] * voice_freq_scale[n];  voice_freq_mod_depth[n]
+  // amplitude and pan modulation by a higher-indexed voice of the group (previous frame's voice_sample) or by the
+  // voice itself (its own sample of THIS frame: synth.c:584-587 post-filter, synth.c:597-602 post-gain)
+  int am_addr, pm_addr;         // lane * 4; -1: none; -2: the voice itself
+  float am_depth, pm_depth;
+  float am_prev, pm_prev;       // this frame's modulator samples, fetched before the voice's own sample changes
+  bool pan_dirty;               // pan modulation rewrote voice_pan_left / _right: the MISC plane is stored back
 };
 
 // NOCLAMP: the caller guarantees 0 <= lo <= pos < hi <= table_size (TAME loops), so the reference's
@@ -104,9 +110,9 @@ __device__ __forceinline__ float fast_advance(FastRegs &r, float inc) {
 
 // The rest of the frame: biquad, envelope / gain, smoother, pan.
 // STALL (steady waves only): the smoother no longer moves in any lane (fast_smoother_stalled) and is skipped.
-template <bool FILTER, bool ENV, bool STEADY, bool STALL = false>
+template <bool FILTER, bool ENV, bool STEADY, bool STALL = false, bool EXT = false>
 __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float &xo, float &yn, float &yo,
-                                          const bool released, float &out_l, float &out_r) {
+                                          const bool released, float &out_l, float &out_r, const bool muted = false) {
   // ---- biquad (mmf_process, synth.c:349-364) ----
   if (FILTER) {
     // xn/yn: newest delay-line entries, xo/yo: the older ones.  The new values overwrite the OLD
@@ -147,9 +153,17 @@ __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float
     gain = r.amp * (e * r.vel);
   }
   // ---- smoother + apply (synth.c:589-593), pan (synth.c:603-604) ----
+  if (EXT && r.am_addr != -1)                            // final = amp * env * mod (synth.c:583-588)
+    gain = gain * ((r.am_addr == -2 ? s : r.am_prev) * r.am_depth);
   if (!STALL) r.sgain += r.k * (gain - r.sgain);
   s *= r.sgain;
   r.sample = s;
+  if (EXT && r.pm_addr != -1 && !muted) {                // synth.c:597-602 (inside the `not disconnected` branch)
+    const float q = (r.pm_addr == -2 ? s : r.pm_prev) * r.pm_depth;
+    r.pan_l = (1.0f - q) / 2.0f;
+    r.pan_r = (1.0f + q) / 2.0f;
+    r.pan_dirty = true;
+  }
   out_l = s * r.pan_l;
   out_r = s * r.pan_r;
 }
@@ -171,16 +185,19 @@ template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTER
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r,
-                                           const bool any_fm = false) {
+                                           const bool any_fm = false, const bool muted = false) {
   float inc = r.inc;
-  if (STOPS && any_fm) {                                // wave-uniform: some lane of the wave is a carrier
+  if (STOPS && any_fm) {                                // wave-uniform: some lane of the wave is modulated
     // voice_sample[m] as the previous frame left it (a modulator that is skipped this frame holds exact zero)
-    const float ms = __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, __float_as_int(r.sample)));
+    const int mine = __float_as_int(r.sample);
+    const float ms = __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, mine));
     if (r.fm_addr >= 0) inc = r.inc + r.fm_k * (ms * r.fm_depth);        // synth.c:551-554
+    r.am_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.am_addr, 0), mine));
+    r.pm_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.pm_addr, 0), mine));
   }
   const float ph = fast_advance<TAME, STOPS>(r, inc);
   const float s = fast_fetch<TAB_LDS, INTERP, TAME && !STOPS>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
-  fast_post<FILTER, ENV, STEADY>(r, s, xn, xo, yn, yo, released, out_l, out_r);
+  fast_post<FILTER, ENV, STEADY, false, STOPS>(r, s, xn, xo, yn, yo, released, out_l, out_r, muted);
 }
 
 // ---- table windows for pools that do not fit in LDS (see skred_render_fast2.hip for the reasoning) ----
@@ -236,8 +253,12 @@ __device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin
 // line in the reference's order whatever role the registers play at this point of the pair -- and the lane turns
 // into a skipped one for the rest of the launch (exact zeros, never stored again).
 __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs &r, int v, bool &dead, bool &silent,
-                                            bool &sample_final, bool swapped, bool last_frame) {
+                                            bool &sample_final, bool swapped, bool last_frame, const uint2 misc_xy) {
   if (r.fin) {
+    if (r.pan_dirty) {                                    // its pan, as modulated up to this frame
+      *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = make_uint4(misc_xy.x, misc_xy.y, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r));
+      r.pan_dirty = false;
+    }
     uint4 s0, s1;
     s0.x = __float_as_uint(r.phase); s0.y = __float_as_uint(r.sgain);
     s0.z = __float_as_uint(swapped ? r.x2 : r.x1); s0.w = __float_as_uint(swapped ? r.x1 : r.x2);
@@ -252,7 +273,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
     r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
     r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
-    r.stop = false; r.fin = false; r.hi_stop = 0.0f; r.fm_addr = -1;
+    r.stop = false; r.fin = false; r.hi_stop = 0.0f; r.fm_addr = -1; r.am_addr = -1; r.pm_addr = -1;
   }
 }
 
@@ -260,9 +281,9 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO, SWAPPED_)                                              \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, any_fm); \
+    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, any_fm, muted); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
-    if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (J) == a.num_frames - 1); \
+    if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (J) == a.num_frames - 1, misc_xy); \
     SK_REDUCE_AND_STORE(J)                                                                               \
   }
 // two steady frames (J even, J+1): delay-line roles swap in between, one 4-chain reduction, one 16-byte store.
@@ -288,10 +309,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
       fast_post<FILTER, ENV, true, STALL_>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);            \
-      if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, true, false);          \
+      if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); \
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
       fast_post<FILTER, ENV, true, STALL_>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
-      if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1); \
+      if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); \
       { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
     }                                                                                                    \
   }
@@ -338,6 +359,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
     const int v = g * SK_GROUP + tid;
     FastRegs r;
     bool dead, silent;            // dead: skipped by synth.c:531-542; silent: dead or muted
+    bool muted = false;           // voice_disconnect
+    uint2 misc_xy = make_uint2(0u, 0u);   // (EXT) sample&hold words of the MISC plane, kept for a pan-modulated store
     bool released = false;
     uint64_t t_start = 0, t_release = 0;
     {
@@ -382,10 +405,17 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.fin = false;
       r.hi_stop = r.hi - 1e-6f;                       // synth.c:243
       r.fm_addr = -1; r.fm_k = 0.0f; r.fm_depth = 0.0f;
+      r.am_addr = -1; r.pm_addr = -1; r.am_depth = 0.0f; r.pm_depth = 0.0f; r.am_prev = 0.0f; r.pm_prev = 0.0f;
+      r.pan_dirty = false;
+      muted = (flags & SKF_MUTED) != 0;
       if (STOPS && (a.fast_mode & SKM_FM)) {
         const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
         const uint4 mf = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODF][v]);
         const int fm_lane = (int)mi.x;
+        const int am_lane = (int)mi.y, pm_lane = (int)mi.z;
+        if (am_lane >= 0) { r.am_addr = am_lane == lane ? -2 : am_lane << 2; r.am_depth = __uint_as_float(mf.z); }
+        if (pm_lane >= 0) { r.pm_addr = pm_lane == lane ? -2 : pm_lane << 2; r.pm_depth = __uint_as_float(mf.w); }
+        misc_xy = make_uint2(s2.x, s2.y);
         // voice_phase_inc[m], whatever m's own state is (read before a skipped lane's numbers are neutralised)
         const float inc_m = __int_as_float(__builtin_amdgcn_ds_bpermute(max(fm_lane, 0) << 2, __float_as_int(r.inc)));
         if (fm_lane >= 0) {
@@ -405,9 +435,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
       r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
       r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
-      r.stop = false; r.fm_addr = -1;
+      r.stop = false; r.fm_addr = -1; r.am_addr = -1; r.pm_addr = -1;
     }
-    const bool any_fm = STOPS && __any(r.fm_addr >= 0);     // carriers in this wave: no table windows, no tame shortcuts
+    // modulated lanes in this wave: no table windows, no tame shortcuts, no stalled-smoother skip
+    const bool any_fm = STOPS && __any(r.fm_addr >= 0 || r.am_addr != -1 || r.pm_addr != -1);
     (void)any_fm;
     // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
     // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>
@@ -493,6 +524,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
     } else if (!sample_final) {
       reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][v])[2] = 0u;
     }
+    if (STOPS && r.pan_dirty)           // pan modulation rewrote voice_pan_left / _right (synth.c:600-601)
+      *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = make_uint4(misc_xy.x, misc_xy.y, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r));
     first_pass = false;
   }
 }

@@ -433,8 +433,9 @@ def test_stopping_one_shots_on_the_specialised_kernel(dev, recipe, interp):
 
 @pytest.mark.parametrize("recipe,interp", [("c2", 0), ("c4", 1)])
 def test_previous_frame_fm_on_the_specialised_kernel(dev, recipe, interp):
-    """Two-operator FM the way the reference's patches write it (`v0 ... F1,depth` / `v1 ... m1`): the modulator has
-    the higher index, so the carrier reads its voice_sample of the previous frame (synth.c:548-555 in index order).
+    """Two-operator FM the way the reference's patches write it (`v0 ... F1,depth` / `v1 ... m1`), plus `A` and `P`
+    modulation of the same kind: the modulator has the higher index, so the carrier reads its voice_sample of the
+    previous frame (synth.c:548-555,584-587,597-602 in index order).
     The one-per-lane kernel serves such banks (ds_bpermute exchange inside the 64-voice group) -- against the oracle
     and against the modulated kernel; deep modulation drives increments negative and beyond a loop length; some
     carriers are stopping one-shots; a modulator is switched off (amp 0) between launches."""
@@ -451,6 +452,21 @@ def test_previous_frame_fm_on_the_specialised_kernel(dev, recipe, interp):
     stops = car[5::40]
     bank["voice_one_shot"][stops] = 1
     bank["voice_loop_enabled"][stops] = 0
+    # amplitude and pan modulation with the same previous-frame semantics (`A`, `P` with a higher-indexed voice),
+    # and by the voice itself (same-frame, but no other lane involved)
+    am = car[3::11]
+    bank["voice_amp_mod_osc"][am] = am + 1
+    bank["voice_amp_mod_depth"][am] = np.float32(3.0)
+    pm = car[7::13]
+    bank["voice_pan_mod_osc"][pm] = np.minimum(pm + 5, (pm // 64) * 64 + 63)
+    bank["voice_pan_mod_depth"][pm] = np.float32(8.0)
+    self_am = car[9::29]
+    bank["voice_amp_mod_osc"][self_am] = self_am
+    bank["voice_amp_mod_depth"][self_am] = np.float32(2.5)
+    self_pm = car[11::31]
+    bank["voice_pan_mod_osc"][self_pm] = self_pm
+    bank["voice_pan_mod_depth"][self_pm] = np.float32(6.0)
+    bank["voice_disconnect"][pm[::4]] = 1               # a muted voice's pan is not modulated (synth.c:596)
 
     def kill_some_modulators(host, now):
         host["voice_amp"][mod[::7]] = 0.0
@@ -512,6 +528,12 @@ def _clean_fuzz_bank(rng):
         bank["voice_freq_mod_osc"][car[ok]] = m[ok]
         bank["voice_freq_mod_depth"][car[ok]] = (rng.random(int(ok.sum())) * 3.0).astype(np.float32)
         bank["voice_freq_scale"][car[ok]] = (0.25 + rng.random(int(ok.sum()))).astype(np.float32)
+        for osc, depth, top in (("voice_amp_mod_osc", "voice_amp_mod_depth", 3.0), ("voice_pan_mod_osc", "voice_pan_mod_depth", 9.0)):
+            c2 = v[(rng.random(n) < 0.15) & (v % 64 < 63)]
+            tgt = np.minimum(c2 + rng.integers(0, 20, len(c2)), (c2 // 64) * 64 + 63)     # +0: the voice itself
+            tgt = np.minimum(tgt, n - 1)
+            bank[osc][c2] = tgt
+            bank[depth][c2] = (rng.random(len(c2)) * top).astype(np.float32)
     return recipe, bank, tables, g, stops or fm
 
 

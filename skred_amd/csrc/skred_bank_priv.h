@@ -85,7 +85,7 @@ struct skred_bank {
 #define SKC_ENV    4u
 #define SKC_EXOTIC 8u   /* needs the generic kernel: see classify() */
 #define SKC_FM    32u   /* carrier of a higher-indexed modulator of its 64-voice group, nothing else modulated */
-#define SKC_STOPS 16u   /* forward one-shot without loop: plays to the table end and finishes (one voice per lane only) */
+#define SKC_STOPS 16u   /* one-shot without loop (plays to its table end and finishes) or reverse playback: the one-per-lane kernel's extended instantiation */
 
 
 int skred_amd_set_error(int code, const char *fmt, ...);

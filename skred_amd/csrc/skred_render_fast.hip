@@ -47,6 +47,7 @@ struct FastRegs {
   float am_depth, pm_depth;
   float am_prev, pm_prev;       // this frame's modulator samples, fetched before the voice's own sample changes
   bool pan_dirty;               // pan modulation rewrote voice_pan_left / _right: the MISC plane is stored back
+  bool rev;                     // voice_direction: the (modulated) increment is negated (synth.c:224)
 };
 
 // NOCLAMP: the caller guarantees 0 <= lo <= pos < hi <= table_size (TAME loops), so the reference's
@@ -194,6 +195,7 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     if (r.fm_addr >= 0) inc = r.inc + r.fm_k * (ms * r.fm_depth);        // synth.c:551-554
     r.am_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.am_addr, 0), mine));
     r.pm_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.pm_addr, 0), mine));
+    if (r.rev) inc = -inc;                               // reverse playback, applied to the modulated increment
   }
   const float ph = fast_advance<TAME, STOPS>(r, inc);
   const float s = fast_fetch<TAB_LDS, INTERP, TAME && !STOPS>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
@@ -273,7 +275,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
     r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
     r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
-    r.stop = false; r.fin = false; r.hi_stop = 0.0f; r.fm_addr = -1; r.am_addr = -1; r.pm_addr = -1;
+    r.stop = false; r.fin = false; r.hi_stop = 0.0f; r.fm_addr = -1; r.am_addr = -1; r.pm_addr = -1; r.rev = false;
   }
 }
 
@@ -407,6 +409,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.fm_addr = -1; r.fm_k = 0.0f; r.fm_depth = 0.0f;
       r.am_addr = -1; r.pm_addr = -1; r.am_depth = 0.0f; r.pm_depth = 0.0f; r.am_prev = 0.0f; r.pm_prev = 0.0f;
       r.pan_dirty = false;
+      r.rev = STOPS && (flags & SKF_REVERSE);
       muted = (flags & SKF_MUTED) != 0;
       if (STOPS && (a.fast_mode & SKM_FM)) {
         const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
@@ -435,10 +438,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
       r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
       r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
-      r.stop = false; r.fm_addr = -1; r.am_addr = -1; r.pm_addr = -1;
+      r.stop = false; r.fm_addr = -1; r.am_addr = -1; r.pm_addr = -1; r.rev = false;
     }
-    // modulated lanes in this wave: no table windows, no tame shortcuts, no stalled-smoother skip
-    const bool any_fm = STOPS && __any(r.fm_addr >= 0 || r.am_addr != -1 || r.pm_addr != -1);
+    // modulated or reversed lanes in this wave: no table windows, no tame shortcuts, no stalled-smoother skip
+    const bool any_fm = STOPS && __any(r.fm_addr >= 0 || r.am_addr != -1 || r.pm_addr != -1 || r.rev);
     (void)any_fm;
     // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
     // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>

@@ -517,6 +517,9 @@ def _clean_fuzz_bank(rng):
         bank["voice_phase_inc"][wild] = (span[wild] * np.float32(1.7)).astype(np.float32)
     bank["voice_disconnect"][rng.random(n) < 0.03] = 1
     bank["voice_amp"][rng.random(n) < 0.03] = 0.0
+    if rng.random() < 0.4:                            # reverse playback on a random subset (extended instantiation)
+        bank["voice_direction"][rng.random(n) < 0.25] = 1
+        stops = True
     fm = rng.random() < 0.4                           # previous-frame FM: modulator above its carrier, same 64-voice group
     if fm:
         v = np.arange(n)
@@ -561,6 +564,57 @@ def test_clean_family_fuzz_vs_oracle(dev, seed):
         mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False, fast2=fast2)
         assert set(k) == {3 if fast2 else 1}, (k, recipe, stops)
         assert not state.rw_equal(ref_state), (state.rw_equal(ref_state), recipe, stops, fast2, interp)
+        assert rel_rms(mix, ref_mix) <= 1e-5
+
+
+@pytest.mark.parametrize("case", ["c4_pcm_oneshot", "c1_sine_adsr64", "c2_mixed_filter64"])
+def test_golden_case_on_the_specialised_kernel(dev, case):
+    """The reference's fixtures without stems, so that the bank takes the one-per-lane kernel: c4_pcm_oneshot is
+    forward / reverse / looped / reverse-looped one-shots, several finishing mid-block (the extended instantiation).
+    State after every segment bit-exact against the reference, mix within tolerance."""
+    g = gio.load(case)
+    for seg in g.segments:
+        db = dev.DeviceBank(seg.bank_in.n)
+        db.set_tables(g.tables)
+        db.upload(seg.bank_in)
+        db.set_globals(seg.g_in)
+        mix = np.zeros((seg.frames, 2), np.float32)
+        p = 0
+        while p < seg.frames:
+            n = min(seg.block, seg.frames - p)
+            mix[p:p + n], _ = db.render_host(n, 2, 0)
+            assert db.last_kernel() == 1, case
+            p += n
+        got = seg.bank_in.copy()
+        db.download(got)
+        db.close()
+        bad = got.rw_equal(gio.expected_out_bank(seg))
+        assert not bad, f"{case} seg{seg.index}: voice state differs {bad}"
+        assert rms(mix.astype(np.float64) - seg.mix.astype(np.float64)) <= MIX_RMS_TOL
+
+
+def test_reverse_playback_on_the_specialised_kernel(dev):
+    """`b1`: reversed loops and reversed one-shots (which finish at the loop start), with and without FM."""
+    n = 2048
+    bank, tables, g = banks.bank_c4(n)
+    rev = np.arange(n) % 3 == 1
+    bank["voice_direction"][rev] = 1
+    stop = np.arange(n) % 6 == 1                          # a subset of the reversed voices stops
+    bank["voice_one_shot"][stop] = 1
+    bank["voice_loop_enabled"][stop] = 0
+    size = bank["voice_table_size"].astype(np.float32)
+    bank["voice_phase"][stop] = np.minimum(size[stop] - 1.0, np.float32(3.0) + np.float32(9.0) * (np.arange(n)[stop] % 97))
+    car = np.arange(0, n, 8)
+    bank["voice_freq_mod_osc"][car] = car + 2
+    bank["voice_freq_mod_depth"][car] = np.float32(1.5)
+    bank["voice_freq_scale"][car] = np.float32(1.0)
+    segs = [(500, None), (77, _release_odd_voices), (900, None)]
+    for interp in (0, 1):
+        mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False)
+        ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+        assert k == [1] * len(segs), k
+        assert int(ref_state["voice_finished"].sum()) > 100
+        assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
         assert rel_rms(mix, ref_mix) <= 1e-5
 
 

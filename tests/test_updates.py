@@ -85,8 +85,8 @@ def actions_for_block(k, n, rng, D):
 
 
 def test_updates_without_ever_downloading(dev):
-    """40 blocks of mixed control actions on a 3000-voice filtered bank (specialised kernel); at block 12 a voice turns
-    to reverse playback (the bank needs the generic kernel), at block 20 it turns back."""
+    """40 blocks of mixed control actions on a 3000-voice filtered bank (specialised kernel); at block 12 a voice
+    switches sample & hold on (the bank needs the generic kernel), at block 20 it switches it off again."""
     D = dev
     n = 3000
     bank, tables, g = banks.bank_c2(n)
@@ -103,7 +103,7 @@ def test_updates_without_ever_downloading(dev):
         acts = actions_for_block(k, n, rng, D)
         if k in (12, 20):
             def flip(b, vs, now_, st, on=(k == 12)):
-                b["voice_direction"][vs] = 1 if on else 0
+                b["voice_sample_hold_max"][vs] = 3 if on else 0      # sample & hold: only the generic kernel has it
             acts.append(Action([77], D.DIRTY_PARAMS, flip))
         for a in acts:
             a.apply_to(truth, now)

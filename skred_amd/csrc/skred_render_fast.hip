@@ -48,6 +48,10 @@ struct FastRegs {
   float am_prev, pm_prev;       // this frame's modulator samples, fetched before the voice's own sample changes
   bool pan_dirty;               // pan modulation rewrote voice_pan_left / _right: the MISC plane is stored back
   bool rev;                     // voice_direction: the (modulated) increment is negated (synth.c:224)
+  // sample & hold (synth.c:560-571), bit-crush (synth.c:574), smoother off (synth.c:589)
+  int hold_max, hold_count, quant;
+  float hold;
+  bool nosmooth;
 };
 
 // NOCLAMP: the caller guarantees 0 <= lo <= pos < hi <= table_size (TAME loops), so the reference's
@@ -156,8 +160,12 @@ __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float
   // ---- smoother + apply (synth.c:589-593), pan (synth.c:603-604) ----
   if (EXT && r.am_addr != -1)                            // final = amp * env * mod (synth.c:583-588)
     gain = gain * ((r.am_addr == -2 ? s : r.am_prev) * r.am_depth);
-  if (!STALL) r.sgain += r.k * (gain - r.sgain);
-  s *= r.sgain;
+  if (EXT && r.nosmooth) {
+    s *= gain;                                           // voice_smoother_gain is left alone (synth.c:589-593)
+  } else {
+    if (!STALL) r.sgain += r.k * (gain - r.sgain);
+    s *= r.sgain;
+  }
   r.sample = s;
   if (EXT && r.pm_addr != -1 && !muted) {                // synth.c:597-602 (inside the `not disconnected` branch)
     const float q = (r.pm_addr == -2 ? s : r.pm_prev) * r.pm_depth;
@@ -198,7 +206,15 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     if (r.rev) inc = -inc;                               // reverse playback, applied to the modulated increment
   }
   const float ph = fast_advance<TAME, STOPS>(r, inc);
-  const float s = fast_fetch<TAB_LDS, INTERP, TAME && !STOPS>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
+  float s = fast_fetch<TAB_LDS, INTERP, TAME && !STOPS>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
+  if (STOPS && any_fm) {                                // (the same wave-uniform flag covers every extended feature)
+    if (r.hold_max) {                                    // sample & hold, synth.c:560-571
+      if (r.hold_count == 0) r.hold = s;
+      s = r.hold;
+      if (++r.hold_count >= r.hold_max) r.hold_count = 0;
+    }
+    if (r.quant) s = crush(s, r.quant);                  // synth.c:574
+  }
   fast_post<FILTER, ENV, STEADY, false, STOPS>(r, s, xn, xo, yn, yo, released, out_l, out_r, muted);
 }
 
@@ -257,8 +273,10 @@ __device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin
 __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs &r, int v, bool &dead, bool &silent,
                                             bool &sample_final, bool swapped, bool last_frame, const uint2 misc_xy) {
   if (r.fin) {
-    if (r.pan_dirty) {                                    // its pan, as modulated up to this frame
-      *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = make_uint4(misc_xy.x, misc_xy.y, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r));
+    if (r.pan_dirty || r.hold_max) {                      // its pan and hold state, as of this frame
+      *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) =
+          r.hold_max ? make_uint4(__float_as_uint(r.hold), (uint32_t)r.hold_count, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r))
+                     : make_uint4(misc_xy.x, misc_xy.y, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r));
       r.pan_dirty = false;
     }
     uint4 s0, s1;
@@ -276,6 +294,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
     r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
     r.stop = false; r.fin = false; r.hi_stop = 0.0f; r.fm_addr = -1; r.am_addr = -1; r.pm_addr = -1; r.rev = false;
+    r.hold_max = 0; r.quant = 0; r.nosmooth = false;
   }
 }
 
@@ -410,6 +429,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.am_addr = -1; r.pm_addr = -1; r.am_depth = 0.0f; r.pm_depth = 0.0f; r.am_prev = 0.0f; r.pm_prev = 0.0f;
       r.pan_dirty = false;
       r.rev = STOPS && (flags & SKF_REVERSE);
+      r.hold_max = STOPS ? (int)(tab.w >> 8) : 0;
+      r.quant = STOPS ? (int)(tab.w & 0xFFu) : 0;
+      r.hold = __uint_as_float(s2.x); r.hold_count = (int)s2.y;
+      r.nosmooth = STOPS && !(flags & SKF_SMOOTH);
       muted = (flags & SKF_MUTED) != 0;
       if (STOPS && (a.fast_mode & SKM_FM)) {
         const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
@@ -439,9 +462,12 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
       r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
       r.stop = false; r.fm_addr = -1; r.am_addr = -1; r.pm_addr = -1; r.rev = false;
+      r.hold_max = 0; r.quant = 0; r.nosmooth = false;
     }
-    // modulated or reversed lanes in this wave: no table windows, no tame shortcuts, no stalled-smoother skip
-    const bool any_fm = STOPS && __any(r.fm_addr >= 0 || r.am_addr != -1 || r.pm_addr != -1 || r.rev);
+    // lanes with any extended feature but stopping (modulated, reversed, sample & hold, crush, smoother off) in this
+    // wave: no table windows, no tame shortcuts, no stalled-smoother skip
+    const bool any_fm = STOPS && __any(r.fm_addr >= 0 || r.am_addr != -1 || r.pm_addr != -1 || r.rev || r.hold_max != 0 ||
+                                       r.quant != 0 || r.nosmooth);
     (void)any_fm;
     // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
     // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>
@@ -527,7 +553,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
     } else if (!sample_final) {
       reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][v])[2] = 0u;
     }
-    if (STOPS && r.pan_dirty)           // pan modulation rewrote voice_pan_left / _right (synth.c:600-601)
+    if (STOPS && !dead && r.hold_max)   // sample & hold state (and the pan next to it)
+      *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = make_uint4(__float_as_uint(r.hold), (uint32_t)r.hold_count, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r));
+    else if (STOPS && r.pan_dirty)      // pan modulation rewrote voice_pan_left / _right (synth.c:600-601)
       *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = make_uint4(misc_xy.x, misc_xy.y, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r));
     first_pass = false;
   }

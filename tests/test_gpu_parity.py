@@ -520,6 +520,11 @@ def _clean_fuzz_bank(rng):
     if rng.random() < 0.4:                            # reverse playback on a random subset (extended instantiation)
         bank["voice_direction"][rng.random(n) < 0.25] = 1
         stops = True
+    if rng.random() < 0.4:                            # sample & hold, crush, smoother off
+        bank["voice_sample_hold_max"][rng.random(n) < 0.1] = int(rng.integers(1, 9))
+        bank["voice_quantize"][rng.random(n) < 0.1] = int(rng.integers(1, 14))
+        bank["voice_smoother_enable"][rng.random(n) < 0.1] = 0
+        stops = True
     fm = rng.random() < 0.4                           # previous-frame FM: modulator above its carrier, same 64-voice group
     if fm:
         v = np.arange(n)
@@ -618,9 +623,32 @@ def test_reverse_playback_on_the_specialised_kernel(dev):
         assert rel_rms(mix, ref_mix) <= 1e-5
 
 
+def test_hold_crush_and_unsmoothed_voices_on_the_specialised_kernel(dev):
+    """`h` (sample & hold), `q` (bit-crush: the +0.5 is a double add, synth.c:343) and `s0` (amp smoother off) on the
+    one-per-lane kernel's extended instantiation, alone and combined, with a stopping voice among them."""
+    n = 2048
+    bank, tables, g = banks.bank_c2(n)
+    v = np.arange(n)
+    bank["voice_sample_hold_max"][v % 5 == 1] = 1 + (v[v % 5 == 1] % 7)
+    bank["voice_quantize"][v % 7 == 2] = 1 + (v[v % 7 == 2] % 12)
+    bank["voice_smoother_enable"][v % 9 == 3] = 0
+    stop = v % 37 == 4
+    bank["voice_one_shot"][stop] = 1
+    bank["voice_loop_enabled"][stop] = 0
+    segs = [(333, None), (100, _release_odd_voices), (800, None)]
+    for interp in (0, 1):
+        mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False)
+        gmix, gstate, kg = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=True)
+        ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+        assert k == [1] * len(segs) and kg == [0] * len(segs), (k, kg)
+        assert not gstate.rw_equal(ref_state), gstate.rw_equal(ref_state)
+        assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
+        assert rel_rms(mix, ref_mix) <= 1e-5
+
+
 def test_exotic_voice_forces_generic_kernel(dev):
     bank, tables, g = banks.bank_c2(512)
-    bank["voice_sample_hold_max"][5] = 3
+    bank["voice_wave_table_index"][5] = 6           # w6, the noise source
     _, _, k = _run_scenario(dev, bank, tables, g, 0, [(64, None)], force_generic=False)
     assert k == [0]
 

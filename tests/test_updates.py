@@ -86,7 +86,7 @@ def actions_for_block(k, n, rng, D):
 
 def test_updates_without_ever_downloading(dev):
     """40 blocks of mixed control actions on a 3000-voice filtered bank (specialised kernel); at block 12 a voice
-    switches sample & hold on (the bank needs the generic kernel), at block 20 it switches it off again."""
+    switches to the noise source (the bank needs the generic kernel), at block 20 it switches back."""
     D = dev
     n = 3000
     bank, tables, g = banks.bank_c2(n)
@@ -103,7 +103,7 @@ def test_updates_without_ever_downloading(dev):
         acts = actions_for_block(k, n, rng, D)
         if k in (12, 20):
             def flip(b, vs, now_, st, on=(k == 12)):
-                b["voice_sample_hold_max"][vs] = 3 if on else 0      # sample & hold: only the generic kernel has it
+                b["voice_wave_table_index"][vs] = 6 if on else 0     # w6, the noise source: only the generic kernel has it
             acts.append(Action([77], D.DIRTY_PARAMS, flip))
         for a in acts:
             a.apply_to(truth, now)

@@ -69,11 +69,13 @@ enum {
 
 /* fast_mode word (host -> launcher) */
 #define SKM_FAST        (1u << 0)  /* bank qualifies for sk_render_fast_kernel (see skred_bank.c:classify) */
-#define SKM_FILTER_ALL  (1u << 1)  /* every live voice runs the biquad (else: none does) */
-#define SKM_ENV_ALL     (1u << 2)  /* every live voice uses the amp envelope (else: none does) */
+#define SKM_FILTER_ALL  (1u << 1)  /* every live voice runs the biquad (with SKM_MIXED: some do) */
+#define SKM_ENV_ALL     (1u << 2)  /* every live voice uses the amp envelope (with SKM_MIXED: some do) */
 #define SKM_TWO_PER_LANE (1u << 3) /* large bank: sk_render_fast2_kernel (two voices per lane, packed fp32) */
 #define SKM_FM          (1u << 5)  /* some voice is frequency-modulated by a higher-indexed voice of its 64-voice group and
                                       nothing else is modulated (sk_render_fast_kernel<STOPS>: previous-frame exchange by ds_bpermute) */
+#define SKM_MIXED       (1u << 6)  /* the biquad and / or the envelope is used by some voices only: per-lane flags
+                                      (sk_render_fast_kernel's extended instantiation) */
 #define SKM_STOPS       (1u << 4)  /* some voice is a forward one-shot that finishes at its table end (sk_render_fast_kernel<STOPS>) */
 
 #define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */

@@ -52,6 +52,9 @@ struct FastRegs {
   int hold_max, hold_count, quant;
   float hold;
   bool nosmooth;
+  // banks in which only some voices run the biquad / the envelope
+  bool filt, use_env;
+  float ox1, ox2, oy1, oy2;     // delay line of an UNfiltered voice as loaded: it is stored back untouched
 };
 
 // NOCLAMP: the caller guarantees 0 <= lo <= pos < hi <= table_size (TAME loops), so the reference's
@@ -128,13 +131,15 @@ __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float
     y = y + r.b2 * xo;
     y = y - r.a1 * yn;
     y = y - r.a2 * yo;
-    xo = s;
-    yo = y;
-    s = y;
+    if (!EXT || r.filt) {                           // (EXT: a voice with filter_mode 0 passes through, synth.c:577)
+      xo = s;
+      yo = y;
+      s = y;
+    }
   }
   // ---- envelope (amp_envelope_step, synth.c:398-431) and gain (synth.c:580-588) ----
   float gain;
-  if (!ENV) {
+  if (!ENV || (EXT && !r.use_env)) {
     gain = r.amp;                                   // amp * 1.0f * 1.0f
   } else if (STEADY) {
     gain = r.gain_sustain;                          // e = sustain_level on every lane
@@ -283,6 +288,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     s0.x = __float_as_uint(r.phase); s0.y = __float_as_uint(r.sgain);
     s0.z = __float_as_uint(swapped ? r.x2 : r.x1); s0.w = __float_as_uint(swapped ? r.x1 : r.x2);
     s1.x = __float_as_uint(swapped ? r.y2 : r.y1); s1.y = __float_as_uint(swapped ? r.y1 : r.y2);
+    if (!r.filt) { s0.z = __float_as_uint(r.ox1); s0.w = __float_as_uint(r.ox2); s1.x = __float_as_uint(r.oy1); s1.y = __float_as_uint(r.oy2); }
     s1.z = last_frame ? __float_as_uint(r.sample) : 0u;    // a later frame of this launch would have zeroed it
     s1.w = r.rw | SKR_FINISHED;
     *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
@@ -329,10 +335,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post<FILTER, ENV, true, STALL_>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);            \
+      fast_post<FILTER, ENV, true, STALL_, STOPS>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);            \
       if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); \
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post<FILTER, ENV, true, STALL_>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
+      fast_post<FILTER, ENV, true, STALL_, STOPS>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
       if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); \
       { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
     }                                                                                                    \
@@ -428,6 +434,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.fm_addr = -1; r.fm_k = 0.0f; r.fm_depth = 0.0f;
       r.am_addr = -1; r.pm_addr = -1; r.am_depth = 0.0f; r.pm_depth = 0.0f; r.am_prev = 0.0f; r.pm_prev = 0.0f;
       r.pan_dirty = false;
+      r.filt = !STOPS || (flags & SKF_FILTER);
+      r.use_env = !STOPS || (flags & SKF_USE_ENV);
+      r.ox1 = r.x1; r.ox2 = r.x2; r.oy1 = r.y1; r.oy2 = r.y2;
+      if (ENV && !r.use_env) { r.gain_sustain = r.amp; released = false; }
       r.rev = STOPS && (flags & SKF_REVERSE);
       r.hold_max = STOPS ? (int)(tab.w >> 8) : 0;
       r.quant = STOPS ? (int)(tab.w & 0xFFu) : 0;
@@ -484,12 +494,12 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
         const uint64_t d_on = base - t_start;
         const uint64_t d_off = base - t_release;
         const uint64_t lim = (1ull << 24) - (uint64_t)SK_CHUNK - 2;   // x + 1.0f stays exact below 2^24
-        exact = __all(dead || ((d_on < lim) && (!released || d_off < lim)));
+        exact = __all(dead || !r.use_env || ((d_on < lim) && (!released || d_off < lim)));
         r.tf = (float)d_on;
         r.trf = released ? (float)d_off : 0.0f;
         // sustain is absorbing within a launch: the clock only grows and note-off arrives between launches
         const float tf_first = (float)(d_on + 1);
-        steady = __all(dead || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
+        steady = __all(dead || !r.use_env || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
       }
       if (STOPS && (!ENV || steady)) {
         int j = 0;
@@ -544,6 +554,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
     // store the recurrences; skipped voices keep their state and get voice_sample = 0 (synth.c:532,538)
     if (!dead) {
       uint4 s0, s1;
+      if (STOPS && !r.filt) { r.x1 = r.ox1; r.x2 = r.ox2; r.y1 = r.oy1; r.y2 = r.oy2; }
       s0.x = __float_as_uint(r.phase); s0.y = __float_as_uint(r.sgain);
       s0.z = __float_as_uint(r.x1);    s0.w = __float_as_uint(r.x2);
       s1.x = __float_as_uint(r.y1);    s1.y = __float_as_uint(r.y2);
@@ -569,7 +580,7 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
   const bool tab_lds = args->lds_table_floats > 0;
   if (!tab_lds) lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);   // one table window per wave
   dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
-  const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM)) ? 16 : 0) |   /* the extended instantiation: stops and / or FM */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
+  const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
 #define SK_FAST_CASE(K, T, F, E, I)                                                                                        \
   case K: hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false>), grid, block, lds_bytes, stream, *args); break;     \

@@ -491,16 +491,21 @@ def _clean_fuzz_bank(rng):
     recipe = ["c2", "c4"][int(rng.integers(0, 2))]
     n = int(rng.integers(130, 2200))
     bank, tables, g = banks.RECIPES[recipe](n)
-    if rng.random() < 0.5:
+    mixed = rng.random() < 0.35                       # filter / envelope on some voices only (extended instantiation)
+    if rng.random() < 0.5 and not mixed:
         bank["voice_filter_mode"][:] = 0
     elif recipe == "c4":
         bank["voice_filter_mode"][:] = 1 + (np.arange(n) % 4)
         c = banks.biquad_coeffs(bank["voice_filter_mode"], 200.0 + 37.0 * (np.arange(n) % 150), np.full(n, 0.9, np.float32), 48000)
         for k in ("b0", "b1", "b2", "a1", "a2"):
             bank["voice_filter"][k] = c[k]
-    if rng.random() < 0.4:
+    if rng.random() < 0.4 and not mixed:
         bank["voice_use_amp_envelope"][:] = 0
     stops = rng.random() < 0.5
+    if mixed:
+        bank["voice_filter_mode"][rng.random(n) < 0.4] = 0
+        bank["voice_use_amp_envelope"][rng.random(n) < 0.4] = 0
+        stops = True
     if stops:
         sel = rng.random(n) < 0.3
         bank["voice_one_shot"][sel] = 1
@@ -621,6 +626,34 @@ def test_reverse_playback_on_the_specialised_kernel(dev):
         assert int(ref_state["voice_finished"].sum()) > 100
         assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
         assert rel_rms(mix, ref_mix) <= 1e-5
+
+
+@pytest.mark.parametrize("recipe,interp", [("c2", 0), ("c4", 1)])
+def test_partly_filtered_partly_enveloped_bank_on_the_specialised_kernel(dev, recipe, interp):
+    """A bank in which only some voices run the biquad and only some use the envelope (the usual case outside
+    benchmarks): per-lane flags in the one-per-lane kernel's extended instantiation.  An unfiltered voice's delay line
+    and an un-enveloped voice's is_active must come back untouched."""
+    n = 3000
+    bank, tables, g = banks.RECIPES[recipe](n)
+    v = np.arange(n)
+    if recipe == "c4":
+        bank["voice_filter_mode"][:] = 1 + (v % 4)
+        c = banks.biquad_coeffs(bank["voice_filter_mode"], 300.0 + 29.0 * (v % 200), np.full(n, 1.1, np.float32), 48000)
+        for k in ("b0", "b1", "b2", "a1", "a2"):
+            bank["voice_filter"][k] = c[k]
+    bank["voice_filter_mode"][v % 3 == 0] = 0
+    f = bank["voice_filter"]
+    f["x1"][:] = (0.01 * (v % 17)).astype(np.float32)      # recognisable delay-line content everywhere
+    f["y2"][:] = (-0.02 * (v % 13)).astype(np.float32)
+    bank["voice_use_amp_envelope"][v % 4 == 1] = 0
+    segs = [(301, None), (333, _release_odd_voices), (1001, None), (64, None)]
+    mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False)
+    gmix, gstate, kg = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=True)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert k == [1] * len(segs) and kg == [0] * len(segs), (k, kg)
+    assert not gstate.rw_equal(ref_state), gstate.rw_equal(ref_state)
+    assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
+    assert rel_rms(mix, ref_mix) <= 1e-5
 
 
 def test_hold_crush_and_unsmoothed_voices_on_the_specialised_kernel(dev):

@@ -322,8 +322,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     float l0, r0, l1, r1;                                                                                \
     const float sa_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
     const float sb_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
-    fast_post<FILTER, ENV, true>(r, sa_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);                      \
-    fast_post<FILTER, ENV, true>(r, sb_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);                      \
+    fast_post<FILTER, ENV, true, false, STOPS>(r, sa_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);        \
+    fast_post<FILTER, ENV, true, false, STOPS>(r, sb_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);        \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
@@ -478,6 +478,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
     // wave: no table windows, no tame shortcuts, no stalled-smoother skip
     const bool any_fm = STOPS && __any(r.fm_addr >= 0 || r.am_addr != -1 || r.pm_addr != -1 || r.rev || r.hold_max != 0 ||
                                        r.quant != 0 || r.nosmooth);
+    const bool any_stop = STOPS && __any(r.stop);         // (a lane that finishes turns its flag off)
+    (void)any_stop;
     (void)any_fm;
     // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
     // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>
@@ -501,7 +503,16 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
         const float tf_first = (float)(d_on + 1);
         steady = __all(dead || !r.use_env || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
       }
-      if (STOPS && (!ENV || steady)) {
+      // a stopping voice that cannot reach its table end within this chunk (forward, unmodulated: phase + 64*inc,
+      // rounding included, stays below it) needs no per-frame finish test yet
+      const bool stop_near = STOPS && any_stop && __any(r.stop && !(r.phase + (float)SK_CHUNK * r.inc + 2.0f < r.hi));
+      if (STOPS && (!ENV || steady) && tame && !any_fm && !stop_near && TAB_LDS) {
+        // an extended bank, but nothing in THIS wave needs the frame loop now (e.g. only some voices filtered, or one-shots
+        // still far from their end): frame pairs
+        int j = 0;
+        for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
+        if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
+      } else if (STOPS && (!ENV || steady)) {
         int j = 0;
         if (!TAB_LDS && tame && !any_fm) {   // a voice about to finish is `direct` in its window block; the block checks per frame
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)

@@ -366,7 +366,7 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   /* two voices per lane pay off for large LDS-table banks (packed fp32); banks whose tables stay in L2 / HBM do
    * better with one voice per lane at every size measured (2^16 .. 2^20: twice the waves to hide the window
    * refills behind) unless the caller set the threshold explicitly */
-  if ((a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) && b->n_voices >= b->fast2_min_voices &&
+  if ((a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_STOPS | SKM_FM)) && b->n_voices >= b->fast2_min_voices &&
       (a.lds_table_floats > 0 || b->fast2_min_user))
     a.fast_mode |= SKM_TWO_PER_LANE;        /* (voices that finish mid-launch are handled by the one-per-lane kernel only) */
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC

@@ -31,6 +31,11 @@ struct Fast2Regs {
   int toff4[2], tsize_m1[2];
   v2f k, b0, b1, b2, a1, a2, gain_const;   // gain_const: gain of a constant-level lane
   v2f pan_lr[2];                           // (pan_left, pan_right) of voice 0 / voice 1: packed by channel, not by voice
+  // MIXED instantiations: banks in which only some voices run the biquad / use the envelope
+  bool filt[2];                            // this voice runs the biquad
+  bool fake_active[2];                     // an un-enveloped voice is rendered as a held note at level 1 (amp * (1*1) == amp):
+                                           // its ENV_ACTIVE bit was forced on for the launch and is taken back at the store
+  v2f ox1, ox2, oy1, oy2;                  // delay lines as loaded: an unfiltered voice gets its own back untouched
   v2f phase, sgain, x1, x2, y1, y2, sample;
   uint32_t rw[2];
 };
@@ -165,7 +170,7 @@ __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, cons
 // EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
 // with the short exact division; 2 general; 3 constant gain AND the amp smoother has stalled in every lane
 // (fast2_smoother_stalled: its update no longer changes it, so it is skipped).  TAME: see fast_frame.
-template <bool FILTER, int EM, bool TAME>
+template <bool FILTER, int EM, bool TAME, bool MIXED = false>
 __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
                                            const bool rel0, const bool rel1, const bool silent0,
                                            const bool silent1, float &out_l, float &out_r) {
@@ -176,9 +181,15 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
     y = y + r.b2 * xo;
     y = y - r.a1 * yn;
     y = y - r.a2 * yo;
-    xo = s;
-    yo = y;
-    s = y;
+    if (MIXED) {                                       // filter_mode 0: the sample passes, the delay line rests (synth.c:577)
+      xo.x = r.filt[0] ? s.x : xo.x; xo.y = r.filt[1] ? s.y : xo.y;
+      yo.x = r.filt[0] ? y.x : yo.x; yo.y = r.filt[1] ? y.y : yo.y;
+      s.x = r.filt[0] ? y.x : s.x;   s.y = r.filt[1] ? y.y : s.y;
+    } else {
+      xo = s;
+      yo = y;
+      s = y;
+    }
   }
   // ---- gain ----
   v2f gain;
@@ -227,13 +238,13 @@ __device__ __forceinline__ bool fast2_smoother_stalled(const Fast2Regs &r) {
   return __all(__float_as_uint(nxt.x) == __float_as_uint(r.sgain.x) && __float_as_uint(nxt.y) == __float_as_uint(r.sgain.y));
 }
 
-template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP>
+template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP, bool MIXED = false>
 __device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
                                             const bool rel0, const bool rel1, const bool silent0,
                                             const bool silent1, const char *lds_tab,
                                             const char *__restrict__ glb_tab, float &out_l, float &out_r) {
   const v2f s = fast2_osc<TAB_LDS, TAME, INTERP>(r, lds_tab, glb_tab);
-  fast2_post<FILTER, EM, TAME>(r, e, s, xn, xo, yn, yo, rel0, rel1, silent0, silent1, out_l, out_r);
+  fast2_post<FILTER, EM, TAME, MIXED>(r, e, s, xn, xo, yn, yo, rel0, rel1, silent0, silent1, out_l, out_r);
 }
 
 // ---- table windows for pools that do not fit in LDS (PCM banks) ----
@@ -320,15 +331,15 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
 #define SK_FAST2_ONE(J, EM_, TAME_)                                                                      \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l, rr);   \
+    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP, MIXED>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l, rr);   \
     SK_REDUCE_AND_STORE(J)                                                                               \
     { v2f t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }                        \
   }
 #define SK_FAST2_PAIR(J, EM_, TAME_)                                                                     \
   {                                                                                                      \
     float l0, r0, l1, r1;                                                                                \
-    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);  \
-    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);  \
+    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP, MIXED>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);  \
+    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP, MIXED>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);  \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
 // Eight frames (J..J+7) with the cross-lane sum through LDS instead of the VALU: every lane parks its (L,R) of
@@ -349,9 +360,9 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const v2f s1_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                              \
-      fast2_post<FILTER, EM_, true>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
+      fast2_post<FILTER, EM_, true, MIXED>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
       if (q_ < 6) s0_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                            \
-      fast2_post<FILTER, EM_, true>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
+      fast2_post<FILTER, EM_, true, MIXED>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
       xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
       xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
     }                                                                                                    \
@@ -381,9 +392,9 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const v2f s0_ = fast2_osc_win<INTERP>(r, wr_, win, lane, glb_tab);                                  \
-      fast2_post<FILTER, EM_, true>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
+      fast2_post<FILTER, EM_, true, MIXED>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
       const v2f s1_ = fast2_osc_win<INTERP>(r, wr_, win, lane, glb_tab);                                  \
-      fast2_post<FILTER, EM_, true>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
+      fast2_post<FILTER, EM_, true, MIXED>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
       SK_REDUCE4_AND_STORE((J) + q_)                                                                     \
     }                                                                                                    \
   }
@@ -426,7 +437,7 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
   wsum = (wsum == wsum0) ? wsum0 + NW * SK_CHUNK : wsum0;
 
 // load the two voices of this lane (vbase + lane, vbase + 64 + lane); returns whether the wave is tame
-template <bool FILTER, bool ENV>
+template <bool FILTER, bool ENV, bool MIXED>
 __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase, int lane, Fast2Regs &r,
                                            Env2Regs &e, bool dead[2], bool silent[2], bool released[2],
                                            uint64_t t_start[2], uint64_t t_release[2], int vidx[2]) {
@@ -472,6 +483,17 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase,
       t_release[c] = ((uint64_t)es.w << 32) | es.z;
       released[c] = t_release[c] != 0;                 // synth.c:417
     }
+    r.filt[c] = !MIXED || (flags & SKF_FILTER);
+    r.fake_active[c] = false;
+    if (MIXED && ENV && !(flags & SKF_USE_ENV)) {
+      // no envelope on this voice: final = amp * 1.0f (synth.c:580-582).  Rendered as a note held at level 1 with
+      // velocity 1 since "now": amp * (1 * 1) is the same float, the clocks stay small, the stage never changes
+      e.att[c] = e.dec[c] = e.attdec[c] = e.rel[c] = 0.0f;
+      e.susv[c] = 1.0f; e.omsv[c] = 0.0f; e.velv[c] = 1.0f;
+      t_start[c] = a.count0; t_release[c] = 0; released[c] = false;
+      r.fake_active[c] = !(r.rw[c] & SKR_ENV_ACTIVE);
+      r.rw[c] |= SKR_ENV_ACTIVE;
+    }
     dead[c] = (r.rw[c] & SKR_FINISHED) || e.ampv[c] == 0.0f || (flags & SKF_INERT);
     silent[c] = dead[c] || (flags & SKF_MUTED);
     if (dead[c]) {   // never stored back: inert numbers -> exact zeros, table index 0 (see sk_render_fast_kernel)
@@ -485,6 +507,7 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase,
   }
   r.span = r.hi - r.lo;
   r.span2 = r.span + r.span;
+  if (MIXED) { r.ox1 = r.x1; r.ox2 = r.x2; r.oy1 = r.y1; r.oy2 = r.y2; }
   bool tame_lane = true;
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -494,6 +517,7 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase,
   return __all(tame_lane);
 }
 
+template <bool MIXED>
 __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fast2Regs &r, const bool dead[2],
                                             const int vidx[2]) {
 #pragma unroll
@@ -501,10 +525,11 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
     const int v = vidx[c];
     if (!dead[c]) {
       uint4 s0, s1;
+      const bool keep = MIXED && !r.filt[c];           // an unfiltered voice's delay line goes back as it came
       s0.x = __float_as_uint(r.phase[c]); s0.y = __float_as_uint(r.sgain[c]);
-      s0.z = __float_as_uint(r.x1[c]);    s0.w = __float_as_uint(r.x2[c]);
-      s1.x = __float_as_uint(r.y1[c]);    s1.y = __float_as_uint(r.y2[c]);
-      s1.z = __float_as_uint(r.sample[c]); s1.w = r.rw[c];
+      s0.z = __float_as_uint(keep ? r.ox1[c] : r.x1[c]);    s0.w = __float_as_uint(keep ? r.ox2[c] : r.x2[c]);
+      s1.x = __float_as_uint(keep ? r.oy1[c] : r.y1[c]);    s1.y = __float_as_uint(keep ? r.oy2[c] : r.y2[c]);
+      s1.z = __float_as_uint(r.sample[c]); s1.w = (MIXED && r.fake_active[c]) ? (r.rw[c] & ~SKR_ENV_ACTIVE) : r.rw[c];
       *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
       *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;
     } else {
@@ -548,7 +573,7 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
 // scale with the wave count).
 template <bool TAB_LDS> struct Fast2Shape { static constexpr int NW = TAB_LDS ? 8 : 4; };
 
-template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP>
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED>
 __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
   constexpr int NW = Fast2Shape<TAB_LDS>::NW;
   SK_FAST2_PROLOGUE()
@@ -559,7 +584,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     bool dead[2], silent[2], released[2];
     uint64_t t_start[2], t_release[2];
     int vidx[2];
-    const bool tame = fast2_load<FILTER, ENV>(a, g * (NW * 128) + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    const bool tame = fast2_load<FILTER, ENV, MIXED>(a, g * (NW * 128) + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
     if (ENV) {
@@ -588,7 +613,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
       SK_FAST2_CHUNK(0)
       SK_FAST2_FLUSH(!first_pass)
     }
-    fast2_store(a, r, dead, vidx);
+    fast2_store<MIXED>(a, r, dead, vidx);
     first_pass = false;
   }
   if (first_pass) {   // every group of this workgroup was deferred: its partial-mix row must still exist
@@ -600,7 +625,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
 #ifndef SK_ENV2_MIN_WAVES
 #define SK_ENV2_MIN_WAVES 3      /* the envelope machinery wants ~170 VGPRs: 3 waves per SIMD measured best (2: no spills, 4: 220 B of scratch) */
 #endif
-template <bool TAB_LDS, bool FILTER, int INTERP>
+template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
   constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
   SK_FAST2_PROLOGUE()
@@ -612,7 +637,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
     bool dead[2], silent[2], released[2];
     uint64_t t_start[2], t_release[2];
     int vidx[2];
-    const bool tame = fast2_load<FILTER, true>(a, g * 512 + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    const bool tame = fast2_load<FILTER, true, MIXED>(a, g * 512 + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
     bool all_const_from_here = false;
@@ -665,9 +690,9 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
             for (int q = 0; q < 8; q += 2) {
               float l0, r0, l1, r1;
               e.tf[0] += 1.0f; e.trf[0] += 1.0f; e.tf[1] += 1.0f; e.trf[1] += 1.0f;
-              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);
+              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP, MIXED>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);
               e.tf[0] += 1.0f; e.trf[0] += 1.0f; e.tf[1] += 1.0f; e.trf[1] += 1.0f;
-              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);
+              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP, MIXED>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);
               { const int J_ = jb + q; wave_sum4_to_lane63(l0, r0, l1, r1);
                 if (lane == 63) *reinterpret_cast<float4 *>(&wsum[wave * SK_CHUNK + J_]) = make_float4(l0, r0, l1, r1); }
             }
@@ -684,7 +709,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
       }
       SK_FAST2_FLUSH(true)
     }
-    fast2_store(a, r, dead, vidx);
+    fast2_store<MIXED>(a, r, dead, vidx);
   }
 }
 
@@ -705,13 +730,20 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
   const size_t lds_fast2 = tab_bytes + (size_t)nw * (2 * SK_CHUNK * sizeof(float2) + per_wave);
   const size_t lds_env2 = tab_bytes + (size_t)4 * (2 * SK_CHUNK * sizeof(float2) + per_wave);
   dim3 grid((unsigned)n_workgroups), block((unsigned)nw * 64), block_env(SK_GROUP);
+  const bool mixed = (args->fast_mode & SKM_MIXED) != 0;     // filter / envelope on some voices only: per-lane flags
   const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
-    hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I>), grid, block, lds_fast2, stream, *args);    \
-    if (E && !args->skip_env2)                                                                          \
-      hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I>), grid, block_env, lds_env2, stream, *args);   \
+    if (mixed) {                                                                                        \
+      hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, true>), grid, block, lds_fast2, stream, *args);  \
+      if (E && !args->skip_env2)                                                                        \
+        hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, true>), grid, block_env, lds_env2, stream, *args); \
+    } else {                                                                                            \
+      hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, false>), grid, block, lds_fast2, stream, *args); \
+      if (E && !args->skip_env2)                                                                        \
+        hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, false>), grid, block_env, lds_env2, stream, *args); \
+    }                                                                                                   \
     break;
   switch (key) {
     SK_FAST2_CASE(0, false, false, false, 0) SK_FAST2_CASE(1, false, false, false, 1)

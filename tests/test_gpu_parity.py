@@ -502,10 +502,9 @@ def _clean_fuzz_bank(rng):
     if rng.random() < 0.4 and not mixed:
         bank["voice_use_amp_envelope"][:] = 0
     stops = rng.random() < 0.5
-    if mixed:
+    if mixed:                                         # (both specialised kernel families carry per-lane flags for this)
         bank["voice_filter_mode"][rng.random(n) < 0.4] = 0
         bank["voice_use_amp_envelope"][rng.random(n) < 0.4] = 0
-        stops = True
     if stops:
         sel = rng.random(n) < 0.3
         bank["voice_one_shot"][sel] = 1
@@ -649,11 +648,13 @@ def test_partly_filtered_partly_enveloped_bank_on_the_specialised_kernel(dev, re
     segs = [(301, None), (333, _release_odd_voices), (1001, None), (64, None)]
     mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False)
     gmix, gstate, kg = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=True)
+    mix2, state2, k2 = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False, fast2=True)
     ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
-    assert k == [1] * len(segs) and kg == [0] * len(segs), (k, kg)
+    assert k == [1] * len(segs) and kg == [0] * len(segs) and k2 == [3] * len(segs), (k, kg, k2)
     assert not gstate.rw_equal(ref_state), gstate.rw_equal(ref_state)
     assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
-    assert rel_rms(mix, ref_mix) <= 1e-5
+    assert not state2.rw_equal(ref_state), state2.rw_equal(ref_state)      # the two-per-lane kernels (MIXED instantiation)
+    assert rel_rms(mix, ref_mix) <= 1e-5 and rel_rms(mix2, ref_mix) <= 1e-5
 
 
 def test_hold_crush_and_unsmoothed_voices_on_the_specialised_kernel(dev):

@@ -66,6 +66,14 @@ def actions_for_block(k, n, rng, D):
             f[name][vs] = c[name]
     out.append(Action(v[4:5], D.DIRTY_PARAMS, set_filter))
 
+    def toggle_filter(b, vs, now, st):                          # `J0` / `J1`: the bank becomes (or stops being) partly filtered
+        b["voice_filter_mode"][vs] = np.where(b["voice_filter_mode"][vs] != 0, 0, 1)
+    out.append(Action(v[1:2], D.DIRTY_PARAMS, toggle_filter))
+
+    def toggle_env(b, vs, now, st):                             # amp_set clears voice_use_amp_envelope (synth.c:829-833)
+        b["voice_use_amp_envelope"][vs] = 0 if k % 2 else 1
+    out.append(Action(v[2:3], D.DIRTY_PARAMS, toggle_env))
+
     def trigger(b, vs, now, st):                                # voice_trigger: osc_trigger + amp_envelope_trigger
         b["voice_finished"][vs] = 0
         b["voice_phase"][vs] = np.where(b["voice_loop_enabled"][vs] != 0, b["voice_loop_start_f"][vs], np.float32(0.0))

@@ -170,7 +170,7 @@ __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, cons
 // EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
 // with the short exact division; 2 general; 3 constant gain AND the amp smoother has stalled in every lane
 // (fast2_smoother_stalled: its update no longer changes it, so it is skipped).  TAME: see fast_frame.
-template <bool FILTER, int EM, bool TAME, bool MIXED = false>
+template <bool FILTER, int EM, bool TAME, bool MIXED = false, bool MUTESEL = false>
 __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
                                            const bool rel0, const bool rel1, const bool silent0,
                                            const bool silent1, float &out_l, float &out_r) {
@@ -217,7 +217,8 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
   r.sample = s;
   // ---- pan, lane-local sum of the two voices ----
   v2f so = s;
-  if (!TAME) {          // TAME loops run only when no live lane is muted (dead lanes already yield exact zeros)
+  if (!TAME || MUTESEL) {   // plain TAME loops run only when no live lane is muted (dead lanes already yield exact zeros);
+                            // MUTESEL: a tame wave with muted live lanes -- their samples are replaced by zero here
     so.x = silent0 ? 0.0f : s.x;
     so.y = silent1 ? 0.0f : s.y;
   }
@@ -352,7 +353,7 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#define SK_FAST2_LDS_BLOCK_Z(J, EM_, LOZ_)                                                                       \
+#define SK_FAST2_LDS_BLOCK_Z(J, EM_, LOZ_, MUTE_)                                                                       \
   {                                                                                                      \
     /* software pipeline: the table gather of the NEXT frame is issued before the biquad/gain chain of the   \
        current one (the source order matters: the compiler may not move an LDS read above the tile write) */  \
@@ -360,9 +361,9 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const v2f s1_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                              \
-      fast2_post<FILTER, EM_, true, MIXED>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
+      fast2_post<FILTER, EM_, true, MIXED, MUTE_>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
       if (q_ < 6) s0_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                            \
-      fast2_post<FILTER, EM_, true, MIXED>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
+      fast2_post<FILTER, EM_, true, MIXED, MUTE_>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
       xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
       xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
     }                                                                                                    \
@@ -383,7 +384,10 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
   }
 // `loz` (wave-uniform, set once per pass): see fast2_osc
 #define SK_FAST2_LDS_BLOCK(J, EM_)                                                                       \
-  { if (loz) SK_FAST2_LDS_BLOCK_Z(J, EM_, true) else SK_FAST2_LDS_BLOCK_Z(J, EM_, false) }
+  { if (loz) SK_FAST2_LDS_BLOCK_Z(J, EM_, true, false) else SK_FAST2_LDS_BLOCK_Z(J, EM_, false, false) }
+// the same for a tame wave with muted live lanes (tame_m): their contribution is selected away, synth.c:596
+#define SK_FAST2_LDS_BLOCK_M(J, EM_)                                                                     \
+  { if (loz) SK_FAST2_LDS_BLOCK_Z(J, EM_, true, true) else SK_FAST2_LDS_BLOCK_Z(J, EM_, false, true) }
 // Eight frames (J..J+7) of a tame wave of a global-table bank through the table windows; DPP pair reductions.
 #define SK_FAST2_WIN_BLOCK(J, EM_)                                                                       \
   {                                                                                                      \
@@ -408,7 +412,9 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
                 else for (; j + 8 <= cn; j += 8) SK_FAST2_WIN_BLOCK(j, EM_)     \
                 for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, true)          \
                 if (j < cn) SK_FAST2_ONE(j, EM_, true) }                        \
-    else      { for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, false)         \
+    else      { if (tame_m && TAB_LDS) { if ((EM_) == 0 && fast2_smoother_stalled(r)) for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK_M(j, (EM_) == 0 ? 3 : (EM_)) \
+                                         else for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK_M(j, EM_) } \
+                for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, false)         \
                 if (j < cn) SK_FAST2_ONE(j, EM_, false) }                       \
   }
 #else
@@ -440,7 +446,7 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
 template <bool FILTER, bool ENV, bool MIXED>
 __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase, int lane, Fast2Regs &r,
                                            Env2Regs &e, bool dead[2], bool silent[2], bool released[2],
-                                           uint64_t t_start[2], uint64_t t_release[2], int vidx[2]) {
+                                           uint64_t t_start[2], uint64_t t_release[2], int vidx[2], bool &tame_m) {
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int v = vbase + c * 64 + lane;            // vbase: first voice of this wave's 128-voice slice
@@ -508,13 +514,16 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase,
   r.span = r.hi - r.lo;
   r.span2 = r.span + r.span;
   if (MIXED) { r.ox1 = r.x1; r.ox2 = r.x2; r.oy1 = r.y1; r.oy2 = r.y2; }
-  bool tame_lane = true;
+  bool tame_lane = true, muted_lane = false;
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
-    tame_lane = tame_lane && !(silent[c] && !dead[c]) &&
+  for (int c = 0; c < 2; ++c) {
+    muted_lane = muted_lane || (silent[c] && !dead[c]);
+    tame_lane = tame_lane &&
                 (dead[c] || (r.inc[c] >= 0.0f && r.inc[c] <= 0.5f * r.span[c] && r.phase[c] >= r.lo[c] &&
                              r.phase[c] <= r.hi[c] && r.lo[c] >= 0.0f && r.hi[c] <= (float)(r.tsize_m1[c] + 1)));
-  return __all(tame_lane);
+  }
+  tame_m = __all(tame_lane);                 // tame but for muted live lanes (the LDS blocks can select those away)
+  return tame_m && !__any(muted_lane);
 }
 
 template <bool MIXED>
@@ -584,7 +593,8 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     bool dead[2], silent[2], released[2];
     uint64_t t_start[2], t_release[2];
     int vidx[2];
-    const bool tame = fast2_load<FILTER, ENV, MIXED>(a, g * (NW * 128) + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    bool tame_m;
+    const bool tame = fast2_load<FILTER, ENV, MIXED>(a, g * (NW * 128) + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx, tame_m);
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
     if (ENV) {
@@ -637,7 +647,8 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
     bool dead[2], silent[2], released[2];
     uint64_t t_start[2], t_release[2];
     int vidx[2];
-    const bool tame = fast2_load<FILTER, true, MIXED>(a, g * 512 + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx);
+    bool tame_m;
+    const bool tame = fast2_load<FILTER, true, MIXED>(a, g * 512 + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx, tame_m);
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
     bool all_const_from_here = false;

@@ -130,11 +130,14 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_redtmp) hipFree(b->d_redtmp);
   free(b->h_class); free(b->h_mod); free(b->h_level);
   sk_queue_free(b);
-  if (b->d_updates) hipFree(b->d_updates);
-  if (b->h_updates) hipHostFree(b->h_updates);
+  for (int i = 0; i < SK_UPD_RING; i++) {
+    if (b->upd[i].d) hipFree(b->upd[i].d);
+    if (b->upd[i].h) hipHostFree(b->upd[i].h);
+    if (b->upd[i].ev) hipEventDestroy(b->upd[i].ev);
+  }
+  free(b->upd_mark);
   if (b->h_quiet) hipHostFree(b->h_quiet);
   for (int i = 0; i < SK_QUIET_RING; i++) if (b->quiet_ev[i]) hipEventDestroy(b->quiet_ev[i]);
-  if (b->ev_updates) hipEventDestroy(b->ev_updates);
   if (b->d_level) hipFree(b->d_level);
   if (b->d_group_flag) hipFree(b->d_group_flag);
   for (int i = 0; i < SK_TIMING_RING; i++) {

@@ -16,6 +16,13 @@
 
 #define SK_TIMING_RING 256
 #define SK_QUIET_RING 8
+#define SK_UPD_RING 8
+
+typedef struct {
+  void *h, *d;                /* pinned host buffer and its device twin */
+  size_t cap;                 /* bytes */
+  hipEvent_t ev;              /* fired once the copy and the scatter that read them have run */
+} sk_upd_slot_t;
 #define SK_FAST2_MIN_VOICES 131072   /* banks at least this large use two voices per lane (measured crossover) */
 
 struct skred_bank {
@@ -73,10 +80,9 @@ struct skred_bank {
   struct sk_queue_item *queue;  /* deferred updates (skred_bank_update.c), singly linked in arrival order */
   struct sk_queue_item *queue_tail;
   int queue_len;
-  void *d_updates;            /* device staging of one batch of voice updates */
-  void *h_updates;            /* its pinned host twin */
-  hipEvent_t ev_updates;      /* recorded after the staging copy: the pinned buffer may be reused once it has fired */
-  size_t updates_cap;         /* in records */
+  sk_upd_slot_t upd[SK_UPD_RING];   /* staging ring of the update path (skred_bank_update.c) */
+  uint32_t upd_head;
+  uint32_t *upd_mark, upd_epoch;    /* per-voice epoch marks: duplicate voices inside one batch */
 };
 
 /* per-voice classification (host shadow) */

@@ -169,6 +169,8 @@ typedef struct sk_queue_item {
   sk_voice_meta_t *meta;     /* NULL unless the batch carries SKRED_DIRTY_PARAMS */
 } sk_queue_item_t;
 
+#define SK_STAMP_ONLY(d) (((d) & ~(uint32_t)(SKRED_STAMP_TRIGGER | SKRED_STAMP_RELEASE)) == 0)
+
 static int build_batch(const skred_bank_t *b, const skred_voice_bank_t *h, const int32_t *voices, int n,
                        uint32_t dirty, sk_update_t **rec_out, sk_voice_meta_t **meta_out) {
   *rec_out = NULL;
@@ -177,56 +179,88 @@ static int build_batch(const skred_bank_t *b, const skred_voice_bank_t *h, const
   sk_update_t *rec = (sk_update_t *)calloc((size_t)n, sizeof(sk_update_t));
   sk_voice_meta_t *meta = (dirty & SKRED_DIRTY_PARAMS) ? (sk_voice_meta_t *)calloc((size_t)n, sizeof(sk_voice_meta_t)) : NULL;
   if (!rec || ((dirty & SKRED_DIRTY_PARAMS) && !meta)) { free(rec); free(meta); return fail(SKRED_E_NO_MEM, "update staging"); }
+  const int stamp_only = SK_STAMP_ONLY(dirty);        /* note-on / note-off stamps carry no values: nothing to pack */
   for (int i = 0; i < n; i++) {
     const int v = voices[i];
     if (v < 0 || v >= b->n_voices || v >= h->n_voices) { free(rec); free(meta); return fail(SKRED_E_RANGE, "update: voice %d outside the bank", v); }
-    sk_voice_meta_t m;
-    const int rc = sk_pack_voice(b, h, v, v, (dirty & SKRED_DIRTY_PHASE) != 0, rec[i].ro, rec[i].rw, &m);
-    if (rc) { free(rec); free(meta); return rc; }
+    if (!stamp_only) {
+      sk_voice_meta_t m;
+      const int rc = sk_pack_voice(b, h, v, v, (dirty & SKRED_DIRTY_PHASE) != 0, rec[i].ro, rec[i].rw, &m);
+      if (rc) { free(rec); free(meta); return rc; }
+      if (meta) meta[i] = m;
+    }
     rec[i].voice = v;
     rec[i].dirty = dirty;
-    if (meta) meta[i] = m;
   }
   *rec_out = rec;
   *meta_out = meta;
   return SKRED_OK;
 }
 
+/* One staging slot of the ring: pinned host buffer, device buffer, and the event after which both may be reused.
+ * With a ring the host only ever waits for a copy issued SK_UPD_RING batches ago (i.e. never, in practice); a
+ * single slot would stall every update behind the render that precedes its copy in the stream. */
+static int staging_slot(skred_bank_t *b, size_t bytes, hipStream_t s, sk_upd_slot_t **out) {
+  sk_upd_slot_t *sl = &b->upd[b->upd_head++ % SK_UPD_RING];
+  if (!sl->ev) HIP_TRY(hipEventCreateWithFlags(&sl->ev, hipEventDisableTiming));
+  else HIP_TRY(hipEventSynchronize(sl->ev));
+  if (bytes > sl->cap) {
+    if (sl->d) { (void)hipFree(sl->d); sl->d = NULL; }
+    if (sl->h) { (void)hipHostFree(sl->h); sl->h = NULL; }
+    sl->cap = 0;
+    size_t cap = 64 * 1024;
+    while (cap < bytes) cap *= 2;
+    HIP_TRY(hipMalloc(&sl->d, cap));
+    HIP_TRY(hipHostMalloc(&sl->h, cap, hipHostMallocDefault));
+    sl->cap = cap;
+  }
+  (void)s;
+  *out = sl;
+  return SKRED_OK;
+}
+
 /* push records to the device and scatter them; a voice named twice is applied in order (one launch per run
- * of distinct voices) */
+ * of distinct voices, found with a per-voice epoch mark: linear in the batch) */
 static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_meta_t *meta, int n, hipStream_t s) {
   HIP_TRY(hipSetDevice(b->device));
-  if (!b->ev_updates) HIP_TRY(hipEventCreateWithFlags(&b->ev_updates, hipEventDisableTiming));
-  /* the pinned staging buffer is free again once the previous batch's copy has run (normally long ago) */
-  else HIP_TRY(hipEventSynchronize(b->ev_updates));
-  if ((size_t)n > b->updates_cap) {
-    if (b->d_updates) { HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(b->d_updates); b->d_updates = NULL; }
-    if (b->h_updates) { (void)hipHostFree(b->h_updates); b->h_updates = NULL; }
-    b->updates_cap = 0;
-    size_t cap = 256;
-    while (cap < (size_t)n) cap *= 2;
-    HIP_TRY(hipMalloc(&b->d_updates, cap * sizeof(sk_update_t)));
-    HIP_TRY(hipHostMalloc(&b->h_updates, cap * sizeof(sk_update_t), hipHostMallocDefault));
-    b->updates_cap = cap;
+  const uint32_t dirty = rec[0].dirty;                 /* a batch has one mask */
+  sk_upd_slot_t *sl;
+  if (SK_STAMP_ONLY(dirty)) {
+    /* note-ons / note-offs: voice ids only (stamping the same voice twice with the same clock is idempotent) */
+    int rc = staging_slot(b, (size_t)n * sizeof(int32_t), s, &sl);
+    if (rc) return rc;
+    int32_t *ids = (int32_t *)sl->h;
+    for (int i = 0; i < n; i++) ids[i] = rec[i].voice;
+    HIP_TRY(hipMemcpyAsync(sl->d, sl->h, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    const hipError_t e = (hipError_t)sk_launch_stamp((const int32_t *)sl->d, n, dirty, b->d_ro, b->d_rw, b->g.synth_sample_count, s);
+    HIP_TRY(hipEventRecord(sl->ev, s));
+    if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "stamp launch -> %s", hipGetErrorString(e));
+    sk_control_changed(b);
+    return SKRED_OK;
   }
-  memcpy(b->h_updates, rec, (size_t)n * sizeof(sk_update_t));
-  HIP_TRY(hipMemcpyAsync(b->d_updates, b->h_updates, (size_t)n * sizeof(sk_update_t), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipEventRecord(b->ev_updates, s));
+  int rc = staging_slot(b, (size_t)n * sizeof(sk_update_t), s, &sl);
+  if (rc) return rc;
+  memcpy(sl->h, rec, (size_t)n * sizeof(sk_update_t));
+  HIP_TRY(hipMemcpyAsync(sl->d, sl->h, (size_t)n * sizeof(sk_update_t), hipMemcpyHostToDevice, s));
+  if (!b->upd_mark) {
+    b->upd_mark = (uint32_t *)calloc((size_t)b->n_voices, sizeof(uint32_t));
+    if (!b->upd_mark) return fail(SKRED_E_NO_MEM, "update marks");
+  }
   int start = 0;
   while (start < n) {
-    int end = start + 1;
+    if (++b->upd_epoch == 0) { memset(b->upd_mark, 0, (size_t)b->n_voices * sizeof(uint32_t)); b->upd_epoch = 1; }
+    int end = start;
     for (; end < n; end++) {
-      int dup = 0;
-      for (int j = start; j < end && !dup; j++) dup = rec[j].voice == rec[end].voice;
-      if (dup) break;
-      if (end - start >= 64) { /* bound the quadratic scan: long batches are split, still in order */ end++; break; }
+      uint32_t *m = &b->upd_mark[rec[end].voice];
+      if (*m == b->upd_epoch) break;                    /* named before in this run: the next launch takes it */
+      *m = b->upd_epoch;
     }
-    if (end > n) end = n;
-    const hipError_t e = (hipError_t)sk_launch_update((const sk_update_t *)b->d_updates + start, end - start, b->d_ro, b->d_rw,
+    const hipError_t e = (hipError_t)sk_launch_update((const sk_update_t *)sl->d + start, end - start, b->d_ro, b->d_rw,
                                                       b->g.synth_sample_count, s);
     if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "update launch -> %s", hipGetErrorString(e));
     start = end;
   }
+  HIP_TRY(hipEventRecord(sl->ev, s));
   if (meta) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i]);
   sk_control_changed(b);
   return SKRED_OK;

@@ -49,6 +49,10 @@ int sk_launch_master(const float *sum, float *out, int num_frames, int num_chann
 int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[SKP_COUNT], sk_plane_t *const rw[SKS_COUNT],
                      uint64_t now, hipStream_t stream);
 
+/* note-on / note-off stamps only: a list of voice ids */
+int sk_launch_stamp(const int32_t *d_ids, int n, uint32_t dirty, sk_plane_t *const ro[SKP_COUNT], sk_plane_t *const rw[SKS_COUNT],
+                    uint64_t now, hipStream_t stream);
+
 /* stem recorder (skred_recorder.c): min/max partials of rec[n_floats]; selected voices -> int16 pairs */
 int sk_rec_partial_floats(void);
 int sk_launch_rec_minmax(const float *rec, size_t n_floats, float *partial, int *n_blocks_out, hipStream_t stream);

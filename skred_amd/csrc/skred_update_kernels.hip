@@ -53,6 +53,36 @@ __global__ __launch_bounds__(64) void sk_update_kernel(const sk_update_t *__rest
   *reinterpret_cast<uint4 *>(&p.rw[SKS_MISC][v]) = s2;
 }
 
+// note-ons / note-offs only: a list of voice ids, the clock, which stamp
+__global__ __launch_bounds__(256) void sk_stamp_kernel(const int32_t *__restrict__ ids, int n, uint32_t dirty, sk_plane_ptrs_t p,
+                                                       uint64_t now) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int v = ids[i];
+  uint32_t *rwflags = reinterpret_cast<uint32_t *>(&p.rw[SKS_FILT][v]) + 3;
+  uint4 es = *reinterpret_cast<const uint4 *>(&p.ro[SKP_ENV_S][v]);
+  uint32_t f = *rwflags;
+  if (dirty & SKU_STAMP_TRIGGER) {
+    es.x = (uint32_t)now; es.y = (uint32_t)(now >> 32); es.z = 0; es.w = 0;
+    f |= SKR_ENV_ACTIVE;
+  }
+  if ((dirty & SKU_STAMP_RELEASE) && (f & SKR_ENV_ACTIVE)) {
+    es.z = (uint32_t)now; es.w = (uint32_t)(now >> 32);
+  }
+  *reinterpret_cast<uint4 *>(&p.ro[SKP_ENV_S][v]) = es;
+  *rwflags = f;
+}
+
+extern "C" int sk_launch_stamp(const int32_t *d_ids, int n, uint32_t dirty, sk_plane_t *const ro[SKP_COUNT],
+                               sk_plane_t *const rw[SKS_COUNT], uint64_t now, hipStream_t stream) {
+  if (n <= 0) return 0;
+  sk_plane_ptrs_t p;
+  for (int k = 0; k < SKP_COUNT; ++k) p.ro[k] = ro[k];
+  for (int k = 0; k < SKS_COUNT; ++k) p.rw[k] = rw[k];
+  hipLaunchKernelGGL(sk_stamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ids, n, dirty, p, now);
+  return (int)hipGetLastError();
+}
+
 extern "C" int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[SKP_COUNT],
                                 sk_plane_t *const rw[SKS_COUNT], uint64_t now, hipStream_t stream) {
   if (n <= 0) return 0;

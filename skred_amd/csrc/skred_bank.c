@@ -91,8 +91,11 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   memset(b->h_mod, -1, (size_t)b->n_padded * 4);
   HIP_TRY(hipMalloc((void **)&b->d_level, (size_t)b->n_padded * sizeof(int)));
   HIP_TRY(hipMemset(b->d_level, 0, (size_t)b->n_padded * sizeof(int)));
-  HIP_TRY(hipMalloc((void **)&b->d_group_flag, (size_t)(b->n_groups / 2 + 1) * sizeof(int32_t)));
-  HIP_TRY(hipMemset(b->d_group_flag, 0, (size_t)(b->n_groups / 2 + 1) * sizeof(int32_t)));
+  /* one hand-over flag per 128-voice wave slice of the two-per-lane kernels, plus the ticket slot */
+  HIP_TRY(hipMalloc((void **)&b->d_group_flag, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
+  HIP_TRY(hipMemset(b->d_group_flag, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void **)&b->d_env_list, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
+  HIP_TRY(hipMemset(b->d_env_list, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
   b->class_dirty = 1;
   b->mod_dirty = 1;
   HIP_TRY(hipMalloc((void **)&b->d_gain_state, 4 * sizeof(float)));
@@ -140,6 +143,7 @@ void skred_bank_destroy(skred_bank_t *b) {
   for (int i = 0; i < SK_QUIET_RING; i++) if (b->quiet_ev[i]) hipEventDestroy(b->quiet_ev[i]);
   if (b->d_level) hipFree(b->d_level);
   if (b->d_group_flag) hipFree(b->d_group_flag);
+  if (b->d_env_list) hipFree(b->d_env_list);
   for (int i = 0; i < SK_TIMING_RING; i++) {
     if (b->ev0[i]) hipEventDestroy(b->ev0[i]);
     if (b->ev1[i]) hipEventDestroy(b->ev1[i]);
@@ -355,6 +359,7 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   a.partial = b->d_partial;
   a.stems = d_stems;
   a.group_flag = b->d_group_flag;
+  a.env_list = b->d_env_list;
   a.count0 = b->g.synth_sample_count;
   a.rng0 = b->g.noise_rng;
   a.n_voices = b->n_voices;
@@ -412,7 +417,7 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
     const int i = b->quiet_head % SK_QUIET_RING;
     if (!b->h_quiet) HIP_TRY(hipHostMalloc((void **)&b->h_quiet, SK_QUIET_RING * sizeof(uint32_t), hipHostMallocDefault));
     if (!b->quiet_ev[i]) HIP_TRY(hipEventCreateWithFlags(&b->quiet_ev[i], hipEventDisableTiming));
-    HIP_TRY(hipMemcpyAsync(&b->h_quiet[i], b->d_group_flag + b->n_groups / 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&b->h_quiet[i], b->d_group_flag + b->n_groups * 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipEventRecord(b->quiet_ev[i], s));
     b->quiet_ticket[i] = a.launch_ticket;
     b->quiet_epoch[i] = b->control_epoch;

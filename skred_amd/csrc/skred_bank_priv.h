@@ -54,7 +54,8 @@ struct skred_bank {
   int8_t *h_mod;              /* [4][n_padded] modulator lane inside the 64-voice group (fm, am, pm, cz) or -1 */
   int *h_level;               /* [n_padded] dependency level of each voice (modulated banks) */
   int *d_level;
-  int32_t *d_group_flag;      /* per 512-voice group: deferred to sk_render_env2_kernel */
+  int32_t *d_env_list;        /* the flagged slices, compacted (sk_compact_flags_kernel) */
+  int32_t *d_group_flag;      /* per 128-voice wave slice: left to sk_render_env2_kernel; one more slot: the ticket */
   int max_level;
   int mod_escapes;            /* some modulator lies outside its carrier's 64-voice group */
   int class_dirty;
@@ -73,7 +74,7 @@ struct skred_bank {
   uint32_t launch_ticket;     /* one per render launch */
   uint32_t control_epoch;     /* bumped by every upload / update / globals change */
   int env_quiet;              /* the last answered launch deferred no group and nothing changed since */
-  uint32_t *h_quiet;          /* pinned: SK_QUIET_RING tickets read back from d_group_flag[n_groups/2] */
+  uint32_t *h_quiet;          /* pinned: SK_QUIET_RING tickets read back from d_group_flag[n_groups*2] */
   hipEvent_t quiet_ev[SK_QUIET_RING];
   uint32_t quiet_ticket[SK_QUIET_RING], quiet_epoch[SK_QUIET_RING];
   int quiet_head, quiet_tail, quiet_pending;

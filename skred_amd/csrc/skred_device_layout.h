@@ -121,8 +121,10 @@ typedef struct {
   const float *tables;     /* HBM pool */
   float *partial;          /* [n_workgroups][num_frames][2] pre-master partial sums */
   float *stems;            /* [num_frames][n_voices][2] or NULL */
-  int32_t *group_flag;     /* [n_groups/2]: 1 = this 512-voice group has envelopes in motion (fast2 -> env2 hand-over);
-                              [n_groups/2] (one more): ticket of the last launch that deferred any group */
+  int32_t *group_flag;     /* [n_groups*2]: 1 = this 128-voice wave slice has an envelope in motion (fast2 -> env2 hand-over);
+                              [n_groups*2] (one more): ticket of the last launch that deferred any slice */
+  int32_t *env_list;       /* [n_groups*2 + 1]: the flagged slices in ascending order, [n_groups*2] = how many
+                              (sk_compact_flags_kernel, between the two kernels) */
   uint64_t count0;         /* synth_sample_count before the first frame */
   uint64_t rng0;           /* noise LCG state before the first frame */
   int32_t n_voices;        /* real voices (stems indexing) */

@@ -568,8 +568,9 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
     __syncthreads();                                                                                 \
   }                                                                                                  \
   const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;                            \
-  const int n_groups2 = a.n_groups >> 1;   /* 512-voice groups: the unit of the fast2 -> env2 hand-over */ \
-  const int n_pass = (a.n_groups * SK_GROUP) / (NW * 128);   /* workgroup passes over the (padded) bank */
+  const int n_groups2 = a.n_groups >> 1;   /* 512-voice groups: one pass of sk_render_env2_kernel */ \
+  const int n_pass = (a.n_groups * SK_GROUP) / (NW * 128);   /* workgroup passes over the (padded) bank */ \
+  const int n_flags = a.n_groups * 2;      /* one hand-over flag per 128-voice wave slice; [n_flags] = the ticket slot */
 
 #ifndef SK_FAST2_MIN_WAVES
 #define SK_FAST2_MIN_WAVES 4     /* <= 128 VGPRs */
@@ -586,6 +587,7 @@ template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED>
 __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
   constexpr int NW = Fast2Shape<TAB_LDS>::NW;
   SK_FAST2_PROLOGUE()
+  (void)n_groups2; (void)n_flags;
   bool first_pass = true;
   for (int g = blockIdx.x; g < n_pass; g += gridDim.x) {
     Fast2Regs r;
@@ -597,6 +599,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     const bool tame = fast2_load<FILTER, ENV, MIXED>(a, g * (NW * 128) + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx, tame_m);
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
+    bool wave_ok = true;
     if (ENV) {
       // constant envelope level on the first frame of the launch <=> for the whole launch (absorbing codes)
       bool ok = true;
@@ -610,20 +613,26 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
         r.gain_const[c] = e.ampv[c] * (level * e.velv[c]);                       // synth.c:582,588
         if (!dead[c] && code == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;                   // synth.c:429
       }
-      const int group_ok = __syncthreads_and(ok ? 1 : 0);
-      if (tid == 0) {
-#pragma unroll
-        for (int j = 0; j < NW / 4; ++j) a.group_flag[g * (NW / 4) + j] = group_ok ? 0 : 1;   // per 512-voice group
-        if (!group_ok) a.group_flag[n_groups2] = (int32_t)a.launch_ticket;   // "this launch deferred something"
+      // hand-over per WAVE (128 voices): a wave with an envelope in motion leaves its slice to sk_render_env2_kernel,
+      // the others render theirs here.  (Notes start and end all the time in a live bank: per 512-voice group almost
+      // every group would be deferred, per wave a good share still is not.)
+      wave_ok = __all(ok);
+      if (lane == 0) {
+        a.group_flag[g * NW + wave] = wave_ok ? 0 : 1;
+        if (!wave_ok) a.group_flag[n_flags] = (int32_t)a.launch_ticket;     // "this launch deferred something"
       }
-      if (!group_ok) continue;                          // sk_render_env2_kernel renders this group
+      if (!__syncthreads_or(wave_ok ? 1 : 0)) continue;   // nothing of this pass is rendered here
     }
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
-      SK_FAST2_CHUNK(0)
+      if (wave_ok) {
+        SK_FAST2_CHUNK(0)
+      } else if (lane < cn) {
+        wsum[wave * SK_CHUNK + lane] = make_float2(0.0f, 0.0f);             // a deferred wave adds nothing to the chunk
+      }
       SK_FAST2_FLUSH(!first_pass)
     }
-    fast2_store<MIXED>(a, r, dead, vidx);
+    if (wave_ok) fast2_store<MIXED>(a, r, dead, vidx);
     first_pass = false;
   }
   if (first_pass) {   // every group of this workgroup was deferred: its partial-mix row must still exist
@@ -639,21 +648,30 @@ template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
   constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
   SK_FAST2_PROLOGUE()
-  (void)n_pass;
-  for (int g = blockIdx.x; g < n_groups2; g += gridDim.x) {
-    if (a.group_flag[g] == 0) continue;
+  (void)n_pass; (void)n_groups2;
+  // the slices sk_render_fast2_kernel left to this kernel, compacted in ascending order (sk_compact_flags_kernel): every
+  // workgroup pass takes four of them, so the launch costs what the flagged share of the bank costs
+  const int n_mine = a.env_list[n_flags];
+  for (int g = blockIdx.x; g * 4 < n_mine; g += gridDim.x) {
+    const bool mine = g * 4 + wave < n_mine;
+    const int slice = mine ? a.env_list[g * 4 + wave] : 0;
     Fast2Regs r;
     Env2Regs e;
     bool dead[2], silent[2], released[2];
     uint64_t t_start[2], t_release[2];
     int vidx[2];
-    bool tame_m;
-    const bool tame = fast2_load<FILTER, true, MIXED>(a, g * 512 + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx, tame_m);
-    const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
-    (void)loz;
+    bool tame_m = false, tame = false, loz = false;
+    if (mine) {
+      tame = fast2_load<FILTER, true, MIXED>(a, slice * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx, tame_m);
+      loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
+    }
+    (void)loz; (void)tame; (void)tame_m;
     bool all_const_from_here = false;
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
+      if (!mine) {
+        if (lane < cn) wsum[wave * SK_CHUNK + lane] = make_float2(0.0f, 0.0f);
+      } else {
       bool steady = true, exact = true, ramp = false;
       float cb_tf[2] = {0.0f, 0.0f}, cb_trf[2] = {0.0f, 0.0f};     // clocks of the frame BEFORE the chunk
       if (!all_const_from_here) {
@@ -718,15 +736,34 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
           SK_FAST2_ONE(j, 2, false)
         }
       }
+      }   // mine
       SK_FAST2_FLUSH(true)
     }
-    fast2_store<MIXED>(a, r, dead, vidx);
+    if (mine) fast2_store<MIXED>(a, r, dead, vidx);
   }
 }
 
 // ---------------------------------------------------------------- launcher (C linkage)
 
-// sk_render_fast2_kernel renders the constant-envelope groups and flags the others; when the bank has
+// flags[n] (0/1 per 128-voice slice) -> list of the flagged slice indices in ascending order, list[n] = their number.
+// One workgroup: every thread counts its contiguous share, an LDS scan places the shares, every thread writes its own.
+__global__ __launch_bounds__(256) void sk_compact_flags_kernel(const int32_t *__restrict__ flags, int n, int32_t *__restrict__ list) {
+  __shared__ int base[257];
+  const int t = threadIdx.x;
+  const int per = (n + 255) / 256, lo = min(t * per, n), hi = min(lo + per, n);
+  int c = 0;
+  for (int i = lo; i < hi; ++i) c += flags[i] != 0;
+  base[t + 1] = c;
+  if (t == 0) base[0] = 0;
+  __syncthreads();
+  if (t == 0) for (int i = 1; i <= 256; ++i) base[i] += base[i - 1];
+  __syncthreads();
+  int w = base[t];
+  for (int i = lo; i < hi; ++i) if (flags[i] != 0) list[w++] = i;
+  if (t == 255) list[n] = base[256];
+}
+
+// sk_render_fast2_kernel renders the constant-envelope slices and flags the others; when the bank has
 // envelopes at all, sk_render_env2_kernel follows on the same stream and renders the flagged groups.
 extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
                                       hipStream_t stream) {
@@ -748,12 +785,16 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
   case K:                                                                                               \
     if (mixed) {                                                                                        \
       hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, true>), grid, block, lds_fast2, stream, *args);  \
-      if (E && !args->skip_env2)                                                                        \
+      if (E && !args->skip_env2) {                                                                      \
+        hipLaunchKernelGGL(sk_compact_flags_kernel, dim3(1), dim3(256), 0, stream, args->group_flag, args->n_groups * 2, args->env_list); \
         hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, true>), grid, block_env, lds_env2, stream, *args); \
+      }                                                                                                 \
     } else {                                                                                            \
       hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, false>), grid, block, lds_fast2, stream, *args); \
-      if (E && !args->skip_env2)                                                                        \
+      if (E && !args->skip_env2) {                                                                      \
+        hipLaunchKernelGGL(sk_compact_flags_kernel, dim3(1), dim3(256), 0, stream, args->group_flag, args->n_groups * 2, args->env_list); \
         hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, false>), grid, block_env, lds_env2, stream, *args); \
+      }                                                                                                 \
     }                                                                                                   \
     break;
   switch (key) {

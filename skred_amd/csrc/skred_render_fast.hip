@@ -327,6 +327,44 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
+// Eight steady frames (J..J+7) of a tame wave of an LDS-table bank with the cross-lane sum through LDS instead of
+// the VALU (the same tile as skred_render_fast2.hip: SK_FAST2_LDS_BLOCK_Z): every lane parks its (L,R) of the 8
+// frames in the wave-private tile xp[8][65]; lane (f = lane&7, seg = lane>>3) adds the 8 lanes of segment seg for
+// frame f, the segment sums cross through xq[8][8], lanes 0..7 finish one frame each.  ~1.75 VALU + 3.25 LDS
+// instructions per frame instead of the 12 v_add_dpp of the pair reduction -- which is most of what a bank too
+// small to give every SIMD a second wave spends per frame.  The gather of the next frame is issued before the
+// biquad / gain chain of the current one.  All traffic stays inside one wavefront: no s_barrier.
+#define SK_FAST_WAVE_SYNC()                                 \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+  __builtin_amdgcn_wave_barrier();                          \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#define SK_FAST_LDS_BLOCK(J, STALL_)                                                                     \
+  {                                                                                                      \
+    float s0_ = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));           \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      float l0, r0, l1, r1;                                                                              \
+      const float s1_ = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));   \
+      fast_post<FILTER, ENV, true, STALL_, STOPS>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);     \
+      if (q_ < 6) s0_ = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));   \
+      fast_post<FILTER, ENV, true, STALL_, STOPS>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);     \
+      xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
+      xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
+    }                                                                                                    \
+    SK_FAST_WAVE_SYNC()                                                                                  \
+    {                                                                                                    \
+      const float2 *src_ = xp + (lane & 7) * 65 + (lane >> 3) * 8;                                       \
+      float2 a0_ = src_[0];                                                                              \
+      _Pragma("unroll") for (int i_ = 1; i_ < 8; ++i_) { const float2 t_ = src_[i_]; a0_.x += t_.x; a0_.y += t_.y; } \
+      xq[lane] = a0_; /* == xq[seg * 8 + f] */                                                           \
+    }                                                                                                    \
+    SK_FAST_WAVE_SYNC()                                                                                  \
+    if (lane < 8) {                                                                                      \
+      float2 t0_ = xq[lane];                                                                             \
+      _Pragma("unroll") for (int g_ = 1; g_ < 8; ++g_) { const float2 t_ = xq[g_ * 8 + lane]; t0_.x += t_.x; t0_.y += t_.y; } \
+      wsum[wave * SK_CHUNK + (J) + lane] = t0_;                                                          \
+    }                                                                                                    \
+    SK_FAST_WAVE_SYNC()                                                                                  \
+  }
 // eight steady frames of a tame wave of a global-table bank through the table window
 #define SK_FAST_WIN_BLOCK(J, STALL_)                                                                     \
   {                                                                                                      \
@@ -368,8 +406,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (SK_WIN * 64);   // global-table banks only
-  (void)win;
+  float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (SK_WIN * 64);   // global-table banks: table windows
+  float2 *xp = reinterpret_cast<float2 *>(win);       // LDS-table banks: the same per-wave region holds the
+  float2 *xq = xp + 8 * 65;                            // transposition tiles of SK_FAST_LDS_BLOCK (8*65 + 64 float2 <= SK_WIN*64 floats)
+  (void)win; (void)xp; (void)xq;
 
   if (TAB_LDS) {
     const int n4 = a.lds_table_floats >> 2;           // padded to a multiple of 4 by the host
@@ -510,6 +550,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
         // an extended bank, but nothing in THIS wave needs the frame loop now (e.g. only some voices filtered, or one-shots
         // still far from their end): frame pairs
         int j = 0;
+        if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, true)
+        else for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, false)
         for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (STOPS && (!ENV || steady)) {
@@ -525,6 +567,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
         if (!TAB_LDS) {
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
+        } else {
+          if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, true)
+          else for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, false)
         }
         for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
@@ -589,7 +634,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
 extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
                                      hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
-  if (!tab_lds) lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);   // one table window per wave
+  lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);   // per wave: one table window, or the reduction tiles of SK_FAST_LDS_BLOCK
   dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
   const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);

@@ -384,7 +384,7 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   const int tslot = b->n_timed % SK_TIMING_RING;
   if (!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) {
     /* passes of sk_render_fast2_kernel: 1024 voices each for LDS-table banks, 512 otherwise (skred_render_fast2.hip) */
-    const int passes = a.lds_table_floats > 0 ? b->n_groups / 4 : b->n_groups / 2;
+    const int passes = a.lds_table_floats > 0 ? b->n_groups * 2 / SK_FAST2_NW_LDS : b->n_groups / 2;
     n_wg = passes < SK_MAX_WORKGROUPS ? passes : SK_MAX_WORKGROUPS;
   }
   /* two-per-lane banks with envelopes: sk_render_fast2_kernel hands groups with envelopes in motion to

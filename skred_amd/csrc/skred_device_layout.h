@@ -80,6 +80,9 @@ enum {
 
 #define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */
 #define SK_CHUNK 64                /* frames between two workgroup-level mix flushes */
+#ifndef SK_FAST2_NW_LDS
+#define SK_FAST2_NW_LDS 8   /* sk_render_fast2_kernel, LDS-table banks: wavefronts (128-voice slices) per workgroup pass */
+#endif
 #define SK_LDS_TABLE_MAX_FLOATS 12288  /* 48 KiB: pools up to this size are staged in LDS */
 #define SK_MAX_WORKGROUPS 2048
 #define SK_WIN 20                  /* floats of one voice's table window (skred_render_fast2.hip: 8 frames at up to

@@ -118,9 +118,12 @@ __device__ __forceinline__ float fast_advance(FastRegs &r, float inc) {
 
 // The rest of the frame: biquad, envelope / gain, smoother, pan.
 // STALL (steady waves only): the smoother no longer moves in any lane (fast_smoother_stalled) and is skipped.
-template <bool FILTER, bool ENV, bool STEADY, bool STALL = false, bool EXT = false>
+// PLAIN (EXT only): the caller has proved that no lane of the wave is modulated or runs without the smoother
+// (`!any_fm`): only the per-lane filter / envelope flags of an extended bank remain.
+template <bool FILTER, bool ENV, bool STEADY, bool STALL = false, bool EXT = false, bool PLAIN = false>
 __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float &xo, float &yn, float &yo,
                                           const bool released, float &out_l, float &out_r, const bool muted = false) {
+  constexpr bool XMOD = EXT && !PLAIN;
   // ---- biquad (mmf_process, synth.c:349-364) ----
   if (FILTER) {
     // xn/yn: newest delay-line entries, xo/yo: the older ones.  The new values overwrite the OLD
@@ -163,16 +166,16 @@ __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float
     gain = r.amp * (e * r.vel);
   }
   // ---- smoother + apply (synth.c:589-593), pan (synth.c:603-604) ----
-  if (EXT && r.am_addr != -1)                            // final = amp * env * mod (synth.c:583-588)
+  if (XMOD && r.am_addr != -1)                           // final = amp * env * mod (synth.c:583-588)
     gain = gain * ((r.am_addr == -2 ? s : r.am_prev) * r.am_depth);
-  if (EXT && r.nosmooth) {
+  if (XMOD && r.nosmooth) {
     s *= gain;                                           // voice_smoother_gain is left alone (synth.c:589-593)
   } else {
     if (!STALL) r.sgain += r.k * (gain - r.sgain);
     s *= r.sgain;
   }
   r.sample = s;
-  if (EXT && r.pm_addr != -1 && !muted) {                // synth.c:597-602 (inside the `not disconnected` branch)
+  if (XMOD && r.pm_addr != -1 && !muted) {               // synth.c:597-602 (inside the `not disconnected` branch)
     const float q = (r.pm_addr == -2 ? s : r.pm_prev) * r.pm_depth;
     r.pan_l = (1.0f - q) / 2.0f;
     r.pan_r = (1.0f + q) / 2.0f;
@@ -322,8 +325,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     float l0, r0, l1, r1;                                                                                \
     const float sa_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
     const float sb_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
-    fast_post<FILTER, ENV, true, false, STOPS>(r, sa_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);        \
-    fast_post<FILTER, ENV, true, false, STOPS>(r, sb_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);        \
+    fast_post<FILTER, ENV, true, false, STOPS, true>(r, sa_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);        \
+    fast_post<FILTER, ENV, true, false, STOPS, true>(r, sb_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);        \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
@@ -338,18 +341,11 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#define SK_FAST_LDS_BLOCK(J, STALL_)                                                                     \
+// Software pipeline across blocks: the 8 table gathers of block J are issued first (the phase recurrence does not
+// depend on the samples), then the tile of the PREVIOUS block is reduced while they are in flight, then the biquad /
+// gain chains of block J run and park their outputs.  SK_FAST_LDS_FLUSH reduces the last pending tile of a chunk.
+#define SK_FAST_TILE_REDUCE(JP)                                                                          \
   {                                                                                                      \
-    float s0_ = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));           \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
-      float l0, r0, l1, r1;                                                                              \
-      const float s1_ = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));   \
-      fast_post<FILTER, ENV, true, STALL_, STOPS>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);     \
-      if (q_ < 6) s0_ = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));   \
-      fast_post<FILTER, ENV, true, STALL_, STOPS>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);     \
-      xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
-      xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
-    }                                                                                                    \
     SK_FAST_WAVE_SYNC()                                                                                  \
     {                                                                                                    \
       const float2 *src_ = xp + (lane & 7) * 65 + (lane >> 3) * 8;                                       \
@@ -361,10 +357,26 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     if (lane < 8) {                                                                                      \
       float2 t0_ = xq[lane];                                                                             \
       _Pragma("unroll") for (int g_ = 1; g_ < 8; ++g_) { const float2 t_ = xq[g_ * 8 + lane]; t0_.x += t_.x; t0_.y += t_.y; } \
-      wsum[wave * SK_CHUNK + (J) + lane] = t0_;                                                          \
+      wsum[wave * SK_CHUNK + (JP) + lane] = t0_;                                                         \
     }                                                                                                    \
     SK_FAST_WAVE_SYNC()                                                                                  \
   }
+#define SK_FAST_LDS_BLOCK(J, STALL_)                                                                     \
+  {                                                                                                      \
+    float smp_[8];                                                                                       \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                     \
+      smp_[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));          \
+    if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      float l0, r0, l1, r1;                                                                              \
+      fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, smp_[q_], r.x1, r.x2, r.y1, r.y2, released, l0, r0);     \
+      fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, smp_[q_ + 1], r.x2, r.x1, r.y2, r.y1, released, l1, r1); \
+      xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
+      xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
+    }                                                                                                    \
+    pend_j = (J);                                                                                        \
+  }
+#define SK_FAST_LDS_FLUSH() if (pend_j >= 0) { SK_FAST_TILE_REDUCE(pend_j) pend_j = -1; }
 // eight steady frames of a tame wave of a global-table bank through the table window
 #define SK_FAST_WIN_BLOCK(J, STALL_)                                                                     \
   {                                                                                                      \
@@ -373,10 +385,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post<FILTER, ENV, true, STALL_, STOPS>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);            \
+      fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);            \
       if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); \
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post<FILTER, ENV, true, STALL_, STOPS>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
+      fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
       if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); \
       { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
     }                                                                                                    \
@@ -391,7 +403,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_WIN_MIN_WAVES 4  /* global-table banks: the window refill wants ~20 more registers (6: 12 B of scratch) */
 #endif
 #ifndef SK_FAST_MIN_WAVES
-#define SK_FAST_MIN_WAVES 6      /* waves per SIMD the register allocator must leave room for */
+#define SK_FAST_MIN_WAVES 4      /* waves per SIMD the register allocator must leave room for (LDS-table banks: the table copy,
+                                    wsum and the reduction tiles take 38..70 KB per workgroup, i.e. 2..4 workgroups per CU anyway) */
 #endif
 // STOPS (the "extended" instantiation): the bank holds forward one-shots that play to their table end and finish
 // (checked frame by frame) and / or carriers frequency-modulated by a higher-indexed voice of their 64-voice group.
@@ -549,9 +562,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       if (STOPS && (!ENV || steady) && tame && !any_fm && !stop_near && TAB_LDS) {
         // an extended bank, but nothing in THIS wave needs the frame loop now (e.g. only some voices filtered, or one-shots
         // still far from their end): frame pairs
-        int j = 0;
+        int j = 0, pend_j = -1;
         if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, true)
         else for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, false)
+        SK_FAST_LDS_FLUSH()
         for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (STOPS && (!ENV || steady)) {
@@ -568,8 +582,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
         } else {
+          int pend_j = -1;
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, false)
+          SK_FAST_LDS_FLUSH()
         }
         for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }

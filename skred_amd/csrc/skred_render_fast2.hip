@@ -581,7 +581,7 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
 // 16 waves, 4 per SIMD -- share a CU's LDS with ONE copy of the tables each (four per SIMD needs <= 40 KB per
 // 256-thread workgroup otherwise, and tables + tiles take ~46 KB); global-table banks keep 4 (their table windows
 // scale with the wave count).
-template <bool TAB_LDS> struct Fast2Shape { static constexpr int NW = TAB_LDS ? 8 : 4; };
+template <bool TAB_LDS> struct Fast2Shape { static constexpr int NW = TAB_LDS ? SK_FAST2_NW_LDS : 4; };
 
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED>
 __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {

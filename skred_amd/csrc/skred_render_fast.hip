@@ -202,15 +202,17 @@ template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTER
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r,
-                                           const bool any_fm = false, const bool muted = false) {
+                                           const bool any_fm = false, const bool muted = false, const bool any_ap = true) {
   float inc = r.inc;
   if (STOPS && any_fm) {                                // wave-uniform: some lane of the wave is modulated
     // voice_sample[m] as the previous frame left it (a modulator that is skipped this frame holds exact zero)
     const int mine = __float_as_int(r.sample);
     const float ms = __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, mine));
     if (r.fm_addr >= 0) inc = r.inc + r.fm_k * (ms * r.fm_depth);        // synth.c:551-554
-    r.am_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.am_addr, 0), mine));
-    r.pm_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.pm_addr, 0), mine));
+    if (any_ap) {                                        // wave-uniform: some lane is amplitude- or pan-modulated
+      r.am_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.am_addr, 0), mine));
+      r.pm_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.pm_addr, 0), mine));
+    }
     if (r.rev) inc = -inc;                               // reverse playback, applied to the modulated increment
   }
   const float ph = fast_advance<TAME, STOPS>(r, inc);
@@ -311,7 +313,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO, SWAPPED_)                                              \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, any_fm, muted); \
+    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, any_fm, muted, any_ap); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
     if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (J) == a.num_frames - 1, misc_xy); \
     SK_REDUCE_AND_STORE(J)                                                                               \
@@ -335,8 +337,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // frames in the wave-private tile xp[8][65]; lane (f = lane&7, seg = lane>>3) adds the 8 lanes of segment seg for
 // frame f, the segment sums cross through xq[8][8], lanes 0..7 finish one frame each.  ~1.75 VALU + 3.25 LDS
 // instructions per frame instead of the 12 v_add_dpp of the pair reduction -- which is most of what a bank too
-// small to give every SIMD a second wave spends per frame.  The gather of the next frame is issued before the
-// biquad / gain chain of the current one.  All traffic stays inside one wavefront: no s_barrier.
+// small to give every SIMD a second wave spends per frame.  All traffic stays inside one wavefront: no s_barrier.
 #define SK_FAST_WAVE_SYNC()                                 \
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
@@ -377,6 +378,26 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     pend_j = (J);                                                                                        \
   }
 #define SK_FAST_LDS_FLUSH() if (pend_j >= 0) { SK_FAST_TILE_REDUCE(pend_j) pend_j = -1; }
+// Eight steady frames of the extended frame loop (modulation exchange, finish test, sample & hold ... per frame) with
+// the same tile reduction instead of 12 v_add_dpp per frame; the per-wave LDS region is free here (no table windows
+// in such a wave).
+#define SK_FAST_X_FRAME(Q, XN, XO, YN, YO, SWAPPED_)                                                     \
+  {                                                                                                      \
+    float l, rr;                                                                                         \
+    fast_frame<TAB_LDS, FILTER, ENV, true, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, any_fm, muted, any_ap); \
+    l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
+    if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (Q) == a.num_frames - 1, misc_xy); \
+    xp[((Q) & 7) * 65 + lane] = make_float2(l, rr);                                                      \
+  }
+#define SK_FAST_X_BLOCK(J)                                                                               \
+  {                                                                                                      \
+    if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      SK_FAST_X_FRAME((J) + q_, r.x1, r.x2, r.y1, r.y2, true)                                            \
+      SK_FAST_X_FRAME((J) + q_ + 1, r.x2, r.x1, r.y2, r.y1, false)                                       \
+    }                                                                                                    \
+    pend_j = (J);                                                                                        \
+  }
 // eight steady frames of a tame wave of a global-table bank through the table window
 #define SK_FAST_WIN_BLOCK(J, STALL_)                                                                     \
   {                                                                                                      \
@@ -531,6 +552,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
     // wave: no table windows, no tame shortcuts, no stalled-smoother skip
     const bool any_fm = STOPS && __any(r.fm_addr >= 0 || r.am_addr != -1 || r.pm_addr != -1 || r.rev || r.hold_max != 0 ||
                                        r.quant != 0 || r.nosmooth);
+    const bool any_ap = STOPS && __any(r.am_addr != -1 || r.pm_addr != -1);
+    (void)any_ap;
     const bool any_stop = STOPS && __any(r.stop);         // (a lane that finishes turns its flag off)
     (void)any_stop;
     (void)any_fm;
@@ -573,6 +596,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
         if (!TAB_LDS && tame && !any_fm) {   // a voice about to finish is `direct` in its window block; the block checks per frame
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
+        } else {
+          int pend_j = -1;
+          for (; j + 8 <= cn; j += 8) SK_FAST_X_BLOCK(j)
+          SK_FAST_LDS_FLUSH()
         }
         for (; j + 1 < cn; j += 2) { SK_FAST_EVEN(j, true) SK_FAST_ODD(j + 1, true) }
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }

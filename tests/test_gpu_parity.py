@@ -362,6 +362,24 @@ def test_fast_kernel_bit_identical_to_generic_and_oracle(dev, recipe, interp):
     assert rel_rms(fast_mix, ref_mix) <= 1e-5
 
 
+@pytest.mark.parametrize("recipe,interp", [("c1", 0), ("c2", 0), ("c2", 1)])
+def test_sustained_bank_on_the_tile_blocks(dev, recipe, interp):
+    """Every voice in its sustain stage (the recipe's last note-on is 5280 frames old after the first segment): the
+    8-frame LDS-tile blocks of the one-voice kernel, with block counts that leave tail frames (777 = 12 chunks + 9
+    frames; 100 = 1 chunk + 36), muted and skipped voices among them; then the smoother stalls (its own block variant).
+    Per-voice state bit for bit against the oracle, mixes within 1e-5."""
+    n = 3000
+    bank, tables, g = banks.RECIPES[recipe](n)
+    bank["voice_disconnect"][:1000:7] = 1        # waves with a muted live voice keep the frame pairs; the others take the blocks
+    bank["voice_amp"][::11] = 0.0
+    segs = [(5700, None), (777, None), (100, None), (8, None), (3, None), (4096, None), (515, None)]
+    mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert k == [1] * len(segs)
+    assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
+    assert rel_rms(mix, ref_mix) <= 1e-5
+
+
 def test_fast_kernel_envelope_clock_beyond_2p24(dev):
     """Notes held for more than 2^24 frames (5.8 min at 48 kHz): (float)(uint64) stops being an
     exact +1 ramp; the kernel must fall back to the integer clock.  Crosses 2^24 inside a launch."""

@@ -318,9 +318,9 @@ def main():
         value = total * F * a.steps / dt
         rl = roofline(F, k_mean, k_min, k_cnt)
         rl["note"] = ("LUTs are LDS-resident and the recurrences live in registers, so compulsory HBM traffic is one "
-                      "state sweep per launch: at F=512 the kernel is bound by fp32 VALU issue (73% VALU-busy, "
-                      "profiles/r01_v8_c3_pmc_summary.json), not by HBM; the HBM fraction grows as F shrinks (low_latency). "
-                      "PCM banks (c4) gather from an L2-resident pool: profiles/r01_v8_c4_pmc_summary.json")
+                      "state sweep per launch: at F=512 the kernel is bound by fp32 VALU issue (72% VALU-busy, "
+                      "profiles/r01_v9_c3_pmc_summary.json), not by HBM; the HBM fraction grows as F shrinks (low_latency). "
+                      "PCM banks (c4) gather from an L2-resident pool: profiles/r01_v9_c4_pmc_summary.json")
         where = ""
         if world > 1:
             where = f"; one such bank per GPU ({world} GPUs)" if a.scaling == "weak" else f"; split over {world} GPUs"

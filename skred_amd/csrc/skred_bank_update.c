@@ -83,11 +83,11 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
     const int stops = h->voice_one_shot[v] && !h->voice_loop_enabled[v];
     /* a one-shot that plays to its end, and reverse playback, are still "clean" voices for the one-per-lane kernel's
      * extended instantiation */
-    if (stops || h->voice_direction[v] || quant || hold || !h->voice_smoother_enable[v]) c |= SKC_STOPS;
+    if (stops || h->voice_direction[v] || quant || hold || !h->voice_smoother_enable[v] || noise) c |= SKC_STOPS;
     /* a phase that lives on the device was finite when it was uploaded and the kernels keep it so */
     const float ph = phase_known ? h->voice_phase[v] : 0.0f, pi = h->voice_phase_inc[v];
     const int finite = (ph - ph == 0.0f) && (pi - pi == 0.0f) && (lo - lo == 0.0f) && (hi - hi == 0.0f) && hi > lo;
-    if (noise || (has_mod && !fm_only) || !finite)
+    if ((has_mod && !fm_only) || (!finite && !noise))        /* (a noise voice never runs its oscillator: synth.c:543-546) */
       c |= SKC_EXOTIC;
     if (fm_only) c |= SKC_FM;
     meta->cls = c;

@@ -52,6 +52,10 @@ struct FastRegs {
   int hold_max, hold_count, quant;
   float hold;
   bool nosmooth;
+  // the noise source (w6, synth.c:543-546): the voice takes the frame's shared LCG draw instead of running its
+  // oscillator; its phase is never touched (ophase is what goes back)
+  bool noise;
+  float ophase;
   // banks in which only some voices run the biquad / the envelope
   bool filt, use_env;
   float ox1, ox2, oy1, oy2;     // delay line of an UNfiltered voice as loaded: it is stored back untouched
@@ -116,13 +120,25 @@ __device__ __forceinline__ float fast_advance(FastRegs &r, float inc) {
   return ph;
 }
 
+// (extended instantiation) which per-lane features occur in the wave at all: wave-uniform, decided once per pass, so
+// that a wave only pays for the exchanges / tests of the features it holds
+#define XF_FM 1        /* a frequency-modulated lane: the modulator's previous sample comes through ds_bpermute */
+#define XF_AP 2        /* amplitude or pan modulation */
+#define XF_REV 4       /* reverse playback */
+#define XF_HOLDQ 8     /* sample & hold, bit-crush */
+#define XF_NOSMOOTH 16 /* smoother off */
+#define XF_NOISE 32    /* the noise source */
+#define XF_STOP 64     /* a one-shot that can finish */
+#define XF_ALL 127
+
 // The rest of the frame: biquad, envelope / gain, smoother, pan.
 // STALL (steady waves only): the smoother no longer moves in any lane (fast_smoother_stalled) and is skipped.
 // PLAIN (EXT only): the caller has proved that no lane of the wave is modulated or runs without the smoother
 // (`!any_fm`): only the per-lane filter / envelope flags of an extended bank remain.
 template <bool FILTER, bool ENV, bool STEADY, bool STALL = false, bool EXT = false, bool PLAIN = false>
 __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float &xo, float &yn, float &yo,
-                                          const bool released, float &out_l, float &out_r, const bool muted = false) {
+                                          const bool released, float &out_l, float &out_r, const bool muted = false,
+                                          const int xf = XF_ALL) {
   constexpr bool XMOD = EXT && !PLAIN;
   // ---- biquad (mmf_process, synth.c:349-364) ----
   if (FILTER) {
@@ -166,16 +182,16 @@ __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float
     gain = r.amp * (e * r.vel);
   }
   // ---- smoother + apply (synth.c:589-593), pan (synth.c:603-604) ----
-  if (XMOD && r.am_addr != -1)                           // final = amp * env * mod (synth.c:583-588)
+  if (XMOD && (xf & XF_AP) && r.am_addr != -1)           // final = amp * env * mod (synth.c:583-588)
     gain = gain * ((r.am_addr == -2 ? s : r.am_prev) * r.am_depth);
-  if (XMOD && r.nosmooth) {
+  if (XMOD && (xf & XF_NOSMOOTH) && r.nosmooth) {
     s *= gain;                                           // voice_smoother_gain is left alone (synth.c:589-593)
   } else {
     if (!STALL) r.sgain += r.k * (gain - r.sgain);
     s *= r.sgain;
   }
   r.sample = s;
-  if (XMOD && r.pm_addr != -1 && !muted) {               // synth.c:597-602 (inside the `not disconnected` branch)
+  if (XMOD && (xf & XF_AP) && r.pm_addr != -1 && !muted) {               // synth.c:597-602 (inside the `not disconnected` branch)
     const float q = (r.pm_addr == -2 ? s : r.pm_prev) * r.pm_depth;
     r.pan_l = (1.0f - q) / 2.0f;
     r.pan_r = (1.0f + q) / 2.0f;
@@ -202,22 +218,25 @@ template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTER
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r,
-                                           const bool any_fm = false, const bool muted = false, const bool any_ap = true) {
+                                           const int xf = 0, const bool muted = false, const float white = 0.0f) {
   float inc = r.inc;
-  if (STOPS && any_fm) {                                // wave-uniform: some lane of the wave is modulated
+  if (STOPS && (xf & (XF_FM | XF_AP))) {                // wave-uniform: some lane of the wave is modulated
     // voice_sample[m] as the previous frame left it (a modulator that is skipped this frame holds exact zero)
     const int mine = __float_as_int(r.sample);
-    const float ms = __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, mine));
-    if (r.fm_addr >= 0) inc = r.inc + r.fm_k * (ms * r.fm_depth);        // synth.c:551-554
-    if (any_ap) {                                        // wave-uniform: some lane is amplitude- or pan-modulated
+    if (xf & XF_FM) {
+      const float ms = __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, mine));
+      if (r.fm_addr >= 0) inc = r.inc + r.fm_k * (ms * r.fm_depth);      // synth.c:551-554
+    }
+    if (xf & XF_AP) {
       r.am_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.am_addr, 0), mine));
       r.pm_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.pm_addr, 0), mine));
     }
-    if (r.rev) inc = -inc;                               // reverse playback, applied to the modulated increment
   }
+  if (STOPS && (xf & XF_REV) && r.rev) inc = -inc;      // reverse playback, applied to the modulated increment
   const float ph = fast_advance<TAME, STOPS>(r, inc);
   float s = fast_fetch<TAB_LDS, INTERP, TAME && !STOPS>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
-  if (STOPS && any_fm) {                                // (the same wave-uniform flag covers every extended feature)
+  if (STOPS && (xf & XF_NOISE) && r.noise) s = white;   // synth.c:543-546 (the lane's oscillator idles on inert numbers)
+  if (STOPS && (xf & XF_HOLDQ)) {
     if (r.hold_max) {                                    // sample & hold, synth.c:560-571
       if (r.hold_count == 0) r.hold = s;
       s = r.hold;
@@ -225,7 +244,7 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     }
     if (r.quant) s = crush(s, r.quant);                  // synth.c:574
   }
-  fast_post<FILTER, ENV, STEADY, false, STOPS>(r, s, xn, xo, yn, yo, released, out_l, out_r, muted);
+  fast_post<FILTER, ENV, STEADY, false, STOPS>(r, s, xn, xo, yn, yo, released, out_l, out_r, muted, xf);
 }
 
 // ---- table windows for pools that do not fit in LDS (see skred_render_fast2.hip for the reasoning) ----
@@ -310,12 +329,17 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 }
 
 // one frame of the chunk loop: STEADY_ selects the envelope mode, A/B the delay-line roles
+// (STOPS) waves that hold a noise voice: the frame's shared draw, synth.c:525 -- one LCG step per frame of the launch
+#define SK_FAST_DRAW()                                                                                   \
+  float white_ = 0.0f;                                                                                   \
+  if (STOPS && (xf & XF_NOISE)) { rng = rng * LCG_A + LCG_C; white_ = (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f; }
 #define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO, SWAPPED_)                                              \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, any_fm, muted, any_ap); \
+    SK_FAST_DRAW()                                                                                       \
+    fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, white_); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
-    if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (J) == a.num_frames - 1, misc_xy); \
+    if (STOPS && (xf & XF_STOP) && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (J) == a.num_frames - 1, misc_xy); \
     SK_REDUCE_AND_STORE(J)                                                                               \
   }
 // two steady frames (J even, J+1): delay-line roles swap in between, one 4-chain reduction, one 16-byte store.
@@ -384,9 +408,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_X_FRAME(Q, XN, XO, YN, YO, SWAPPED_)                                                     \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast_frame<TAB_LDS, FILTER, ENV, true, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, any_fm, muted, any_ap); \
+    SK_FAST_DRAW()                                                                                       \
+    fast_frame<TAB_LDS, FILTER, ENV, true, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, white_); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
-    if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (Q) == a.num_frames - 1, misc_xy); \
+    if (STOPS && (xf & XF_STOP) && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (Q) == a.num_frames - 1, misc_xy); \
     xp[((Q) & 7) * 65 + lane] = make_float2(l, rr);                                                      \
   }
 #define SK_FAST_X_BLOCK(J)                                                                               \
@@ -517,6 +542,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.quant = STOPS ? (int)(tab.w & 0xFFu) : 0;
       r.hold = __uint_as_float(s2.x); r.hold_count = (int)s2.y;
       r.nosmooth = STOPS && !(flags & SKF_SMOOTH);
+      r.noise = STOPS && (flags & SKF_NOISE);
+      r.ophase = r.phase;
       muted = (flags & SKF_MUTED) != 0;
       if (STOPS && (a.fast_mode & SKM_FM)) {
         const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
@@ -546,17 +573,31 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       r.b0 = r.b1 = r.b2 = r.a1 = r.a2 = 0.0f; r.x1 = r.x2 = r.y1 = r.y2 = 0.0f;
       r.pan_l = r.pan_r = 0.0f; r.rw &= ~SKR_ENV_ACTIVE;
       r.stop = false; r.fm_addr = -1; r.am_addr = -1; r.pm_addr = -1; r.rev = false;
-      r.hold_max = 0; r.quant = 0; r.nosmooth = false;
+      r.hold_max = 0; r.quant = 0; r.nosmooth = false; r.noise = false;
     }
-    // lanes with any extended feature but stopping (modulated, reversed, sample & hold, crush, smoother off) in this
-    // wave: no table windows, no tame shortcuts, no stalled-smoother skip
-    const bool any_fm = STOPS && __any(r.fm_addr >= 0 || r.am_addr != -1 || r.pm_addr != -1 || r.rev || r.hold_max != 0 ||
-                                       r.quant != 0 || r.nosmooth);
-    const bool any_ap = STOPS && __any(r.am_addr != -1 || r.pm_addr != -1);
-    (void)any_ap;
-    const bool any_stop = STOPS && __any(r.stop);         // (a lane that finishes turns its flag off)
-    (void)any_stop;
-    (void)any_fm;
+    if (STOPS && r.noise) {
+      // osc_next is never called for a noise voice (synth.c:543-546: no phase advance, no finish, frequency modulation
+      // ignored): its oscillator idles on inert numbers; everything after the oscillator applies as usual
+      r.inc = 0.0f; r.lo = 0.0f; r.hi = 1.0f; r.span = 1.0f; r.span2 = 2.0f; r.phase = 0.0f;
+      r.toff4 = 0; r.tsize_m1 = 0;
+      r.stop = false; r.fm_addr = -1; r.rev = false;
+    }
+    // lanes with any extended feature but stopping (modulated, reversed, sample & hold, crush, smoother off, noise) in
+    // this wave: no table windows, no tame shortcuts, no stalled-smoother skip
+    int xf = 0;                                            // XF_*: wave-uniform
+    if (STOPS) {
+      if (__any(r.fm_addr >= 0)) xf |= XF_FM;
+      if (__any(r.am_addr != -1 || r.pm_addr != -1)) xf |= XF_AP;
+      if (__any(r.rev)) xf |= XF_REV;
+      if (__any(r.hold_max != 0 || r.quant != 0)) xf |= XF_HOLDQ;
+      if (__any(r.nosmooth)) xf |= XF_NOSMOOTH;
+      if (__any(r.noise)) xf |= XF_NOISE;
+      if (__any(r.stop)) xf |= XF_STOP;                    // (a lane that finishes turns its flag off: the bit stays, harmless)
+    }
+    const bool any_fm = (xf & ~XF_STOP) != 0;              // any extended feature but stopping
+    const bool any_stop = (xf & XF_STOP) != 0;
+    uint64_t rng = a.rng0;                                // noise LCG state before the first frame of the launch
+    (void)any_stop; (void)any_fm; (void)rng;
     // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
     // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>
     const bool tame = __all(dead || (r.inc >= 0.0f && r.inc <= 0.5f * r.span && r.phase >= r.lo && r.phase <= r.hi &&
@@ -654,7 +695,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
     if (!dead) {
       uint4 s0, s1;
       if (STOPS && !r.filt) { r.x1 = r.ox1; r.x2 = r.ox2; r.y1 = r.oy1; r.y2 = r.oy2; }
-      s0.x = __float_as_uint(r.phase); s0.y = __float_as_uint(r.sgain);
+      s0.x = __float_as_uint(STOPS && r.noise ? r.ophase : r.phase); s0.y = __float_as_uint(r.sgain);
       s0.z = __float_as_uint(r.x1);    s0.w = __float_as_uint(r.x2);
       s1.x = __float_as_uint(r.y1);    s1.y = __float_as_uint(r.y2);
       s1.z = __float_as_uint(r.sample); s1.w = r.rw;

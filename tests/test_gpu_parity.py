@@ -7,6 +7,7 @@ Bars:
   * float mix: RMS error <= 1e-5 against the reference / the f64-accumulated truth
     (the wavefront tree sum orders additions differently from the reference's voice loop).
 """
+import os
 import numpy as np
 import pytest
 
@@ -564,12 +565,16 @@ def _clean_fuzz_bank(rng):
             tgt = np.minimum(tgt, n - 1)
             bank[osc][c2] = tgt
             bank[depth][c2] = (rng.random(len(c2)) * top).astype(np.float32)
+    if rng.random() < 0.4:                            # w6 voices: the frame's shared LCG draw (extended instantiation)
+        bank["voice_wave_table_index"][rng.random(n) < 0.06] = 6
+        g.noise_rng = int(rng.integers(1, 1 << 62))
+        stops = True
     return recipe, bank, tables, g, stops or fm
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("SKRED_FUZZ_SEEDS", "6")))))
 def test_clean_family_fuzz_vs_oracle(dev, seed):
-    """Fuzz of the specialised kernels (one / two voices per lane, LDS tables / table windows, stopping one-shots, FM):
+    """Fuzz of the specialised kernels (one / two voices per lane, LDS tables / table windows, stopping one-shots, FM, noise):
     random clean banks, random block lengths, note-offs and re-triggers in between; per-voice state bit-exact."""
     rng = np.random.default_rng(1000 + seed)
     recipe, bank, tables, g, stops = _clean_fuzz_bank(rng)
@@ -700,9 +705,45 @@ def test_hold_crush_and_unsmoothed_voices_on_the_specialised_kernel(dev):
 
 def test_exotic_voice_forces_generic_kernel(dev):
     bank, tables, g = banks.bank_c2(512)
-    bank["voice_wave_table_index"][5] = 6           # w6, the noise source
-    _, _, k = _run_scenario(dev, bank, tables, g, 0, [(64, None)], force_generic=False)
+    bank["voice_phase_inc"][5] = np.inf             # osc_next's !isfinite() branch: only the generic kernel has it
+    mix, state, k = _run_scenario(dev, bank, tables, g, 0, [(64, None)], force_generic=False)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, 0, [(64, None)])
     assert k == [0]
+    assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
+
+
+@pytest.mark.parametrize("recipe,interp", [("c2", 0), ("c4", 1)])
+def test_noise_voices_on_the_specialised_kernel(dev, recipe, interp):
+    """w6 voices (synth.c:543-546) take the frame's shared LCG draw instead of running their oscillator: phase
+    untouched, frequency modulation ignored, everything downstream (sample & hold, crush, biquad, envelope, smoother,
+    pan) as usual.  The one-per-lane kernel's extended instantiation steps the LCG once per frame in the waves that hold
+    such a voice; banks with noise voices no longer need the generic kernel.  Among the noise voices: a one-shot (never
+    finishes), a reversed one, one with a wild phase, a sample-and-hold one, a modulated one, a muted modulator."""
+    n = 1500
+    bank, tables, g = banks.RECIPES[recipe](n)
+    v = np.arange(n)
+    noisy = (v % 13 == 4) & (v > 200)               # the first waves stay free of noise voices
+    bank["voice_wave_table_index"][noisy] = 6
+    idx = v[noisy]
+    bank["voice_one_shot"][idx[0]] = 1; bank["voice_loop_enabled"][idx[0]] = 0
+    bank["voice_direction"][idx[1]] = 1
+    bank["voice_phase"][idx[2]] = np.float32(1e9)
+    bank["voice_sample_hold_max"][idx[3:40:3]] = 5
+    bank["voice_quantize"][idx[4:40:3]] = 6
+    car = idx[5]                                    # frequency modulation of a noise voice is ignored
+    bank["voice_freq_mod_osc"][car] = car + 1; bank["voice_freq_mod_depth"][car] = 2.0
+    car2 = idx[6] - 1                               # a noise voice as (muted) modulator of the voice below it
+    bank["voice_freq_mod_osc"][car2] = car2 + 1; bank["voice_freq_mod_depth"][car2] = 0.3
+    bank["voice_disconnect"][car2 + 1] = 1
+    g.noise_rng = 0x1234567
+    segs = [(301, None), (333, _release_odd_voices), (700, None), (64, None)]
+    mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False)
+    gmix, gstate, kg = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=True)   # (modulators: the modulated kernel)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert k == [1] * len(segs) and kg == [2] * len(segs), (k, kg)
+    assert not gstate.rw_equal(ref_state), gstate.rw_equal(ref_state)
+    assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
+    assert rel_rms(mix, ref_mix) <= 1e-5
 
 
 @pytest.mark.parametrize("recipe,interp", [("c1", 0), ("c2", 0), ("c2", 1), ("c4", 0), ("c4", 1)])

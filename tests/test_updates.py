@@ -94,7 +94,7 @@ def actions_for_block(k, n, rng, D):
 
 def test_updates_without_ever_downloading(dev):
     """40 blocks of mixed control actions on a 3000-voice filtered bank (specialised kernel); at block 12 a voice
-    switches to the noise source (the bank needs the generic kernel), at block 20 it switches back."""
+    gets a non-finite phase increment (the bank needs the generic kernel), at block 20 it gets its own back."""
     D = dev
     n = 3000
     bank, tables, g = banks.bank_c2(n)
@@ -110,8 +110,8 @@ def test_updates_without_ever_downloading(dev):
         now = gl.synth_sample_count
         acts = actions_for_block(k, n, rng, D)
         if k in (12, 20):
-            def flip(b, vs, now_, st, on=(k == 12)):
-                b["voice_wave_table_index"][vs] = 6 if on else 0     # w6, the noise source: only the generic kernel has it
+            def flip(b, vs, now_, st, on=(k == 12), inc0=bank["voice_phase_inc"][77]):
+                b["voice_phase_inc"][vs] = np.inf if on else inc0    # osc_next's !isfinite() branch: only the generic kernel has it
             acts.append(Action([77], D.DIRTY_PARAMS, flip))
         for a in acts:
             a.apply_to(truth, now)

@@ -337,8 +337,8 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   HIP_TRY(hipSetDevice(b->device));
   classify(b);
   /* the modulated kernel serves every kind of modulation; banks whose only modulation is previous-frame FM stay on
-   * the one-per-lane kernel when they are otherwise clean (and no stems are asked for) */
-  const int fast_ok = (b->fast_mode & SKM_FAST) && !b->force_generic && !d_stems;
+   * the one-per-lane kernel when they are otherwise clean */
+  const int fast_ok = (b->fast_mode & SKM_FAST) && !b->force_generic;
   const int modulated = (b->features & SKB_ANY_MOD) != 0 || ((b->features & SKB_ANY_FM) && b->cnt_fm > 0 && !fast_ok);
   int n_wg = b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS;   /* workgroups stride over 256-voice passes */
   /* partial rows: alternate between two buffers (only the overlapped tail needs it; harmless otherwise) */
@@ -370,12 +370,12 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   a.interp = interp;
   a.features = b->features;
   classify(b);
-  a.fast_mode = (b->force_generic || d_stems) ? 0u : b->fast_mode;
+  a.fast_mode = b->force_generic ? 0u : b->fast_mode;
   /* two voices per lane pay off for large LDS-table banks (packed fp32); banks whose tables stay in L2 / HBM do
    * better with one voice per lane at every size measured (2^16 .. 2^20: twice the waves to hide the window
    * refills behind) unless the caller set the threshold explicitly */
   if ((a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_STOPS | SKM_FM)) && b->n_voices >= b->fast2_min_voices &&
-      (a.lds_table_floats > 0 || b->fast2_min_user))
+      (a.lds_table_floats > 0 || b->fast2_min_user) && !d_stems)      /* (per-voice stems: the one-voice kernel writes them) */
     a.fast_mode |= SKM_TWO_PER_LANE;        /* (voices that finish mid-launch are handled by the one-per-lane kernel only) */
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;

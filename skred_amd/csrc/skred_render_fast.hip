@@ -329,6 +329,12 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 }
 
 // one frame of the chunk loop: STEADY_ selects the envelope mode, A/B the delay-line roles
+// per-voice stems (synth.c:607-611; a.stems != NULL): frame I of this chunk, this lane's voice; skipped and muted voices
+// write exact +0.0f like the reference (an inert lane's product can be -0.0f)
+#define SK_FAST_STEM(I, L, R)                                                                            \
+  if (stems_on && v < a.n_voices)                                                                        \
+    reinterpret_cast<float2 *>(a.stems)[(size_t)(c0 + (I)) * (size_t)a.n_voices + (size_t)v] =          \
+        make_float2(silent ? 0.0f : (L), silent ? 0.0f : (R));
 // (STOPS) waves that hold a noise voice: the frame's shared draw, synth.c:525 -- one LCG step per frame of the launch
 #define SK_FAST_DRAW()                                                                                   \
   float white_ = 0.0f;                                                                                   \
@@ -339,6 +345,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     SK_FAST_DRAW()                                                                                       \
     fast_frame<TAB_LDS, FILTER, ENV, STEADY_, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, white_); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
+    SK_FAST_STEM(J, l, rr)                                                                               \
     if (STOPS && (xf & XF_STOP) && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (J) == a.num_frames - 1, misc_xy); \
     SK_REDUCE_AND_STORE(J)                                                                               \
   }
@@ -354,6 +361,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     fast_post<FILTER, ENV, true, false, STOPS, true>(r, sa_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);        \
     fast_post<FILTER, ENV, true, false, STOPS, true>(r, sb_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);        \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
+    SK_FAST_STEM(J, l0, r0) SK_FAST_STEM((J) + 1, l1, r1)                                                \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
 // Eight steady frames (J..J+7) of a tame wave of an LDS-table bank with the cross-lane sum through LDS instead of
@@ -396,6 +404,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       float l0, r0, l1, r1;                                                                              \
       fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, smp_[q_], r.x1, r.x2, r.y1, r.y2, released, l0, r0);     \
       fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, smp_[q_ + 1], r.x2, r.x1, r.y2, r.y1, released, l1, r1); \
+      SK_FAST_STEM((J) + q_, l0, r0) SK_FAST_STEM((J) + q_ + 1, l1, r1)                                  \
       xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
       xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
     }                                                                                                    \
@@ -411,6 +420,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     SK_FAST_DRAW()                                                                                       \
     fast_frame<TAB_LDS, FILTER, ENV, true, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, white_); \
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
+    SK_FAST_STEM(Q, l, rr)                                                                               \
     if (STOPS && (xf & XF_STOP) && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (Q) == a.num_frames - 1, misc_xy); \
     xp[((Q) & 7) * 65 + lane] = make_float2(l, rr);                                                      \
   }
@@ -436,7 +446,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
       fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
       if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); \
-      { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
+      { const int J_ = (J) + q_; (void)J_; SK_FAST_STEM(J_, l0, r0) SK_FAST_STEM(J_ + 1, l1, r1) SK_REDUCE4_AND_STORE(J_) } \
     }                                                                                                    \
   }
 // after an EVEN frame the newest delay-line entries sit in x2 / y2 (roles swapped), after an ODD one in x1 / y1
@@ -480,6 +490,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
 
   const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;
   bool first_pass = true;
+  const bool stems_on = a.stems != nullptr;          // (launch-uniform: one scalar branch per frame)
 
   for (int g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
     const int v = g * SK_GROUP + tid;

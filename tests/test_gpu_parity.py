@@ -922,23 +922,26 @@ def test_random_feature_mix_vs_oracle(dev, seed):
     ref_bank, ref_g = b.copy(), g.copy()
     r = cpuref.render(ref_bank, ref_g, tables, frames, 0, want_stems=True)
     ref_mix = cpuref.master(ref_g, r["sum64"].astype(np.float32))
-    db = dev.DeviceBank(n)
-    db.set_tables(tables)
-    db.upload(b)
-    db.set_globals(g)
-    mix, stems = db.render_host(frames, 2, 0, want_stems=True)
-    assert db.last_kernel() == (2 if modulated else 0)
-    got = b.copy()
-    db.download(got)
-    gl = db.get_globals()
-    db.close()
-    finite = np.isfinite(r["stems"]) 
-    assert gio.bits_equal(np.where(finite, stems, 0), np.where(finite, r["stems"], 0)), "stems differ"
-    assert (np.isfinite(stems) == finite).all()
-    assert not got.rw_equal(ref_bank), got.rw_equal(ref_bank)
-    assert gl.noise_rng == ref_g.noise_rng
-    if np.isfinite(ref_mix).all():
-        assert rel_rms(mix, ref_mix) <= 1e-5
+    # unmodulated banks: the one-voice kernel's extended instantiation (it writes stems too), then the generic kernel
+    for force in ((False,) if modulated else (False, True)):
+        db = dev.DeviceBank(n)
+        db.set_tables(tables)
+        db.upload(b)
+        db.set_globals(g)
+        db.force_generic(force)
+        mix, stems = db.render_host(frames, 2, 0, want_stems=True)
+        assert db.last_kernel() == (2 if modulated else 0 if force else 1)
+        got = b.copy()
+        db.download(got)
+        gl = db.get_globals()
+        db.close()
+        finite = np.isfinite(r["stems"])
+        assert gio.bits_equal(np.where(finite, stems, 0), np.where(finite, r["stems"], 0)), "stems differ"
+        assert (np.isfinite(stems) == finite).all()
+        assert not got.rw_equal(ref_bank), got.rw_equal(ref_bank)
+        assert gl.noise_rng == ref_g.noise_rng
+        if np.isfinite(ref_mix).all():
+            assert rel_rms(mix, ref_mix) <= 1e-5
 
 
 def test_non_finite_phase_increments(dev):

@@ -64,14 +64,11 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   b->timing_every = 1;
   b->n_padded = b->n_groups * SK_GROUP;
   const size_t plane_bytes = (size_t)b->n_padded * sizeof(sk_plane_t);
-  for (int p = 0; p < SKP_COUNT; p++) {
-    HIP_TRY(hipMalloc((void **)&b->d_ro[p], plane_bytes));
-    HIP_TRY(hipMemset(b->d_ro[p], 0, plane_bytes));
-  }
-  for (int p = 0; p < SKS_COUNT; p++) {
-    HIP_TRY(hipMalloc((void **)&b->d_rw[p], plane_bytes));
-    HIP_TRY(hipMemset(b->d_rw[p], 0, plane_bytes));
-  }
+  /* one slab, planes back to back (read-only planes first): a window of voices across all planes is one pitched copy */
+  HIP_TRY(hipMalloc((void **)&b->d_planes, (size_t)(SKP_COUNT + SKS_COUNT) * plane_bytes));
+  HIP_TRY(hipMemset(b->d_planes, 0, (size_t)(SKP_COUNT + SKS_COUNT) * plane_bytes));
+  for (int p = 0; p < SKP_COUNT; p++) b->d_ro[p] = b->d_planes + (size_t)p * (size_t)b->n_padded;
+  for (int p = 0; p < SKS_COUNT; p++) b->d_rw[p] = b->d_planes + (size_t)(SKP_COUNT + p) * (size_t)b->n_padded;
   /* every slot starts inert (skipped by the kernel) until a voice is uploaded into it */
   sk_plane_t *inert = (sk_plane_t *)calloc((size_t)b->n_padded, sizeof(sk_plane_t));
   if (!inert) return fail(SKRED_E_NO_MEM, "calloc");
@@ -117,8 +114,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
 void skred_bank_destroy(skred_bank_t *b) {
   if (!b) return;
   hipSetDevice(b->device);
-  for (int p = 0; p < SKP_COUNT; p++) if (b->d_ro[p]) hipFree(b->d_ro[p]);
-  for (int p = 0; p < SKS_COUNT; p++) if (b->d_rw[p]) hipFree(b->d_rw[p]);
+  if (b->d_planes) hipFree(b->d_planes);
   if (b->d_tables) hipFree(b->d_tables);
   for (int i = 0; i < 2; i++) {
     if (b->d_partial_buf[i]) hipFree(b->d_partial_buf[i]);
@@ -190,11 +186,9 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
     for (int p = 0; p < SKS_COUNT; p++) st[(size_t)(SKP_COUNT + p) * count + i] = rw[p];
   }
   const size_t bytes = (size_t)count * sizeof(sk_plane_t);
-  hipError_t e = hipSuccess;
-  for (int p = 0; p < SKP_COUNT && e == hipSuccess; p++)
-    e = hipMemcpy(b->d_ro[p] + dst_first, st + (size_t)p * count, bytes, hipMemcpyHostToDevice);
-  for (int p = 0; p < SKS_COUNT && e == hipSuccess; p++)
-    e = hipMemcpy(b->d_rw[p] + dst_first, st + (size_t)(SKP_COUNT + p) * count, bytes, hipMemcpyHostToDevice);
+  /* all planes of the window in one pitched copy (rows = planes) */
+  const hipError_t e = hipMemcpy2D(b->d_planes + dst_first, (size_t)b->n_padded * sizeof(sk_plane_t), st, bytes, bytes, (size_t)NP,
+                                   hipMemcpyHostToDevice);
   free(st);
   if (e != hipSuccess) { free(meta); HIP_TRY(e); }
   if (dst_first == 0 && count == b->n_voices) { b->features = 0; b->mod_escapes = 0; }   /* whole bank replaced */
@@ -267,9 +261,9 @@ int skred_bank_download(skred_bank_t *b, skred_voice_bank_t *h, int src_first, i
   sk_plane_t *st = (sk_plane_t *)malloc((size_t)SKS_COUNT * (size_t)count * sizeof(sk_plane_t));
   if (!st) return fail(SKRED_E_NO_MEM, "download staging");
   HIP_TRY(hipDeviceSynchronize());
-  hipError_t e = hipSuccess;
-  for (int p = 0; p < SKS_COUNT && e == hipSuccess; p++)
-    e = hipMemcpy(st + (size_t)p * count, b->d_rw[p] + src_first, (size_t)count * sizeof(sk_plane_t), hipMemcpyDeviceToHost);
+  const size_t bytes = (size_t)count * sizeof(sk_plane_t);
+  const hipError_t e = hipMemcpy2D(st, bytes, b->d_rw[0] + src_first, (size_t)b->n_padded * sizeof(sk_plane_t), bytes, (size_t)SKS_COUNT,
+                                   hipMemcpyDeviceToHost);      /* the read-write planes of the window: one pitched copy */
   if (e != hipSuccess) { free(st); HIP_TRY(e); }
   for (int i = 0; i < count; i++) {
     const int v = dst_first + i;

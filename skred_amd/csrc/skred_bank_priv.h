@@ -28,6 +28,7 @@ typedef struct {
 struct skred_bank {
   int device;
   int n_voices, n_padded, n_groups;
+  sk_plane_t *d_planes;       /* the slab behind d_ro[] / d_rw[] */
   sk_plane_t *d_ro[SKP_COUNT];
   sk_plane_t *d_rw[SKS_COUNT];
   float *d_tables;

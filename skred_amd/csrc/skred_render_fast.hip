@@ -330,7 +330,9 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 
 // one frame of the chunk loop: STEADY_ selects the envelope mode, A/B the delay-line roles
 // per-voice stems (synth.c:607-611; a.stems != NULL): frame I of this chunk, this lane's voice; skipped and muted voices
-// write exact +0.0f like the reference (an inert lane's product can be -0.0f)
+// write exact +0.0f like the reference (an inert lane's product can be -0.0f).  Only the frame-by-frame paths carry
+// it: a launch with stems takes those for every chunk, so the block and pair paths stay free of the test (one more
+// scalar instruction per frame costs a lone wave 5 % on a small bank)
 #define SK_FAST_STEM(I, L, R)                                                                            \
   if (stems_on && v < a.n_voices)                                                                        \
     reinterpret_cast<float2 *>(a.stems)[(size_t)(c0 + (I)) * (size_t)a.n_voices + (size_t)v] =          \
@@ -361,7 +363,6 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     fast_post<FILTER, ENV, true, false, STOPS, true>(r, sa_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);        \
     fast_post<FILTER, ENV, true, false, STOPS, true>(r, sb_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);        \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
-    SK_FAST_STEM(J, l0, r0) SK_FAST_STEM((J) + 1, l1, r1)                                                \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
 // Eight steady frames (J..J+7) of a tame wave of an LDS-table bank with the cross-lane sum through LDS instead of
@@ -404,7 +405,6 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       float l0, r0, l1, r1;                                                                              \
       fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, smp_[q_], r.x1, r.x2, r.y1, r.y2, released, l0, r0);     \
       fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, smp_[q_ + 1], r.x2, r.x1, r.y2, r.y1, released, l1, r1); \
-      SK_FAST_STEM((J) + q_, l0, r0) SK_FAST_STEM((J) + q_ + 1, l1, r1)                                  \
       xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
       xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
     }                                                                                                    \
@@ -446,7 +446,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
       fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
       if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); \
-      { const int J_ = (J) + q_; (void)J_; SK_FAST_STEM(J_, l0, r0) SK_FAST_STEM(J_ + 1, l1, r1) SK_REDUCE4_AND_STORE(J_) } \
+      { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
     }                                                                                                    \
   }
 // after an EVEN frame the newest delay-line entries sit in x2 / y2 (roles swapped), after an ODD one in x1 / y1
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
       // a stopping voice that cannot reach its table end within this chunk (forward, unmodulated: phase + 64*inc,
       // rounding included, stays below it) needs no per-frame finish test yet
       const bool stop_near = STOPS && any_stop && __any(r.stop && !(r.phase + (float)SK_CHUNK * r.inc + 2.0f < r.hi));
-      if (STOPS && (!ENV || steady) && tame && !any_fm && !stop_near && TAB_LDS) {
+      if (STOPS && (!ENV || steady) && tame && !any_fm && !stop_near && TAB_LDS && !stems_on) {
         // an extended bank, but nothing in THIS wave needs the frame loop now (e.g. only some voices filtered, or one-shots
         // still far from their end): frame pairs
         int j = 0, pend_j = -1;
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (STOPS && (!ENV || steady)) {
         int j = 0;
-        if (!TAB_LDS && tame && !any_fm) {   // a voice about to finish is `direct` in its window block; the block checks per frame
+        if (!TAB_LDS && tame && !any_fm && !stems_on) {   // a voice about to finish is `direct` in its window block; the block checks per frame
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
         } else {
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
         }
         for (; j + 1 < cn; j += 2) { SK_FAST_EVEN(j, true) SK_FAST_ODD(j + 1, true) }
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
-      } else if ((!ENV || steady) && tame) {
+      } else if ((!ENV || steady) && tame && !stems_on) {
         int j = 0;
         if (!TAB_LDS) {
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
@@ -670,7 +670,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (!ENV || steady) {
         int j = 0;
-        for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, false)
+        if (stems_on) for (; j + 1 < cn; j += 2) { SK_FAST_EVEN(j, true) SK_FAST_ODD(j + 1, true) }   // frame by frame, stems written
+        else for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, false)
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (exact) {
         int j = 0;

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""tools/measure_banks.py SCENARIO... -- the one-off measurements quoted in DESIGN.md, reproducible (run on the GPU box).
+
+  kernels    the users of the one-voice kernel at BASELINE sizes (C1/C2, 2^18 / 2^20 banks forced onto it, FM, one-shots)
+  crossover  one voice per lane vs two per lane, 32 768 .. 262 144 voices  (SK_FAST2_MIN_VOICES)
+  overhead   per-block time outside the render kernel on small banks (overlapped tail, sampled kernel timing)
+  frames     kernel time vs frames per launch on a 4096-voice bank (per-frame cost of a lone wavefront + fixed cost)
+  fm         2^20-voice two-operator FM banks (carrier v, modulator v+1)
+  noise      2^20-voice banks with w6 voices, specialised vs generic kernel
+  live       notes starting / ending every block on a 2^20-voice bank (cost of control)
+
+Each line: ms per block over the timed blocks (wall clock, tail overlapped), voice-samples/s, and the render kernel's
+duration from the library's own event pair around the latest bracketed launch.
+"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from skred_amd import banks, device  # noqa: E402
+
+
+def run(name, bank, tables, g, interp=0, F=512, steps=60, min2=None, generic=False, overlap=True, timing=4):
+    n = bank.n
+    out = torch.zeros(F, 2, device="cuda")
+    db = device.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    if min2 is not None:
+        db.fast2_min_voices(min2)
+    db.force_generic(generic)
+    db.overlap_tail(overlap)
+    db.kernel_timing(timing)
+    for _ in range(25):
+        db.render_mix(F, out.data_ptr(), 2, 0, interp)
+    db.wait_mix(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        db.render_mix(F, out.data_ptr(), 2, 0, interp)
+    t1 = time.perf_counter()
+    db.wait_mix(0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    k = f"{db.last_render_ms():.4f}" if timing else "-"
+    print(f"{name:48s} kernel={db.last_kernel()} {dt * 1e3:.4f} ms/block {n * F / dt:.3e} voice-samples/s  "
+          f"render kernel {k} ms  host issue {(t1 - t0) / steps * 1e6:.1f} us")
+    db.close()
+
+
+def kernels():
+    b, t, g = banks.bank_c1(4096); run("c1 4096", b, t, g)
+    b, t, g = banks.bank_c1(65536); run("c1 65536", b, t, g)
+    b, t, g = banks.bank_c2(65536); run("c2 65536", b, t, g)
+    b, t, g = banks.bank_c2(1 << 18); run("c2 2^18 two per lane", b, t, g, min2=1)
+    b, t, g = banks.bank_c2(1 << 18); run("c2 2^18 one per lane", b, t, g, min2=1 << 30)
+    b, t, g = banks.bank_c2(1 << 20); run("c2 2^20 one per lane", b, t, g, min2=1 << 30)
+    b, t, g = banks.bank_c2(1 << 20)
+    car = np.arange(0, 1 << 20, 8); b["voice_freq_mod_osc"][car] = car + 3; b["voice_freq_mod_depth"][car] = 0.2
+    run("c2 2^20 FM (1/8 carriers)", b, t, g)
+    b, t, g = banks.bank_c2(1 << 20)
+    b["voice_one_shot"][::3] = 1; b["voice_loop_enabled"][::3] = 0
+    run("c2 2^20 one-shots (1/3, finished after warm-up)", b, t, g)
+    b, t, g = banks.bank_c2(1 << 20); run("c3 2^20 two per lane", b, t, g)
+    b, t, g = banks.bank_c4(262144); run("c4 262144 linear", b, t, g, interp=1)
+
+
+def crossover():
+    for rec in ("c1", "c2"):
+        for n in (32768, 65536, 131072, 196608, 262144):
+            b, t, g = banks.RECIPES[rec](n)
+            run(f"{rec} {n} one per lane", b, t, g, min2=1 << 30)
+            run(f"{rec} {n} two per lane", b, t, g, min2=1)
+
+
+def overhead():
+    for n in (4096, 65536):
+        b, t, g = banks.bank_c1(n)
+        run(f"c1 {n} overlapped tail, timing every 4th", b, t, g, steps=200)
+        run(f"c1 {n} overlapped tail, no timing", b, t, g, steps=200, timing=0)
+        run(f"c1 {n} in-order tail, no timing", b, t, g, steps=200, timing=0, overlap=False)
+
+
+def frames():
+    for rec in ("c1", "c2"):
+        for F in (64, 256, 512, 2048):
+            b, t, g = banks.RECIPES[rec](4096)
+            run(f"{rec} 4096 F={F}", b, t, g, F=F, steps=100, timing=1)
+
+
+def fm():
+    for rec in ("c1", "c2"):
+        for mute in (False, True):
+            b, t, g = banks.RECIPES[rec](1 << 20)
+            car = np.arange(0, 1 << 20, 2)
+            b["voice_freq_mod_osc"][car] = car + 1
+            b["voice_freq_mod_depth"][car] = 0.2
+            if mute:
+                b["voice_disconnect"][car + 1] = 1
+            run(f"{rec} 2^20 two-operator FM" + (", modulators muted (m1)" if mute else ""), b, t, g, steps=40)
+
+
+def noise():
+    n = 1 << 20
+    for frac, label in ((0.05, "5% noise voices, scattered"), (0.0, "noise voices in the last 1/16 of the bank")):
+        b, t, g = banks.bank_c2(n)
+        v = np.arange(n)
+        if frac:
+            b["voice_wave_table_index"][(v * 2654435761 % 1000) < frac * 1000] = 6
+        else:
+            b["voice_wave_table_index"][n - n // 16:] = 6
+        run("c2 2^20 " + label, b, t, g, steps=30)
+        run("c2 2^20 " + label + " (generic kernel)", b, t, g, steps=30, generic=True)
+
+
+def live():
+    D = device
+    n, F = 1 << 20, 512
+    out = torch.zeros(F, 2, device="cuda")
+    bank, tables, g = banks.bank_c2(n)
+    db = device.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    db.overlap_tail(True)
+    db.kernel_timing(0)
+    for _ in range(30):
+        db.render_mix(F, out.data_ptr(), 2)
+    rng = np.random.default_rng(1)
+    for frac in (0.0, 0.0001, 0.0005, 0.005, 0.02):
+        k = int(n * frac)
+        for _rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(60):
+                if k:
+                    vs = rng.choice(n, k, replace=False).astype(np.int32)
+                    db.update(bank, vs[:k // 2], D.STAMP_RELEASE)
+                    db.update(bank, vs[k // 2:], D.STAMP_TRIGGER | D.DIRTY_PHASE | D.DIRTY_PARAMS)
+                db.render_mix(F, out.data_ptr(), 2)
+            db.wait_mix(0)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 60
+        print(f"{frac * 100:.2f} % of the voices get a note-off / note-on per block: {dt * 1e3:.3f} ms/block  "
+              f"{n * F / dt:.3e} voice-samples/s")
+    db.close()
+
+
+SCENARIOS = {"kernels": kernels, "crossover": crossover, "overhead": overhead, "frames": frames, "fm": fm,
+             "noise": noise, "live": live}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(SCENARIOS)
+    for nm in names:
+        if nm not in SCENARIOS:
+            sys.exit(f"unknown scenario {nm!r}; one of: {', '.join(SCENARIOS)}")
+    for nm in names:
+        print(f"== {nm}")
+        SCENARIOS[nm]()

@@ -264,9 +264,10 @@ int  skred_bank_defer(skred_bank_t *bank, uint64_t when, const skred_voice_bank_
 int  skred_bank_run_queue(skred_bank_t *bank, int frame_count, void *stream);
 int  skred_bank_queue_pending(const skred_bank_t *bank);
 
-/* Options.  Two kernels implement the render loop: a generic one (every synth() feature the path
- * supports) and a specialised one chosen automatically for "clean" banks; their per-voice results are
- * bit-identical.  FORCE_GENERIC pins the generic kernel (used by the parity tests to cross-check). */
+/* Options.  The render loop has full-featured kernels (generic; modulated for banks with cross-voice modulation) and
+ * specialised ones chosen per launch from what the bank holds (one voice per lane, two per lane);
+ * their per-voice results, stems included, are bit-identical.  FORCE_GENERIC pins the full-featured kernels (the parity
+ * tests use it to cross-check the specialised ones). */
 enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size from which the two-voices-per-lane kernel is used */,
        SKRED_OPT_KERNEL_TIMING = 4 /* n: an event pair brackets the render kernels of every n-th launch (default 1: every
                                       launch; 0: none).  skred_bank_last_render_ms / _timing_summary report the bracketed

@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
                     help="weak (default): every GPU gets a whole bank of the workload size; strong: one bank is split over the GPUs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-fixed-point", action="store_true", help="skip the fixed-point leg (N=1 only)")
     ap.add_argument("--no-low-latency", action="store_true", help="skip the secondary F=64 measurement")
     ap.add_argument("--no-recipe-warmup", action="store_true",
                     help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
@@ -355,6 +356,31 @@ def main():
         lb["value"] = total * 4800 * k3 / dt3
         lb["realtime_factor_48k"] = lb["value"] / (total * 48000.0)
         res["long_block"] = lb
+    # the fixed-point LUT path (include/skred_amd_fxpt.h; integer mix, exact): same voice count, int16 LUT pyramids in LDS,
+    # linear interpolation, ADSR + smoother, no biquad (section 6 of DESIGN.md)
+    if world == 1 and not a.no_low_latency and not a.no_fixed_point and a.workload != "c4":
+        from skred_amd import fxbank
+        fb, fpool, fcount0 = fxbank.bank_fx(bank_voices)
+        fdb = fxbank.DeviceFxBank(bank_voices, local)
+        fdb.set_tables(fpool)
+        fdb.upload(fb)
+        fdb.set_sample_count(fcount0)
+        fmix = torch.zeros(F, 2, device=dev, dtype=torch.int64)
+        for _ in range(12 + a.warmup):                      # 12 x 512 frames: the recipe's last note-on reaches sustain
+            fdb.render(F, fmix.data_ptr(), 1, 0, stream)
+        fence()
+        t0 = time.perf_counter()
+        kms = []
+        for _ in range(a.steps):
+            fdb.render(F, fmix.data_ptr(), 1, 0, stream)
+        fence()
+        fdt = time.perf_counter() - t0
+        kms.append(fdb.last_render_ms())
+        res["fixed_point"] = {"value": bank_voices * F * a.steps / fdt, "unit": "voice-samples/s", "dtype": "q15/u32/i64",
+                              "frames_per_launch": F, "ms_per_step": fdt / a.steps * 1e3, "kernel": "sk_fx_render_kernel",
+                              "kernel_ms_last": kms[-1], "mix_nonzero": bool((fmix != 0).any().item()),
+                              "workload": "fixed-point analogue of the C2 recipe without the biquad (fxbank.bank_fx), linear interpolation"}
+        fdb.close()
     if rank == 0:
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(recipe, interp)

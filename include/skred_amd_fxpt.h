@@ -19,9 +19,10 @@
  *              held         e = S                      (sample_release == 0)
  *              tr < R       e = S - ((((tr * rR) >> 17) * S) >> 15),  tr = sat32(now - sample_release)
  *              else         e = 0, is_active = 0
- *   gain     target = (amp_q15 * ((e * velocity_q15) >> 15)) >> 15        (amp_q15 <= 65535)
+ *   gain     target = (amp_q15 * ((e * velocity_q15) >> 15)) >> 15        (amp_q15 <= 65535; this product in 64 bits)
  *            smoother (optional): g += ((target - g) * k_q15) >> 15, gain = g
- *   output   v = (s * gain) >> 15 ; L = (v * pan_left_q15) >> 15 ; R = (v * pan_right_q15) >> 15
+ *   output   v = (s * gain) >> 15 (product in 64 bits) ; L = (v * pan_left_q15) >> 15 ; R = (v * pan_right_q15) >> 15
+ *            every other product is an int32 one (keep it inside 32 bits: Q15 gains, velocity <= 65535)
  *   mix      int64 sum of L and of R over all voices, per frame
  *   skipped  amp_q15 == 0: v = 0, state frozen (as synth.c:537-542 does for the float path)
  */

@@ -36,11 +36,92 @@ __device__ __forceinline__ void wave_isum2_to_lane63(int &l, int &r) {
 
 __device__ __forceinline__ uint32_t sat32(uint64_t x) { return x > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)x; }
 
+// a * b of the definition (int32, wrapping).  NARROW: the caller has proved that both operands fit 24 bits signed, so
+// v_mul_i32_i24 (full rate; the 32-bit v_mul_lo_u32 is quarter rate) returns the same low 32 bits
+template <bool NARROW>
+__device__ __forceinline__ int fxmul(int a, int b) { return NARROW ? __mul24(a, b) : a * b; }
+// (a * b) >> 15 where the definition forms the product in 64 bits (amp * e, s * gain: oracle/cpu_ref_fxpt.c:67,74).
+// NARROW: both operands fit 24 bits and the product fits 32, so the 24-bit multiply and a 32-bit shift give the same
+__device__ __forceinline__ int fxmul64_s15(int a, int b) { return (int)(((long long)a * (long long)b) >> 15); }
+template <bool NARROW>
+__device__ __forceinline__ int fxmul_s15(int a, int b) { return NARROW ? (__mul24(a, b) >> 15) : fxmul64_s15(a, b); }
+
+__device__ __forceinline__ bool fits24(int x) { return x >= -(1 << 23) && x < (1 << 23); }
+
+#define SKX_WAVE_SYNC()                                     \
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+  __builtin_amdgcn_wave_barrier();                          \
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#define SKX_TILE (8 * 65 + 64)     /* int2 per wave: transposition tile [8][65] + segment sums [64] */
+
+// Launch-constant part of a voice, as the frame code wants it
+struct FxVoice {
+  uint32_t inc;            // 0 for a skipped voice: its phase stays frozen
+  int L;
+  uint32_t mask;
+  int pan_l, pan_r, k;     // k = 0 for a skipped voice: its smoother stays frozen
+  bool smooth, silent;     // silent: skipped or muted -> (0, 0) out
+};
+
+// Eight frames of a wave whose envelope levels are constant over the chunk (`target` = (amp * e) >> 15 per lane):
+// oscillator, smoother, output, per-voice (L, R) parked in the wave-private tile xp[8][65]; then the same
+// transposition sum as the float kernels (skred_render_fast2.hip), in integers -- any order is exact.
+template <bool STEMS, bool NARROW, bool INTERP, bool STALL>
+__device__ __forceinline__ void fx_block(const skx_args_t &a, const FxVoice &vc, const int16_t *lut, uint32_t &phase,
+                                         int &sg, int &sample, const int target, int2 *xp, int2 *xq, int2 *wsum_row,
+                                         const int lane, const int v, const int frame0) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    phase += vc.inc;
+    const uint32_t idx = phase >> (32 - vc.L);
+    int s = lut[idx];
+    if (INTERP) {
+      const int nxt = lut[(idx + 1) & vc.mask];
+      const int frac = (int)((uint32_t)(phase << vc.L) >> 17);
+      s = s + (__mul24(nxt - s, frac) >> 15);            // |nxt - s| < 2^17, frac < 2^15: always within 24 bits
+    }
+    int gain = target;
+    if (vc.smooth) {
+      if (!STALL) sg += fxmul<NARROW>(target - sg, vc.k) >> 15;
+      gain = sg;
+    }
+    const int smp = fxmul_s15<NARROW>(s, gain);
+    sample = smp;
+    int l = fxmul<NARROW>(smp, vc.pan_l) >> 15;
+    int r = fxmul<NARROW>(smp, vc.pan_r) >> 15;
+    l = vc.silent ? 0 : l;
+    r = vc.silent ? 0 : r;
+    if (STEMS) {
+      if (v < a.n_voices)
+        reinterpret_cast<int2 *>(a.stems)[(size_t)(frame0 + q) * (size_t)a.n_voices + (size_t)v] = make_int2(l, r);
+    }
+    xp[q * 65 + lane] = make_int2(l, r);
+  }
+  SKX_WAVE_SYNC()
+  {
+    const int2 *src = xp + (lane & 7) * 65 + (lane >> 3) * 8;
+    int2 t = src[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { const int2 u = src[i]; t.x += u.x; t.y += u.y; }
+    xq[lane] = t;                                        // == xq[seg * 8 + f]
+  }
+  SKX_WAVE_SYNC()
+  if (lane < 8) {
+    int2 t = xq[lane];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) { const int2 u = xq[g * 8 + lane]; t.x += u.x; t.y += u.y; }
+    wsum_row[lane] = t;                                  // |per-voice| < 2^17, 64 of them: fits int32
+  }
+  SKX_WAVE_SYNC()
+}
+
 template <bool STEMS>
 __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_t a) {
-  extern __shared__ int16_t lut_lds[];                               // [lds_entries] then int2 wsum[4][SKX_CHUNK]
+  extern __shared__ int16_t lut_lds[];                 // [lds_entries] | int2 wsum[4][SKX_CHUNK] | int2 tile[4][SKX_TILE]
   int2 *wsum = reinterpret_cast<int2 *>(reinterpret_cast<char *>(lut_lds) + a.lds_bytes_tables);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int2 *xp = wsum + 4 * SKX_CHUNK + wave * SKX_TILE;
+  int2 *xq = xp + 8 * 65;
   const bool lut_in_lds = a.lds_bytes_tables > 0;
   if (lut_in_lds) {
     const int n4 = a.lds_bytes_tables >> 4;
@@ -74,12 +155,46 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
     int sg = (int)st.y, sample = (int)st.z;
     uint32_t active = st.w & 1u;
     const bool dead = amp == 0 || (flags & SKXF_INERT);
-    const int16_t *lut = (lut_in_lds ? lut_lds : a.tables) + toff;
+    // (a skipped lane runs the block code on inert numbers: entries 0..1 of the pool, whatever its own table fields say)
+    const int16_t *lut = (lut_in_lds ? lut_lds : a.tables) + (dead ? 0 : toff);
     const uint32_t mask = (1u << L) - 1u;
+    const bool uses_env = (flags & SKXF_USE_ENV) != 0;
+
+    FxVoice vc;
+    vc.inc = dead ? 0u : inc; vc.L = dead ? 1 : L; vc.mask = dead ? 1u : mask;
+    vc.pan_l = pan_l; vc.pan_r = pan_r; vc.k = dead ? 0 : k;
+    vc.smooth = (flags & SKXF_SMOOTH) != 0;
+    vc.silent = dead || (flags & SKXF_MUTED);
+    // NARROW blocks (24-bit multiplies): pan gains within 24 bits, 0 <= k <= 32768 (the smoother state then stays between
+    // itself and its target), and |smoother state|, |target| <= 65535, so that s * gain fits 32 bits like the int16
+    // sample times a Q16 gain it is meant to be; anything else takes the blocks with the definition's full-width products
+    const bool narrow = __all(dead || (fits24(pan_l) && fits24(pan_r) && k >= 0 && k <= 32768 && sg >= -65535 && sg <= 65535));
 
     for (int c0 = 0; c0 < a.num_frames; c0 += SKX_CHUNK) {
       const int cn = min(SKX_CHUNK, a.num_frames - c0);
-      for (int j = 0; j < cn; ++j) {
+      // steady: the envelope level of every live lane is one constant over this chunk -- no envelope, an inactive one
+      // (it stays inactive), or a held note past its decay (t only grows; note-off arrives between launches)
+      const uint32_t t_first = sat32(a.count0 + (uint64_t)c0 + 1 - t_start);
+      const bool steady = __all(dead || !uses_env || !active || (t_release == 0 && (uint64_t)t_first >= AD));
+      int j = 0;
+      if (steady && cn >= 8) {
+        const int lvl = active ? S : 0;
+        const int e = uses_env ? (lvl * vel) >> 15 : 32768;
+        const int target = fxmul64_s15(amp, e);
+        const bool stalled = __all(dead || !vc.smooth || (((target - sg) * vc.k) >> 15) == 0);
+        const bool narrow_c = narrow && __all(dead || (target >= -65535 && target <= 65535));
+        int2 *row = wsum + wave * SKX_CHUNK;
+#define SKX_BLOCKS(NARROW_, INTERP_, STALL_)                                                                       \
+  for (; j + 8 <= cn; j += 8) fx_block<STEMS, NARROW_, INTERP_, STALL_>(a, vc, lut, phase, sg, sample, target, xp, xq, row + j, lane, v, c0 + j);
+        if (narrow_c) {
+          if (a.interp) { if (stalled) SKX_BLOCKS(true, true, true) else SKX_BLOCKS(true, true, false) }
+          else          { if (stalled) SKX_BLOCKS(true, false, true) else SKX_BLOCKS(true, false, false) }
+        } else {
+          if (a.interp) SKX_BLOCKS(false, true, false) else SKX_BLOCKS(false, false, false)
+        }
+#undef SKX_BLOCKS
+      }
+      for (; j < cn; ++j) {
         const uint64_t now = a.count0 + (uint64_t)(c0 + j) + 1;
         int l = 0, r = 0;
         if (!dead) {
@@ -115,12 +230,12 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
             }
             e = (lvl * vel) >> 15;
           }
-          int gain = (amp * e) >> 15;
+          int gain = fxmul64_s15(amp, e);
           if (flags & SKXF_SMOOTH) {
             sg += ((gain - sg) * k) >> 15;
             gain = sg;
           }
-          sample = (s * gain) >> 15;
+          sample = fxmul64_s15(s, gain);
           if (!(flags & SKXF_MUTED)) {
             l = (sample * pan_l) >> 15;
             r = (sample * pan_r) >> 15;
@@ -151,6 +266,25 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
   }
 }
 
+// partial[W][ncols] -> out[ncols] (int64, so any order of addition is exact).  Large W: stage 1 folds the rows into
+// SKX_RED_SLABS slabs (grid: column tiles x slabs, four row-strided slices per workgroup), stage 2 adds the slabs.
+#define SKX_RED_SLABS 32
+__global__ __launch_bounds__(256) void sk_fx_reduce_slabs_kernel(const long long *__restrict__ partial,
+                                                                 long long *__restrict__ tmp, int W, int ncols) {
+  __shared__ long long part[4][64];
+  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const int slabs = gridDim.y;
+  const int w0 = (int)((long long)W * blockIdx.y / slabs), w1 = (int)((long long)W * (blockIdx.y + 1) / slabs);
+  long long s = 0;
+  if (col < ncols)
+    for (int w = w0 + slice; w < w1; w += 4) s += partial[(size_t)w * ncols + col];
+  part[slice][c] = s;
+  __syncthreads();
+  if (slice == 0 && col < ncols)
+    tmp[(size_t)blockIdx.y * ncols + col] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+}
+
 __global__ __launch_bounds__(256) void sk_fx_reduce_kernel(const long long *__restrict__ partial,
                                                            long long *__restrict__ out, int W, int ncols) {
   const int col = blockIdx.x * 256 + threadIdx.x;
@@ -161,14 +295,24 @@ __global__ __launch_bounds__(256) void sk_fx_reduce_kernel(const long long *__re
 }
 
 extern "C" int skx_launch_render(const skx_args_t *args, int n_workgroups, hipStream_t stream) {
-  const size_t lds = (size_t)args->lds_bytes_tables + (size_t)4 * SKX_CHUNK * sizeof(int2);
+  const size_t lds = (size_t)args->lds_bytes_tables + (size_t)4 * SKX_CHUNK * sizeof(int2) + (size_t)4 * SKX_TILE * sizeof(int2);
   dim3 grid((unsigned)n_workgroups), block(SKX_GROUP);
   if (args->stems) hipLaunchKernelGGL((sk_fx_render_kernel<true>), grid, block, lds, stream, *args);
   else             hipLaunchKernelGGL((sk_fx_render_kernel<false>), grid, block, lds, stream, *args);
   return (int)hipGetLastError();
 }
 
-extern "C" int skx_launch_reduce(const long long *partial, long long *out, int W, int ncols, hipStream_t stream) {
-  hipLaunchKernelGGL(sk_fx_reduce_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, partial, out, W, ncols);
+extern "C" int skx_reduce_tmp_elems(int ncols) { return SKX_RED_SLABS * ncols; }
+
+// tmp: skx_reduce_tmp_elems(ncols) int64 of scratch (used when W > 4 * SKX_RED_SLABS)
+extern "C" int skx_launch_reduce(const long long *partial, long long *tmp, long long *out, int W, int ncols, hipStream_t stream) {
+  const long long *rows = partial;
+  int n_rows = W;
+  if (W > 4 * SKX_RED_SLABS) {
+    hipLaunchKernelGGL(sk_fx_reduce_slabs_kernel, dim3((unsigned)((ncols + 63) / 64), SKX_RED_SLABS), dim3(256), 0, stream, partial, tmp, W, ncols);
+    rows = tmp;
+    n_rows = SKX_RED_SLABS;
+  }
+  hipLaunchKernelGGL(sk_fx_reduce_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, rows, out, n_rows, ncols);
   return (int)hipGetLastError();
 }

@@ -15,7 +15,8 @@
 #include "skred_fx_layout.h"
 
 int skx_launch_render(const skx_args_t *args, int n_workgroups, hipStream_t stream);
-int skx_launch_reduce(const long long *partial, long long *out, int W, int ncols, hipStream_t stream);
+int skx_launch_reduce(const long long *partial, long long *tmp, long long *out, int W, int ncols, hipStream_t stream);
+int skx_reduce_tmp_elems(int ncols);
 int skred_amd_set_error(int code, const char *fmt, ...);   /* skred_bank.c */
 
 struct skred_fxbank {
@@ -25,6 +26,7 @@ struct skred_fxbank {
   int16_t *d_tables;
   size_t table_entries, table_bytes_padded;
   long long *d_partial; size_t partial_cap;
+  long long *d_redtmp; size_t redtmp_cap;   /* stage-1 output of the partial-row reduction */
   long long *d_mix; size_t mix_cap;
   int32_t *d_stems; size_t stems_cap;
   uint64_t count;
@@ -80,6 +82,7 @@ void skred_fxbank_destroy(skred_fxbank_t *fx) {
   if (fx->d_rw) hipFree(fx->d_rw);
   if (fx->d_tables) hipFree(fx->d_tables);
   if (fx->d_partial) hipFree(fx->d_partial);
+  if (fx->d_redtmp) hipFree(fx->d_redtmp);
   if (fx->d_mix) hipFree(fx->d_mix);
   if (fx->d_stems) hipFree(fx->d_stems);
   if (fx->ev0) hipEventDestroy(fx->ev0);
@@ -180,6 +183,7 @@ int skred_fxbank_render(skred_fxbank_t *fx, int num_frames, int interp, int64_t 
   const int n_wg = fx->n_groups < SKX_MAX_WORKGROUPS ? fx->n_groups : SKX_MAX_WORKGROUPS;
   int rc = grow_bytes((void **)&fx->d_partial, &fx->partial_cap, (size_t)n_wg * (size_t)num_frames * 2 * sizeof(long long));
   if (rc) return rc;
+  if ((rc = grow_bytes((void **)&fx->d_redtmp, &fx->redtmp_cap, (size_t)skx_reduce_tmp_elems(2 * num_frames) * sizeof(long long)))) return rc;
   skx_args_t a;
   memset(&a, 0, sizeof(a));
   for (int p = 0; p < SKX_COUNT; p++) a.ro[p] = fx->d_ro[p];
@@ -192,7 +196,7 @@ int skred_fxbank_render(skred_fxbank_t *fx, int num_frames, int interp, int64_t 
   if (e != hipSuccess) return skred_amd_set_error(SKRED_E_NO_DEVICE, "fx render launch -> %s", hipGetErrorString(e));
   HIP_TRY(hipEventRecord(fx->ev1, s));
   fx->timed = 1;
-  e = (hipError_t)skx_launch_reduce(fx->d_partial, (long long *)d_mix, n_wg, 2 * num_frames, s);
+  e = (hipError_t)skx_launch_reduce(fx->d_partial, fx->d_redtmp, (long long *)d_mix, n_wg, 2 * num_frames, s);
   if (e != hipSuccess) return skred_amd_set_error(SKRED_E_NO_DEVICE, "fx reduce launch -> %s", hipGetErrorString(e));
   fx->count += (uint64_t)num_frames;
   return SKRED_OK;

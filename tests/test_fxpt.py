@@ -76,6 +76,44 @@ def test_fx_gpu_bit_exact(n, interp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("interp", [0, 1])
+def test_fx_wide_parameters_bit_exact(interp):
+    """Parameters outside the Q15 habit: velocity 60000 (amp * e and s * gain then need the definition's 64-bit
+    products, the gain exceeds 16 bits), a smoother state of 2^20, a pan gain beyond 24 bits.  Such waves take the
+    block code with full-width multiplies instead of the 24-bit ones; held notes, so the steady blocks run."""
+    n = 1000
+    b, pool, c0 = fxbank.bank_fx(n)
+    x = slice(256, 320)
+    b["velocity_q15"][x] = 60000
+    b["amp_q15"][x] = 65535
+    b["pan_left_q15"][x] = 8192
+    b["pan_right_q15"][x] = 4096
+    b["smoother_gain_q15"][x] = 1 << 20
+    y = slice(512, 576)
+    b["amp_q15"][y] = 100
+    b["pan_left_q15"][y] = 9_000_000
+    b["smoother_k_q15"][700:764] = 40000          # k above 1.0: not the narrow case either
+    segs = [(6000, None), (512, None), (100, None), (7, None)]
+    rb, count = b.copy(), c0
+    ref = []
+    for frames, _ in segs:
+        m, st, count = cpuref.fx_render(rb, pool, count, frames, interp, want_stems=True)
+        ref.append((m, st))
+    db = fxbank.DeviceFxBank(n)
+    db.set_tables(pool)
+    db.upload(b)
+    db.set_sample_count(c0)
+    for k, (frames, _) in enumerate(segs):
+        m, st = db.render_host(frames, interp, want_stems=True)
+        assert (m == ref[k][0]).all(), f"integer mix differs in segment {k}"
+        assert (st == ref[k][1]).all(), f"stems differ in segment {k}"
+    host = b.copy()
+    db.download(host)
+    db.close()
+    assert not host.rw_mismatch(rb), host.rw_mismatch(rb)
+
+
+@pytest.mark.gpu
 def test_fx_mix_is_exactly_additive():
     """Integer path: mix(A u B) == mix(A) + mix(B) EXACTLY -> a multi-GPU sum of partial mixes is bit-exact."""
     n, frames = 8192, 256

@@ -294,8 +294,11 @@ def main():
         B = gather_bytes + (STATE_READ + STATE_WRITE) / frames       # algorithmic bytes / voice-sample
         launch_bytes = B * shard.n * frames
         achieved = launch_bytes / (k_mean * 1e-3)
+        traffic = pmc_traffic(a.workload, shard.n, frames)      # HBM bytes per launch from the PMC passes (profiles/)
         return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(a.workload, shard.n, frames),
+                "frac": achieved / HBM_PEAK, "traffic": traffic,
+                "traffic_rate": None if traffic is None else traffic / (k_mean * 1e-3) / 1e9,   # measured HBM GB/s of this kernel
+                "traffic_frac": None if traffic is None else traffic / (k_mean * 1e-3) / HBM_PEAK,
                 "kernel": KERNELS.get(db.last_kernel(), "?"), "frames_per_launch": frames,
                 "kernel_ms_mean": k_mean, "kernel_ms_min": k_min, "launches_timed": k_cnt,
                 "algorithmic_bytes_per_voice_sample": B, "algorithmic_bytes_per_launch": launch_bytes,

@@ -458,6 +458,12 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #ifndef SK_FAST_WIN_MIN_WAVES
 #define SK_FAST_WIN_MIN_WAVES 4  /* global-table banks: the window refill wants ~20 more registers (6: 12 B of scratch) */
 #endif
+#ifndef SK_FAST_EXT_MIN_WAVES
+#define SK_FAST_EXT_MIN_WAVES 3  /* the extended instantiation (LDS-table banks) carries ~30 more per-lane fields: at 4 waves (128
+                                    VGPRs) it spills inside the frame loops, and its LDS footprint allows 3 workgroups per CU in most
+                                    banks anyway: one-shot bank 0.46 -> 0.40 ms, FM 1.31 -> 1.22 ms.  PCM banks keep 4: there the
+                                    occupancy hides the window refills (0.347 -> 0.372 ms with 3) */
+#endif
 #ifndef SK_FAST_MIN_WAVES
 #define SK_FAST_MIN_WAVES 4      /* waves per SIMD the register allocator must leave room for (LDS-table banks: the table copy,
                                     wsum and the reduction tiles take 38..70 KB per workgroup, i.e. 2..4 workgroups per CU anyway) */
@@ -466,7 +472,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // (checked frame by frame) and / or carriers frequency-modulated by a higher-indexed voice of their 64-voice group.
 // Such banks run the plain frame loop (no frame pairs); table windows only in waves without carriers.
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS>
-__global__ __launch_bounds__(SK_GROUP, TAB_LDS ? SK_FAST_MIN_WAVES : SK_FAST_WIN_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
+__global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES : SK_FAST_MIN_WAVES) : SK_FAST_WIN_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
   const char *lds_tab = reinterpret_cast<const char *>(lds);

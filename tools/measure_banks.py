@@ -66,6 +66,12 @@ def kernels():
     run("c2 2^20 one-shots (1/3, finished after warm-up)", b, t, g)
     b, t, g = banks.bank_c2(1 << 20); run("c3 2^20 two per lane", b, t, g)
     b, t, g = banks.bank_c4(262144); run("c4 262144 linear", b, t, g, interp=1)
+    b, t, g = banks.bank_c4(262144)
+    b["voice_one_shot"][::3] = 1; b["voice_loop_enabled"][::3] = 0
+    run("c4 262144 linear, one-shots (1/3, finished)", b, t, g, interp=1)
+    b, t, g = banks.bank_c4(262144)
+    b["voice_sample_hold_max"][::16] = 4
+    run("c4 262144 linear, sample & hold on 1/16", b, t, g, interp=1)
 
 
 def crossover():

@@ -9,8 +9,10 @@
   noise      2^20-voice banks with w6 voices, specialised vs generic kernel
   live       notes starting / ending every block on a 2^20-voice bank (cost of control)
 
-Each line: ms per block over the timed blocks (wall clock, tail overlapped), voice-samples/s, and the render kernel's
-duration from the library's own event pair around the latest bracketed launch.
+Each line: ms per block over the timed blocks (wall clock), voice-samples/s, and the render kernel's duration from the
+library's own event pair around the latest bracketed launch (a bracketed launch runs alone).  kernels / fm / noise print
+every bank twice: with SKRED_OPT_OVERLAP_TAIL and in stream order -- the overlap pays on the four bench workloads and
+costs up to a third on some extended banks ("Per-block launch count").
 """
 import sys
 import time
@@ -22,7 +24,12 @@ sys.path.insert(0, ".")
 from skred_amd import banks, device  # noqa: E402
 
 
-def run(name, bank, tables, g, interp=0, F=512, steps=60, min2=None, generic=False, overlap=True, timing=4):
+def run(name, bank, tables, g, interp=0, F=512, steps=60, min2=None, generic=False, overlap=None, timing=4):
+    """overlap=None: both forms of the block (tail overlapped with the next render / in stream order), two lines."""
+    if overlap is None:
+        run(name + " [tail overlapped]", bank, tables, g, interp, F, steps, min2, generic, True, timing)
+        run(name + " [in order]", bank, tables, g, interp, F, steps, min2, generic, False, timing)
+        return
     n = bank.n
     out = torch.zeros(F, 2, device="cuda")
     db = device.DeviceBank(n)
@@ -46,7 +53,7 @@ def run(name, bank, tables, g, interp=0, F=512, steps=60, min2=None, generic=Fal
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     k = f"{db.last_render_ms():.4f}" if timing else "-"
-    print(f"{name:48s} kernel={db.last_kernel()} {dt * 1e3:.4f} ms/block {n * F / dt:.3e} voice-samples/s  "
+    print(f"{name:66s} kernel={db.last_kernel()} {dt * 1e3:.4f} ms/block {n * F / dt:.3e} voice-samples/s  "
           f"render kernel {k} ms  host issue {(t1 - t0) / steps * 1e6:.1f} us")
     db.close()
 
@@ -78,15 +85,15 @@ def crossover():
     for rec in ("c1", "c2"):
         for n in (32768, 65536, 131072, 196608, 262144):
             b, t, g = banks.RECIPES[rec](n)
-            run(f"{rec} {n} one per lane", b, t, g, min2=1 << 30)
-            run(f"{rec} {n} two per lane", b, t, g, min2=1)
+            run(f"{rec} {n} one per lane", b, t, g, min2=1 << 30, overlap=True)
+            run(f"{rec} {n} two per lane", b, t, g, min2=1, overlap=True)
 
 
 def overhead():
     for n in (4096, 65536):
         b, t, g = banks.bank_c1(n)
-        run(f"c1 {n} overlapped tail, timing every 4th", b, t, g, steps=200)
-        run(f"c1 {n} overlapped tail, no timing", b, t, g, steps=200, timing=0)
+        run(f"c1 {n} overlapped tail, timing every 4th", b, t, g, steps=200, overlap=True)
+        run(f"c1 {n} overlapped tail, no timing", b, t, g, steps=200, timing=0, overlap=True)
         run(f"c1 {n} in-order tail, no timing", b, t, g, steps=200, timing=0, overlap=False)
 
 
@@ -94,7 +101,7 @@ def frames():
     for rec in ("c1", "c2"):
         for F in (64, 256, 512, 2048):
             b, t, g = banks.RECIPES[rec](4096)
-            run(f"{rec} 4096 F={F}", b, t, g, F=F, steps=100, timing=1)
+            run(f"{rec} 4096 F={F}", b, t, g, F=F, steps=100, timing=1, overlap=True)
 
 
 def fm():

@@ -146,9 +146,11 @@ def main():
                     help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket the render kernels of every n-th launch with HIP events (kernel duration for the roofline)")
-    ap.add_argument("--no-tail-overlap", action="store_true",
-                    help="one GPU: keep every block's reduction + master stage on the render stream instead of overlapping "
-                         "them with the next block's render (SKRED_OPT_OVERLAP_TAIL)")
+    ap.add_argument("--tail-overlap", action="store_true",
+                    help="one GPU: run every block's reduction + master stage on the bank's internal stream so that the next "
+                         "block's render overlaps them (SKRED_OPT_OVERLAP_TAIL).  Off by default: measured at these very settings "
+                         "it is worth -4..+0.5 % on the four workloads (DESIGN.md, 'Per-block launch count')")
+    ap.add_argument("--no-tail-overlap", action="store_true", help="(the default; kept for the scripts under tools/)")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="with one process: still create a (1-rank) process group and run the N>1 code path through it "
                          "(exercises the RCCL calls on a single-GPU box)")
@@ -218,7 +220,7 @@ def main():
     # the render kernels of every 8th launch are bracketed by an event pair (roofline.kernel_ms_*): a pair costs ~6 us
     # of stream time, so bracketing every launch would tax the very throughput being measured
     db.kernel_timing(max(1, min(a.time_every, a.steps)))
-    if world == 1 and not a.rehearse_dist and not a.no_tail_overlap:
+    if world == 1 and not a.rehearse_dist and a.tail_overlap and not a.no_tail_overlap:
         db.overlap_tail(True)          # block k's reduction + master overlap block k+1's render (all inside the timed region)
 
     stream = torch.cuda.current_stream().cuda_stream

@@ -154,9 +154,12 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="with one process: still create a (1-rank) process group and run the N>1 code path through it "
                          "(exercises the RCCL calls on a single-GPU box)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N>1: wait for each launch's reduce before rendering the next block (default: double-buffered, "
-                         "reduce k overlaps render k+1)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N>1: double-buffered step, the reduce of block k (RCCL's stream) overlaps the render of block k+1 "
+                         "(ShardedRender.step_overlapped).  Default: the sequential step render -> reduce -> master; measured "
+                         "through a one-rank RCCL group the overlapped form costs 17 us more per block than it hides "
+                         "(0.293 vs 0.276 ms: the collective's kernel dispatched in turns with the render), DESIGN.md section 5")
+    ap.add_argument("--no-overlap", action="store_true", help="(the default; kept for older command lines)")
     ap.add_argument("--backend", default=os.environ.get("SKRED_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default).  gloo is only for rehearsing the N>1 code path on a box with fewer "
                          "GPUs than ranks (ranks then share devices and the partial mix is reduced through host memory)")
@@ -259,7 +262,7 @@ def main():
             red = host
         else:
             red = partial
-        if use_dist and not a.no_overlap:
+        if use_dist and a.overlap and not a.no_overlap:
             # double-buffered: the reduce of block k (RCCL, its own stream) overlaps the render of block k+1;
             # every block is still rendered, reduced and mastered inside the region it is counted in (drain)
             sh.begin([red, torch.zeros_like(red)])
@@ -338,7 +341,7 @@ def main():
             "config": {"workload": DESCR[a.workload] + (f" [voices overridden: {bank_voices} per bank]" if a.voices else "") + where,
                        "voices_total": total, "voices_per_gpu": shard.n,
                        "frames_per_launch": F, "sample_rate": 48000, "interp": "linear" if interp else "truncate",
-                       "parallelism": f"voices block-partitioned over {world} GPU(s)" + ("; one RCCL reduce(sum) of float[F][2] per launch" + ("" if a.no_overlap else ", overlapped with the next launch's render") if world > 1 else ""),
+                       "parallelism": f"voices block-partitioned over {world} GPU(s)" + ("; one RCCL reduce(sum) of float[F][2] per launch" + (", overlapped with the next launch's render" if a.overlap and not a.no_overlap else "") if world > 1 else ""),
                        "seed": "0x5EED", "recipe_warmup_frames": recipe_warmup_frames},
             "realtime_factor_48k": value / (total * 48000.0),
             "output_finite": finite,

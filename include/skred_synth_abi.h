@@ -14,10 +14,11 @@
  *   synth.def:12-89   per-voice arrays       [VOICE_MAX = 64, skred.h:9]
  *   synth-types.h     mmf_t / envelope_t (here skred_mmf_t / skred_envelope_t, same layout)
  *
- * NOT exported (on purpose): osc_next, cz_phasor, quantize_bits_int, mmf_process,
- * amp_envelope_step, audio_rng_init/next/float.  They are the per-sample internals of the loop
- * that now lives in the HIP kernels; no other translation unit of the reference references them,
- * and keeping host copies would be a CPU render path in disguise.
+ * The per-sample functions synth.h also declares (osc_next, cz_phasor, quantize_bits_int,
+ * mmf_process, amp_envelope_step, audio_rng_init/next/float; synth.h:24-26,29,30,33,38,43) are
+ * exported too (skred_amd/csrc/skred_synth_persample.c): one voice, one sample, on the host arrays.
+ * synth() never calls them -- the render loop is the HIP kernels' -- and no other translation unit
+ * of the reference does; they complete the header's surface.
  *
  * Imported from the host program, as in the reference (all optional here, weak):
  *   int debug (skred.c:53), float *mw_free(float*) (miniwav.c:94),
@@ -183,6 +184,17 @@ void  voice_show(int v, char c, int verbose);
 int   voice_show_all(int voice, int verbose);
 char *synth_stats(void);
 void  synth_voice_bench(int voice);
+
+/* ---- per-sample entry points, same signatures as synth.h:24-26,29,30,33,38,43; host side, one
+ *      voice of the global arrays, one sample (skred_synth_persample.c).  Not used by synth(). ---- */
+void     audio_rng_init(uint64_t *rng, uint64_t seed);     /* synth.c:105-107  */
+uint64_t audio_rng_next(uint64_t *rng);                    /* synth.c:110-114  */
+float    audio_rng_float(uint64_t *rng);                   /* synth.c:117-123  */
+float    cz_phasor(int n, float p, float d, int table_size);   /* synth.c:149-215 */
+float    osc_next(int voice, float phase_inc);             /* synth.c:217-275  */
+float    quantize_bits_int(float v, int bits);             /* synth.c:341-345  */
+float    mmf_process(int n, float input);                  /* synth.c:349-364  */
+float    amp_envelope_step(int v);                         /* synth.c:398-431  */
 
 /* ---- `.sk` patch subset -> voice state (skred_patch.c; SURVEY 8f "next" #1) ---- */
 typedef struct { int voice; int unsupported; int errors; } skred_patch_t;

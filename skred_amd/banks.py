@@ -21,8 +21,8 @@ from .bank import GlobalsC, VoiceBank
 LCG_A = np.uint64(6364136223846793005)
 LCG_C = np.uint64(1442695040888963407)
 SEED = 0x5EED
-_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LUT_FILE = os.path.join(_ROOT, "tests", "golden", "notamy_luts.npz")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LUT_FILE = os.path.join(_HERE, "data", "notamy_luts.npz")      # package data (skred_amd/data/extract_notamy_luts.py)
 PCM_LENGTH = 1176036        # amysamples.h:7
 PCM_RATE = 22050.0          # amysamples.h:6
 

@@ -14,6 +14,7 @@
  *      callback outputs silence and records the error (an audio callback must not abort).
  */
 #define _GNU_SOURCE
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,6 +31,7 @@
 #define ERR_FREQ 101                 /* synth.c:860 */
 
 enum { SLOT_SINE = 0, SLOT_SQR, SLOT_SAW_DOWN, SLOT_SAW_UP, SLOT_TRI, SLOT_NOISE, SLOT_NOISE_ALT,
+       SLOT_KORG_FIRST = 32, SLOT_KORG_LAST = 62,          /* WAVE_TABLE_KRG1 .. KRG32-1, synth.c:1253 */
        SLOT_AMY_FIRST = 100, SLOT_AMY_LAST = 199 };        /* skred.h:24-76 */
 
 /* ------------------------------------------------------------------ imported (weak) symbols */
@@ -80,95 +82,110 @@ float volume_threshold = 0.05f;
 float volume_smoother_higher_smoothing = 0.3f;
 
 static inline int bad_voice(int v) { return v < 0 || v >= NV; }
-static inline int toggled(int state, int current) { return state < 0 ? !current : state; }
+static inline int flip_or_set(int state, int current) { return state < 0 ? !current : state; }
 
 /* ================================================================== control path */
 
-int volume_set(float v) {                         /* synth.c:96-100 */
+/* ---- master volume (synth.c:96-100) ---- */
+int volume_set(float v) {
   volume_user = v;
   volume_final = v * SKRED_AMY_FACTOR;
   return 0;
 }
 
-/* table samples advanced per output frame, synth.c:125-132 */
+/* ---- oscillator set-up ---- */
+
+/* table samples advanced per output frame (synth.c:125-132); the association of the products and
+ * quotients is the reference's, kept because phase_inc feeds the render bit for bit */
 float osc_get_phase_inc(int v, float f) {
-  float g = f;
-  if (voice_one_shot[v]) g /= voice_offset_hz[v];
+  const float pitch = voice_one_shot[v] ? f / voice_offset_hz[v] : f;
   const float tr = voice_table_rate[v];
-  return (g * (float)voice_table_size[v]) / tr * (tr / RATE);
+  return (pitch * (float)voice_table_size[v]) / tr * (tr / RATE);
 }
 
 void osc_set_freq(int v, float f) { voice_phase_inc[v] = osc_get_phase_inc(v, f); }
 
-/* point a voice at a wave slot and inherit the slot's playback attributes, synth.c:277-314 */
-void osc_set_wave_table_index(int voice, int wave) {
-  if (!(wave_table_data[wave] && wave_size[wave] && wave_rate[wave] > 0.0)) return;
-  const int geometry_changed = voice_table_rate[voice] != wave_rate[wave] ||
-                               voice_table_size[voice] != wave_size[wave];
+/* what a voice inherits from the wave slot it is pointed at (synth.c:277-314) */
+static void adopt_slot(int voice, int wave) {
   voice_wave_table_index[voice] = wave;
-  voice_finished[voice] = wave_one_shot[wave] ? 1 : 0;   /* one-shots wait for a trigger */
-  voice_table_rate[voice] = wave_rate[wave];
-  voice_table_size[voice] = wave_size[wave];
-  voice_table[voice] = wave_table_data[wave];
-  voice_one_shot[voice] = wave_one_shot[wave];
-  voice_loop_start[voice] = wave_loop_start[wave];
+  voice_table[voice]        = wave_table_data[wave];
+  voice_table_size[voice]   = wave_size[wave];
+  voice_table_rate[voice]   = wave_rate[wave];
+  voice_one_shot[voice]     = wave_one_shot[wave];
+  voice_finished[voice]     = wave_one_shot[wave] ? 1 : 0;     /* a one-shot waits for its trigger */
   voice_loop_enabled[voice] = wave_loop_enabled[wave];
-  voice_loop_end[voice] = wave_loop_end[wave];
-  voice_midi_note[voice] = wave_midi_note[wave];
-  voice_offset_hz[voice] = wave_offset_hz[wave];
-  const int s = voice_loop_start[voice], e = voice_loop_end[voice];
-  voice_loop_start_f[voice] = (float)s;
-  voice_loop_end_f[voice] = (float)e;
-  voice_loop_valid[voice] = e > s;
-  voice_loop_length[voice] = (int)(float)(e > s ? e - s : voice_table_size[voice]);
-  if (geometry_changed) osc_set_freq(voice, voice_freq[voice]);
+  voice_loop_start[voice]   = wave_loop_start[wave];
+  voice_loop_end[voice]     = wave_loop_end[wave];
+  voice_midi_note[voice]    = wave_midi_note[wave];
+  voice_offset_hz[voice]    = wave_offset_hz[wave];
 }
 
-/* (re)start playback at the boundary that matches direction and looping, synth.c:316-339 */
+/* the loop window in the form the render loop reads (floats + a validity bit) */
+static void derive_loop_window(int voice) {
+  const int lo = voice_loop_start[voice], hi = voice_loop_end[voice];
+  const int ok = hi > lo;
+  voice_loop_start_f[voice] = (float)lo;
+  voice_loop_end_f[voice] = (float)hi;
+  voice_loop_valid[voice] = ok;
+  voice_loop_length[voice] = (int)(float)(ok ? hi - lo : voice_table_size[voice]);
+}
+
+void osc_set_wave_table_index(int voice, int wave) {
+  const int usable = wave_table_data[wave] && wave_size[wave] && wave_rate[wave] > 0.0;
+  if (!usable) return;                                        /* empty slot: the voice keeps its table */
+  const int retune = voice_table_rate[voice] != wave_rate[wave] || voice_table_size[voice] != wave_size[wave];
+  adopt_slot(voice, wave);
+  derive_loop_window(voice);
+  if (retune) osc_set_freq(voice, voice_freq[voice]);         /* same pitch on the new geometry */
+}
+
+/* (re)start playback at the end that matches direction and looping (synth.c:316-339) */
 void osc_trigger(int voice) {
+  const int reversed = voice_direction[voice];
+  const int whole_table = voice_one_shot[voice] || !voice_loop_enabled[voice];
+  float at;
+  if (whole_table) at = reversed ? (float)(voice_table_size[voice] - 1) : 0.0f;
+  else             at = reversed ? (float)voice_loop_end[voice] - 1e-6f : (float)voice_loop_start[voice];
+  voice_phase[voice] = at;
   voice_finished[voice] = 0;
-  const int backwards = voice_direction[voice];
-  const float last = (float)(voice_table_size[voice] - 1);
-  if (voice_one_shot[voice] || !voice_loop_enabled[voice]) {
-    voice_phase[voice] = backwards ? last : 0.0f;
-  } else {
-    voice_phase[voice] = backwards ? (float)voice_loop_end[voice] - 1e-6f
-                                   : (float)voice_loop_start[voice];
+}
+
+/* ---- biquad coefficients: RBJ cookbook, cached on (freq, resonance, mode) (synth.c:929-1008) ---- */
+
+typedef struct { float b0, b1, b2; } rbj_numerator_t;
+
+static rbj_numerator_t rbj_numerator(int mode, float cs, float alpha) {
+  switch (mode) {
+    case 2:  return (rbj_numerator_t){ (1.0f + cs) / 2.0f, -(1.0f + cs), (1.0f + cs) / 2.0f };   /* high-pass */
+    case 3:  return (rbj_numerator_t){ alpha, 0.0f, -alpha };                                    /* band-pass */
+    case 4:  return (rbj_numerator_t){ 1.0f, -2.0f * cs, 1.0f };                                 /* notch */
+    case 5:  return (rbj_numerator_t){ 1.0f - alpha, -2.0f * cs, 1.0f + alpha };                 /* all-pass */
+    default: return (rbj_numerator_t){ (1.0f - cs) / 2.0f, 1.0f - cs, (1.0f - cs) / 2.0f };      /* low-pass; also any unknown mode */
   }
 }
 
-/* RBJ cookbook biquad, recomputed only when (freq, resonance, mode) changed; synth.c:929-1008 */
 void mmf_set_params(int n, float f, float resonance) {
   skred_mmf_t *q = &voice_filter[n];
   const int mode = voice_filter_mode[n];
-  if (f == q->last_freq && resonance == q->last_resonance && mode == q->last_mode) return;
-  q->last_freq = f;
-  q->last_resonance = resonance;
-  q->last_mode = mode;
-  if (mode == 0) return;
-
+  if (q->last_freq == f && q->last_resonance == resonance && q->last_mode == mode) return;
+  q->last_freq = f; q->last_resonance = resonance; q->last_mode = mode;
+  if (mode == 0) return;                                      /* bypassed: keys remembered, nothing computed */
   const float w = 2.0f * (float)M_PI * f / (float)RATE;
   const float sn = sinf(w), cs = cosf(w);
   const float alpha = sn / (2.0f * resonance);
-  const float a0 = 1.0f + alpha, a1 = -2.0f * cs, a2 = 1.0f - alpha;
-  float b0, b1, b2;
-  switch (mode) {
-    case 2:  b0 = (1.0f + cs) / 2.0f; b1 = -(1.0f + cs); b2 = (1.0f + cs) / 2.0f; break; /* high-pass */
-    case 3:  b0 = alpha;              b1 = 0.0f;         b2 = -alpha;             break; /* band-pass */
-    case 4:  b0 = 1.0f;               b1 = -2.0f * cs;   b2 = 1.0f;               break; /* notch     */
-    case 5:  b0 = 1.0f - alpha;       b1 = -2.0f * cs;   b2 = 1.0f + alpha;       break; /* all-pass  */
-    default: b0 = (1.0f - cs) / 2.0f; b1 = 1.0f - cs;    b2 = (1.0f - cs) / 2.0f; break; /* low-pass (1, and any unknown mode) */
-  }
-  q->b0 = b0 / a0; q->b1 = b1 / a0; q->b2 = b2 / a0;
-  q->a1 = a1 / a0; q->a2 = a2 / a0;
+  const float a0 = 1.0f + alpha;
+  const rbj_numerator_t num = rbj_numerator(mode, cs, alpha);
+  q->b0 = num.b0 / a0; q->b1 = num.b1 / a0; q->b2 = num.b2 / a0;
+  q->a1 = (-2.0f * cs) / a0;
+  q->a2 = (1.0f - alpha) / a0;
   voice_filter_freq[n] = f;
   voice_filter_res[n] = resonance;
 }
 
-void mmf_init(int n, float f, float resonance) {            /* synth.c:1015-1030 */
+void mmf_init(int n, float f, float resonance) {              /* synth.c:1015-1030 */
   skred_mmf_t *q = &voice_filter[n];
   q->x1 = q->x2 = q->y1 = q->y2 = 0.0f;
-  q->last_freq = q->last_resonance = -1.0f;
+  q->last_freq = q->last_resonance = -1.0f;                   /* impossible keys: the next set recomputes */
   q->last_mode = -1;
   voice_filter_freq[n] = f;
   voice_filter_res[n] = resonance;
@@ -178,18 +195,18 @@ void mmf_init(int n, float f, float resonance) {            /* synth.c:1015-1030
 int mmf_set_freq(int n, float f) { mmf_set_params(n, f, voice_filter_res[n]); return 0; }
 int mmf_set_res(int n, float res) { if (res > 0) mmf_set_params(n, voice_filter_freq[n], res); return 0; }
 
-void envelope_init(int v, float a, float d, float s, float r) {   /* synth.c:367-380 */
+/* ---- envelope (synth.c:367-395,632-638,1146-1159) ---- */
+
+void envelope_init(int v, float a, float d, float s, float r) {
   skred_envelope_t *e = &voice_amp_envelope[v];
-  e->a = a; e->d = d; e->s = s; e->r = r;
-  e->attack_time = a * RATE;
-  e->decay_time = d * RATE;
+  e->a = a; e->d = d; e->s = s; e->r = r;                     /* seconds, as typed */
+  e->attack_time = a * RATE; e->decay_time = d * RATE; e->release_time = r * RATE;   /* frames */
   e->sustain_level = fmaxf(0, fminf(1.0f, s));
-  e->release_time = r * RATE;
   e->sample_start = e->sample_release = 0;
   e->is_active = 0;
 }
 
-void amp_envelope_trigger(int v, float velocity) {          /* synth.c:383-388 */
+void amp_envelope_trigger(int v, float velocity) {
   skred_envelope_t *e = &voice_amp_envelope[v];
   e->sample_start = synth_sample_count;
   e->sample_release = 0;
@@ -197,18 +214,20 @@ void amp_envelope_trigger(int v, float velocity) {          /* synth.c:383-388 *
   e->is_active = 1;
 }
 
-void amp_envelope_release(int v) {                          /* synth.c:391-395 */
-  if (voice_amp_envelope[v].is_active) voice_amp_envelope[v].sample_release = synth_sample_count;
+void amp_envelope_release(int v) {
+  skred_envelope_t *e = &voice_amp_envelope[v];
+  if (e->is_active) e->sample_release = synth_sample_count;
 }
 
-int envelope_is_flat(int v) {                               /* synth.c:632-638 */
+int envelope_is_flat(int v) {
   const skred_envelope_t *e = &voice_amp_envelope[v];
   return e->a == 0.0f && e->d == 0.0f && e->s == 1.0f && e->r == 0.0f;
 }
 
 int envelope_set(int voice, float a, float d, float s, float r) { envelope_init(voice, a, d, s, r); return 0; }
 
-int envelope_velocity(int voice, float f) {                 /* synth.c:1146-1159 */
+/* `l<velocity>`: 0 is note-off, anything else (re)starts the note */
+int envelope_velocity(int voice, float f) {
   if (bad_voice(voice)) return ERR_ARG;
   if (f == 0) { amp_envelope_release(voice); return 0; }
   voice_use_amp_envelope[voice] = 1;
@@ -217,17 +236,24 @@ int envelope_velocity(int voice, float f) {                 /* synth.c:1146-1159
   return 0;
 }
 
+/* ---- one-line setters (synth.c:829-911) ---- */
+
 int cz_set(int v, int n, float f) { voice_cz_mode[v] = n; voice_cz_distortion[v] = f; return 0; }
 int cmod_set(int voice, int o, float f) { voice_cz_mod_osc[voice] = o; voice_cz_mod_depth[voice] = f; return 0; }
+int wave_quant(int voice, int n) { voice_quantize[voice] = n; return 0; }
+int wave_mute(int voice, int state) { voice_disconnect[voice] = flip_or_set(state, voice_disconnect[voice]); return 0; }
+int wave_dir(int voice, int state) { voice_direction[voice] = flip_or_set(state, voice_direction[voice]); return 0; }
+int wave_loop(int voice, int state) { voice_loop_enabled[voice] = flip_or_set(state, voice_loop_enabled[voice]); return 0; }
+int voice_trigger(int voice) { osc_trigger(voice); return 0; }
 
-int amp_set(int voice, float f) {                           /* synth.c:829-836 */
+int amp_set(int voice, float f) {
   if (!(f >= 0)) return ERR_ARG;
-  voice_use_amp_envelope[voice] = 0;
+  voice_use_amp_envelope[voice] = 0;                          /* a plain level switches the envelope off */
   voice_amp[voice] = voice_user_amp[voice] = f;
   return 0;
 }
 
-int pan_set(int voice, float f) {                           /* synth.c:838-847 */
+int pan_set(int voice, float f) {                             /* linear pan law */
   if (!(f >= -1.0f && f <= 1.0f)) return ERR_ARG;
   voice_pan[voice] = f;
   voice_pan_left[voice] = (1.0f - f) / 2.0f;
@@ -235,69 +261,68 @@ int pan_set(int voice, float f) {                           /* synth.c:838-847 *
   return 0;
 }
 
-int wave_quant(int voice, int n) { voice_quantize[voice] = n; return 0; }
-
-int freq_set(int voice, float f) {                          /* synth.c:854-861 */
+int freq_set(int voice, float f) {
   if (!(f >= 0 && f < (double)RATE)) return ERR_FREQ;
   voice_freq[voice] = f;
   osc_set_freq(voice, f);
   return 0;
 }
 
-int wave_mute(int voice, int state) { voice_disconnect[voice] = toggled(state, voice_disconnect[voice]); return 0; }
-int wave_dir(int voice, int state) { voice_direction[voice] = toggled(state, voice_direction[voice]); return 0; }
-int wave_loop(int voice, int state) { voice_loop_enabled[voice] = toggled(state, voice_loop_enabled[voice]); return 0; }
-
-int wave_set(int voice, int wave) {                         /* synth.c:889-896 */
+int wave_set(int voice, int wave) {
   if (wave < 0 || wave >= NW) return ERR_ARG;
   osc_set_wave_table_index(voice, wave);
   return 0;
 }
 
-int pan_mod_set(int voice, int o, float f) {                /* synth.c:882-887 */
-  if (bad_voice(voice) || bad_voice(o)) return ERR_ARG;
-  voice_pan_mod_osc[voice] = o; voice_pan_mod_depth[voice] = f;
+/* the three modulator routings share one argument check */
+static int route(int voice, int source, int *osc, float *depth, float amount) {
+  if (bad_voice(voice) || bad_voice(source)) return ERR_ARG;
+  osc[voice] = source;
+  depth[voice] = amount;
   return 0;
 }
 
-int amp_mod_set(int voice, int o, float f) {                /* synth.c:898-903 */
-  if (bad_voice(voice) || bad_voice(o)) return ERR_ARG;
-  voice_amp_mod_osc[voice] = o; voice_amp_mod_depth[voice] = f;
-  return 0;
+int pan_mod_set(int voice, int o, float f) { return route(voice, o, voice_pan_mod_osc, voice_pan_mod_depth, f); }
+int amp_mod_set(int voice, int o, float f) { return route(voice, o, voice_amp_mod_osc, voice_amp_mod_depth, f); }
+
+int freq_mod_set(int voice, int o, float f) {
+  const int rc = route(voice, o, voice_freq_mod_osc, voice_freq_mod_depth, f);
+  if (!rc) voice_freq_scale[voice] = (float)voice_table_size[voice] / (float)voice_table_size[o];
+  return rc;
 }
 
-int freq_mod_set(int voice, int o, float f) {               /* synth.c:905-911 */
-  if (bad_voice(voice) || bad_voice(o)) return ERR_ARG;
-  voice_freq_mod_osc[voice] = o; voice_freq_mod_depth[voice] = f;
-  voice_freq_scale[voice] = (float)voice_table_size[voice] / (float)voice_table_size[o];
-  return 0;
-}
+/* ---- notes (synth.c:1056-1088) ---- */
 
-float midi2hz(float f) { return 440.0f * powf(2.0f, (f - 69.0f) / 12.0f); }   /* synth.c:1056-1059 */
+float midi2hz(float f) { return 440.0f * powf(2.0f, (f - 69.0f) / 12.0f); }
 
-int voice_set(int n, int *old_voice) {                      /* synth.c:1061-1065 */
+int voice_set(int n, int *old_voice) {
   if (bad_voice(n)) return ERR_ARG;
   if (old_voice) *old_voice = n;
   return 0;
 }
 
-int voice_trigger(int voice) { osc_trigger(voice); return 0; }
-
-int wave_default(int voice) {                               /* synth.c:1072-1079 */
-  const float hz = midi2hz((float)voice_midi_note[voice]);
+int wave_default(int voice) {                                 /* play the slot at its own root note */
+  const float note = (float)voice_midi_note[voice];
+  const float hz = midi2hz(note);
   voice_freq[voice] = hz;
-  voice_note[voice] = (float)voice_midi_note[voice];
+  voice_note[voice] = note;
   osc_set_freq(voice, hz);
   return 0;
 }
 
-int freq_midi(int voice, float f) {                         /* synth.c:1081-1088 */
+int freq_midi(int voice, float f) {
   if (!(f >= 0.0 && f <= 127.0)) return ERR_ARG;
   if (voice_midi_transpose[voice]) f += voice_midi_transpose[voice];
   return freq_set(voice, midi2hz(f));
 }
 
-int voice_copy(int v, int n) {                              /* synth.c:1033-1054, same order of effects */
+/* ---- whole-voice operations ---- */
+
+/* `>n`: voice v's patch onto voice n through the setters, in the reference's order of effects
+ * (synth.c:1033-1054): each setter's side effects (retune on a new table, envelope switch-off on a
+ * plain level, filter memory cleared) must land in that order for the states to agree */
+int voice_copy(int v, int n) {
+  const skred_envelope_t *e = &voice_amp_envelope[v];
   wave_set(n, voice_wave_table_index[v]);
   amp_set(n, voice_user_amp[v]);
   freq_set(n, voice_freq[v]);
@@ -311,7 +336,6 @@ int voice_copy(int v, int n) {                              /* synth.c:1033-1054
   voice_sample_hold_max[n] = voice_sample_hold_max[v];
   voice_sample_hold_count[n] = voice_sample_hold_count[v];
   voice_sample_hold[n] = voice_sample_hold[v];
-  const skred_envelope_t *e = &voice_amp_envelope[v];
   envelope_set(n, e->a, e->d, e->s, e->r);
   cz_set(n, voice_cz_mode[v], voice_cz_distortion[v]);
   cmod_set(n, voice_cz_mod_osc[v], voice_cz_mod_depth[v]);
@@ -320,40 +344,40 @@ int voice_copy(int v, int n) {                              /* synth.c:1033-1054
   return 0;
 }
 
-/* power-on state of one voice, synth.c:1090-1132 */
+/* Power-on values of the plain per-voice fields (synth.c:1090-1132) as a list; voice_reset() stores
+ * them and then runs the three initialisers whose results depend on them. */
+typedef struct { void *array; char type; float value; } field_default_t;     /* type: 'i' int, 'f' float */
+static const field_default_t POWER_ON[] = {
+  { voice_wave_table_index, 'i', 0 },   { voice_table_rate, 'f', 0 },        { voice_table_size, 'i', 0 },
+  { voice_sample, 'f', 0 },             { voice_amp, 'f', 0 },               { voice_user_amp, 'f', 0 },
+  { voice_pan, 'f', 0 },                { voice_pan_left, 'f', 0.5f },       { voice_pan_right, 'f', 0.5f },
+  { voice_use_amp_envelope, 'i', 0 },
+  { voice_amp_mod_osc, 'i', -1 },       { voice_freq_mod_osc, 'i', -1 },     { voice_pan_mod_osc, 'i', -1 },
+  { voice_freq_mod_depth, 'f', 0 },     { voice_freq_scale, 'f', 1.0f },
+  { voice_disconnect, 'i', 0 },         { voice_quantize, 'i', 0 },          { voice_direction, 'i', 0 },
+  { voice_freq, 'f', 440.0f },          { voice_midi_note, 'f', 69.0f },     { voice_midi_transpose, 'f', 0 },
+  { voice_link_midi_a, 'f', -1 },       { voice_link_midi_b, 'f', -1 },
+  { voice_link_velo_a, 'f', -1 },       { voice_link_velo_b, 'f', -1 },      { voice_link_trig, 'f', -1 },
+  { voice_filter_mode, 'i', 0 },
+  { voice_smoother_enable, 'i', 1 },    { voice_smoother_gain, 'f', 0 },     { voice_smoother_smoothing, 'f', SMOOTH_K },
+  { voice_glissando_enable, 'i', 0 },   { voice_glissando_speed, 'f', 0 },   { voice_glissando_target, 'f', 440.0f },
+  { voice_record, 'i', 0 },
+};
+
 void voice_reset(int i) {
-  voice_wave_table_index[i] = 0;
-  voice_table_rate[i] = 0; voice_table_size[i] = 0;
-  voice_sample[i] = 0;
-  voice_amp[i] = voice_user_amp[i] = 0;
-  voice_pan[i] = 0; voice_pan_left[i] = voice_pan_right[i] = 0.5f;
-  voice_use_amp_envelope[i] = 0;
-  voice_amp_mod_osc[i] = voice_freq_mod_osc[i] = voice_pan_mod_osc[i] = -1;
-  voice_freq_mod_depth[i] = 0.0f;
-  voice_freq_scale[i] = 1.0f;
-  voice_disconnect[i] = voice_quantize[i] = voice_direction[i] = 0;
-  envelope_init(i, 0.0f, 0.0f, 1.0f, 0.0f);
-  voice_freq[i] = 440.0f;
-  voice_midi_note[i] = 69.0f;
-  voice_midi_transpose[i] = 0;
-  voice_link_midi_a[i] = voice_link_midi_b[i] = -1;
-  voice_link_velo_a[i] = voice_link_velo_b[i] = -1;
-  voice_link_trig[i] = -1;
-  osc_set_wave_table_index(i, SLOT_SINE);
-  voice_filter_mode[i] = 0;
+  for (size_t k = 0; k < sizeof(POWER_ON) / sizeof(POWER_ON[0]); k++) {
+    const field_default_t *d = &POWER_ON[k];
+    if (d->type == 'i') ((int *)d->array)[i] = (int)d->value; else ((float *)d->array)[i] = d->value;
+  }
+  envelope_init(i, 0.0f, 0.0f, 1.0f, 0.0f);                   /* flat: level 1, no ramps */
+  osc_set_wave_table_index(i, SLOT_SINE);                     /* geometry was zeroed above, so this retunes to 440 Hz */
   mmf_init(i, 8000.0f, 0.707f);
-  voice_smoother_enable[i] = 1;
-  voice_smoother_gain[i] = 0.0f;
-  voice_smoother_smoothing[i] = SMOOTH_K;
-  voice_glissando_enable[i] = 0;
-  voice_glissando_speed[i] = 0.0f;
-  voice_glissando_target[i] = voice_freq[i];
-  voice_record[i] = 0;
 }
 
 void voice_init(void) { for (int i = 0; i < NV; i++) voice_reset(i); }
 
-int wave_reset(int voice, int n) {                          /* synth.c:1140-1144 */
+/* `S<n>`: one voice, or every voice when n names none (synth.c:1140-1144) */
+int wave_reset(int voice, int n) {
   (void)voice;
   if (bad_voice(n)) voice_init(); else voice_reset(n);
   return 0;
@@ -364,10 +388,7 @@ int wave_reset(int voice, int n) {                          /* synth.c:1140-1144
 void synth_init(void) { printf("# synth_init :: GPU render path (libskred_amd), static arrays\n"); }
 void synth_free(void) { skred_synth_shutdown(); printf("# synth_free\n"); }
 
-static uint64_t lcg_step(uint64_t *s) { *s = *s * 6364136223846793005ULL + 1442695040888963407ULL; return *s; }
-static float lcg_unit(uint64_t *s) { return (float)(int32_t)(uint32_t)(lcg_step(s) >> 32) / 2147483648.0f; }
-
-static void scale_to_unit_peak(float *d, int n) {           /* synth.c:1175-1197 */
+static void scale_to_unit_peak(float *d, int n) {             /* synth.c:1175-1197 */
   float peak = 0.0f;
   for (int i = 0; i < n; i++) if (fabsf(d[i]) > peak) peak = fabsf(d[i]);
   if (peak == 0.0) return;
@@ -375,53 +396,105 @@ static void scale_to_unit_peak(float *d, int n) {           /* synth.c:1175-1197
   for (int i = 0; i < n; i++) d[i] *= k;
 }
 
-/* Built-in single-cycle tables (slots 0-6: 4096 entries generated from one running phase,
- * synth.c:1208-1249) and the AMY PCM regions when the host program provides pcm/pcm_map
- * (slots 100.., synth.c:1270-1292).  The Korg DW-8000 waves of slots 32-62 (retro/korg.h data,
- * synth.c:1253-1268) are not bundled with this build: those slots stay empty and wave_set() on them
- * is ignored, as for any empty slot. */
-void wave_table_init(void) {
-  for (int i = 0; i < NW; i++) { wave_table_data[i] = NULL; wave_size[i] = 0; wave_is_miniwav[i] = 0; }
-  uint64_t rng = 1;
-  const int n = 4096;
+static void fill_slot(int slot, float *data, int n, float rate, int one_shot, int loop_lo, int loop_hi) {
+  wave_table_data[slot] = data; wave_size[slot] = n; wave_rate[slot] = rate;
+  wave_one_shot[slot] = one_shot; wave_loop_start[slot] = loop_lo; wave_loop_end[slot] = loop_hi;
+}
+
+/* slots 0-6: 4096-entry single cycles generated from one running float phase (synth.c:1208-1249);
+ * the two noise slots draw from one LCG stream seeded 1 */
+static void make_builtin_cycles(void) {
+  enum { N = 4096 };
+  uint64_t rng;
+  audio_rng_init(&rng, 1);
+  const float step = 1.0f / (float)N;
   for (int w = SLOT_SINE; w <= SLOT_NOISE_ALT; w++) {
-    float *t = (float *)malloc(sizeof(float) * (size_t)n);
-    wave_table_data[w] = t; wave_size[w] = n; wave_rate[w] = RATE;
-    wave_one_shot[w] = 0; wave_loop_start[w] = 0; wave_loop_end[w] = n - 1;
-    const float step = 1.0f / (float)n;
-    float ph = 0.0f;
-    for (int k = 0; ph < 1.0f; k++, ph += step) {
-      const float s = sinf(2.0f * (float)M_PI * ph);
+    float *t = (float *)malloc(sizeof(float) * N);
+    int k = 0;
+    for (float ph = 0.0f; ph < 1.0f; ph += step, k++) {
       float v;
       switch (w) {
-        case SLOT_SINE:     v = s; break;
+        case SLOT_SINE:     v = sinf(2.0f * (float)M_PI * ph); break;
         case SLOT_SQR:      v = (ph < 0.5) ? 1.0f : -1.0f; break;
         case SLOT_SAW_DOWN: v = 2.0f * ph - 1.0f; break;
         case SLOT_SAW_UP:   v = 1.0f - 2.0f * ph; break;
         case SLOT_TRI:      v = (ph < 0.5f) ? (4.0f * ph - 1.0f) : (3.0f - 4.0f * ph); break;
-        default:            v = lcg_unit(&rng); break;     /* both noise slots share one stream */
+        default:            v = audio_rng_float(&rng); break;
       }
       t[k] = v;
     }
-  }
-  if (pcm_map && pcm) {
-    for (int i = 0; i < AMY_REGIONS; i++) {
-      const int slot = SLOT_AMY_FIRST + i;
-      if (slot > SLOT_AMY_LAST - 1) break;
-      const amy_region_t *m = &pcm_map[i];
-      float *t = (float *)malloc(sizeof(float) * (size_t)m->length);
-      for (uint32_t k = 0; k < m->length; k++) t[k] = (float)pcm[m->offset + k] / 32767.0f;
-      scale_to_unit_peak(t, (int)m->length);
-      wave_table_data[slot] = t; wave_size[slot] = (int)m->length; wave_rate[slot] = AMY_RATE;
-      wave_one_shot[slot] = 1; wave_loop_enabled[slot] = 0;
-      wave_loop_start[slot] = (int)m->loopstart; wave_loop_end[slot] = (int)m->loopend;
-      wave_midi_note[slot] = (int)m->midinote;
-      wave_offset_hz[slot] = midi2hz((float)m->midinote);
-    }
+    fill_slot(w, t, N, RATE, 0, 0, N - 1);
   }
 }
 
-void wave_free(void) {                                      /* synth.c:1296-1307 */
+/* Where this library's data files live: $SKRED_AMD_DATA, else data/ beside the shared object. */
+static const char *data_path(const char *name, char *buf, size_t cap) {
+  const char *dir = getenv("SKRED_AMD_DATA");
+  if (dir && *dir) { snprintf(buf, cap, "%s/%s", dir, name); return buf; }
+  Dl_info info;
+  if (dladdr((void *)&data_path, &info) && info.dli_fname) {
+    snprintf(buf, cap, "%s", info.dli_fname);
+    char *slash = strrchr(buf, '/');
+    if (slash) { snprintf(slash + 1, cap - (size_t)(slash + 1 - buf), "data/%s", name); return buf; }
+  }
+  snprintf(buf, cap, "data/%s", name);
+  return buf;
+}
+
+/* slots 32-62: the Korg DW-8000 single cycles (synth.c:1251-1268: int16/32767, MAIN_SAMPLE_RATE, not
+ * one-shot, loop 0..size-1) from the package's data blob (skred_amd/data/korg_waves.bin: "SKKORG1\0",
+ * u32 count, u32 size[count], int16 samples; written by skred_amd/data/extract_korg_waves.py).
+ * Returns the number of slots filled; a missing or damaged blob is reported, never papered over. */
+static int load_korg_cycles(void) {
+  char path[1024];
+  FILE *f = fopen(data_path("korg_waves.bin", path, sizeof path), "rb");
+  if (!f) { fprintf(stderr, "# skred_synth: %s not found: wave slots %d-%d stay empty\n", path, SLOT_KORG_FIRST, SLOT_KORG_LAST); return 0; }
+  char magic[8];
+  uint32_t count = 0, sizes[SLOT_KORG_LAST - SLOT_KORG_FIRST + 1];
+  int filled = 0;
+  if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "SKKORG1", 8) && fread(&count, 4, 1, f) == 1 &&
+      count <= SLOT_KORG_LAST - SLOT_KORG_FIRST + 1 && fread(sizes, 4, count, f) == count) {
+    for (uint32_t k = 0; k < count; k++) {
+      const int n = (int)sizes[k];
+      int16_t *raw = (int16_t *)malloc(sizeof(int16_t) * (size_t)n);
+      float *t = (float *)malloc(sizeof(float) * (size_t)n);
+      if (fread(raw, sizeof(int16_t), (size_t)n, f) != (size_t)n) { free(raw); free(t); break; }
+      for (int j = 0; j < n; j++) t[j] = (float)raw[j] / (float)32767;
+      free(raw);
+      fill_slot(SLOT_KORG_FIRST + (int)k, t, n, RATE, 0, 0, n - 1);
+      filled++;
+    }
+  }
+  fclose(f);
+  if (filled != SLOT_KORG_LAST - SLOT_KORG_FIRST + 1)
+    fprintf(stderr, "# skred_synth: %s is damaged: only %d of %d Korg waves loaded\n", path, filled, SLOT_KORG_LAST - SLOT_KORG_FIRST + 1);
+  return filled;
+}
+
+/* slots 100..: the AMY PCM regions, when the host program provides pcm / pcm_map (synth.c:1270-1292) */
+static void load_amy_regions(void) {
+  if (!(pcm_map && pcm)) return;
+  for (int i = 0; i < AMY_REGIONS && SLOT_AMY_FIRST + i < SLOT_AMY_LAST; i++) {
+    const int slot = SLOT_AMY_FIRST + i;
+    const amy_region_t *m = &pcm_map[i];
+    float *t = (float *)malloc(sizeof(float) * (size_t)m->length);
+    for (uint32_t k = 0; k < m->length; k++) t[k] = (float)pcm[m->offset + k] / 32767.0f;
+    scale_to_unit_peak(t, (int)m->length);
+    fill_slot(slot, t, (int)m->length, AMY_RATE, 1, (int)m->loopstart, (int)m->loopend);
+    wave_loop_enabled[slot] = 0;
+    wave_midi_note[slot] = (int)m->midinote;
+    wave_offset_hz[slot] = midi2hz((float)m->midinote);
+  }
+}
+
+void wave_table_init(void) {                                  /* synth.c:1199-1294 */
+  for (int i = 0; i < NW; i++) { wave_table_data[i] = NULL; wave_size[i] = 0; wave_is_miniwav[i] = 0; }
+  make_builtin_cycles();
+  load_korg_cycles();
+  load_amy_regions();
+}
+
+void wave_free(void) {                                        /* synth.c:1296-1307 */
   for (int i = 0; i < NW; i++) {
     if (!wave_table_data[i]) continue;
     if (wave_is_miniwav[i] && mw_free) mw_free(wave_table_data[i]); else free(wave_table_data[i]);
@@ -435,65 +508,110 @@ static long long ns_between(const struct timespec *a, const struct timespec *b) 
   return ((long long)b->tv_sec - a->tv_sec) * 1000000000LL + ((long long)b->tv_nsec - a->tv_nsec);
 }
 
-#define PUT(...) (p += sprintf(p, __VA_ARGS__))
-/* a voice as wire text, same tokens and order as synth.c:663-808 */
+/* voice_format() writes a voice back as the wire text that would recreate it (synth.c:663-808).
+ * The token list below is that format: each token is up to four values, each with the text in front of
+ * it, printed when its condition holds (always in verbose mode, except where noted). */
+typedef struct { const char *lead; char type; const void *base; size_t stride; } value_t;   /* 'i' int, 'f' float */
+typedef enum {
+  WHEN_NONZERO,         /* cond[0] != 0                                   */
+  WHEN_ANY_ASSIGNED,    /* cond[0] >= 0 || cond[1] >= 0  (floats; -1 = unassigned) */
+  WHEN_ROUTED,          /* cond[0] (int osc) >= 0 && cond[1] (float depth) > 0 */
+  WHEN_CUSTOM_SMOOTHING,/* (verbose || enable) && smoothing != default: verbose alone does not force it */
+  WHEN_SHAPED_ENVELOPE, /* !envelope_is_flat(v)                            */
+} when_t;
+typedef struct { when_t when; value_t cond[2]; value_t val[4]; } token_t;
+
+#define INTS(a)   'i', (a), sizeof(int)
+#define FLTS(a)   'f', (a), sizeof(float)
+#define ENVF(m)   'f', &voice_amp_envelope[0].m, sizeof(skred_envelope_t)
+static const token_t TOKENS[] = {
+  { WHEN_NONZERO,      {{0, FLTS(voice_midi_transpose)}},                         {{" N", FLTS(voice_midi_transpose)}} },
+  { WHEN_ANY_ASSIGNED, {{0, FLTS(voice_link_midi_a)}, {0, FLTS(voice_link_midi_b)}}, {{" G", FLTS(voice_link_midi_a)}, {",", FLTS(voice_link_midi_b)}} },
+  { WHEN_ANY_ASSIGNED, {{0, FLTS(voice_link_velo_a)}, {0, FLTS(voice_link_velo_b)}}, {{" H", FLTS(voice_link_velo_a)}, {",", FLTS(voice_link_velo_b)}} },
+  { WHEN_ANY_ASSIGNED, {{0, FLTS(voice_link_trig)}, {0, FLTS(voice_link_trig)}},  {{" L", FLTS(voice_link_trig)}} },
+  { WHEN_NONZERO,      {{0, INTS(voice_direction)}},                              {{" b", INTS(voice_direction)}} },
+  { WHEN_NONZERO,      {{0, INTS(voice_loop_enabled)}},                           {{" B", INTS(voice_loop_enabled)}} },
+  { WHEN_NONZERO,      {{0, FLTS(voice_pan)}},                                    {{" p", FLTS(voice_pan)}} },
+  { WHEN_NONZERO,      {{0, FLTS(voice_note)}},                                   {{" n", FLTS(voice_note)}} },
+  { WHEN_NONZERO,      {{0, INTS(voice_filter_mode)}},                            {{" J", INTS(voice_filter_mode)}, {" K", FLTS(voice_filter_freq)}, {" Q", FLTS(voice_filter_res)}} },
+  { WHEN_NONZERO,      {{0, INTS(voice_cz_mode)}},                                {{" c", INTS(voice_cz_mode)}, {",", FLTS(voice_cz_distortion)}} },
+  { WHEN_NONZERO,      {{0, INTS(voice_quantize)}},                               {{" q", INTS(voice_quantize)}} },
+  { WHEN_NONZERO,      {{0, INTS(voice_sample_hold_max)}},                        {{" h", INTS(voice_sample_hold_max)}} },
+  { WHEN_ROUTED,       {{0, INTS(voice_amp_mod_osc)}, {0, FLTS(voice_amp_mod_depth)}},   {{" A", INTS(voice_amp_mod_osc)}, {",", FLTS(voice_amp_mod_depth)}} },
+  { WHEN_ROUTED,       {{0, INTS(voice_cz_mod_osc)}, {0, FLTS(voice_cz_mod_depth)}},     {{" C", INTS(voice_cz_mod_osc)}, {",", FLTS(voice_cz_mod_depth)}} },
+  { WHEN_ROUTED,       {{0, INTS(voice_freq_mod_osc)}, {0, FLTS(voice_freq_mod_depth)}}, {{" F", INTS(voice_freq_mod_osc)}, {",", FLTS(voice_freq_mod_depth)}} },
+  { WHEN_ROUTED,       {{0, INTS(voice_pan_mod_osc)}, {0, FLTS(voice_pan_mod_depth)}},   {{" P", INTS(voice_pan_mod_osc)}, {",", FLTS(voice_pan_mod_depth)}} },
+  { WHEN_NONZERO,      {{0, INTS(voice_disconnect)}},                             {{" m", INTS(voice_disconnect)}} },
+  { WHEN_NONZERO,      {{0, INTS(voice_record)}},                                 {{" r", INTS(voice_record)}} },
+  { WHEN_CUSTOM_SMOOTHING, {{0, INTS(voice_smoother_enable)}, {0, FLTS(voice_smoother_smoothing)}}, {{" s", FLTS(voice_smoother_smoothing)}} },
+  { WHEN_NONZERO,      {{0, INTS(voice_glissando_enable)}},                       {{" g", FLTS(voice_glissando_speed)}} },
+  { WHEN_SHAPED_ENVELOPE, {{0}},                                                  {{" t", ENVF(a)}, {",", ENVF(d)}, {",", ENVF(s)}, {",", ENVF(r)}} },
+};
+/* the read-only tail of the verbose form: runtime state, not part of a patch */
+static const value_t VERBOSE_TAIL[] = {
+  {" freq_scale:", FLTS(voice_freq_scale)}, {" finished:", INTS(voice_finished)}, {" one_shot:", INTS(voice_one_shot)},
+  {" sample:", FLTS(voice_sample)}, {" smoother:", FLTS(voice_smoother_gain)},
+  {" phase:", FLTS(voice_phase)}, {" phase_inc:", FLTS(voice_phase_inc)}, {" offset_hz:", FLTS(voice_offset_hz)},
+};
+
+static double value_at(const value_t *x, int v) {
+  const char *p = (const char *)x->base + (size_t)v * x->stride;
+  return x->type == 'i' ? (double)*(const int *)p : (double)*(const float *)p;
+}
+
+static char *put_value(char *p, const value_t *x, int v) {
+  const char *at = (const char *)x->base + (size_t)v * x->stride;
+  if (x->type == 'i') return p + sprintf(p, "%s%d", x->lead, *(const int *)at);
+  return p + sprintf(p, "%s%g", x->lead, *(const float *)at);
+}
+
+static int token_due(const token_t *t, int v, int verbose) {
+  switch (t->when) {
+    case WHEN_NONZERO:          return verbose || value_at(&t->cond[0], v) != 0;
+    case WHEN_ANY_ASSIGNED:     return verbose || value_at(&t->cond[0], v) >= 0 || value_at(&t->cond[1], v) >= 0;
+    case WHEN_ROUTED:           return verbose || (value_at(&t->cond[0], v) >= 0 && value_at(&t->cond[1], v) > 0);
+    case WHEN_CUSTOM_SMOOTHING: return (verbose || value_at(&t->cond[0], v) != 0) && *((const float *)t->cond[1].base + v) != SMOOTH_K;
+    case WHEN_SHAPED_ENVELOPE:  return verbose || !envelope_is_flat(v);
+  }
+  return 0;
+}
+
 char *voice_format(int v, char *out, int verbose) {
   if (!out) return "(NULL)";
   if (bad_voice(v)) { out[0] = '\0'; return out; }
-  char *p = out;
-  const skred_envelope_t *e = &voice_amp_envelope[v];
-  PUT("v%d w%d f%g a%g", v, voice_wave_table_index[v], voice_freq[v], voice_user_amp[v]);
-  if (verbose || voice_midi_transpose[v]) PUT(" N%g", voice_midi_transpose[v]);
-  if (verbose || voice_link_midi_a[v] >= 0 || voice_link_midi_b[v] >= 0) PUT(" G%g,%g", voice_link_midi_a[v], voice_link_midi_b[v]);
-  if (verbose || voice_link_velo_a[v] >= 0 || voice_link_velo_b[v] >= 0) PUT(" H%g,%g", voice_link_velo_a[v], voice_link_velo_b[v]);
-  if (verbose || voice_link_trig[v] >= 0) PUT(" L%g", voice_link_trig[v]);
-  if (verbose || voice_direction[v]) PUT(" b%d", voice_direction[v]);
-  if (verbose || voice_loop_enabled[v]) PUT(" B%d", voice_loop_enabled[v]);
-  if (verbose || voice_pan[v]) PUT(" p%g", voice_pan[v]);
-  if (verbose || voice_note[v]) PUT(" n%g", voice_note[v]);
-  if (verbose || voice_filter_mode[v]) PUT(" J%d K%g Q%g", voice_filter_mode[v], voice_filter_freq[v], voice_filter_res[v]);
-  if (verbose || voice_cz_mode[v]) PUT(" c%d,%g", voice_cz_mode[v], voice_cz_distortion[v]);
-  if (verbose || voice_quantize[v]) PUT(" q%d", voice_quantize[v]);
-  if (verbose || voice_sample_hold_max[v]) PUT(" h%d", voice_sample_hold_max[v]);
-  if (verbose || (voice_amp_mod_osc[v] >= 0 && voice_amp_mod_depth[v] > 0)) PUT(" A%d,%g", voice_amp_mod_osc[v], voice_amp_mod_depth[v]);
-  if (verbose || (voice_cz_mod_osc[v] >= 0 && voice_cz_mod_depth[v] > 0)) PUT(" C%d,%g", voice_cz_mod_osc[v], voice_cz_mod_depth[v]);
-  if (verbose || (voice_freq_mod_osc[v] >= 0 && voice_freq_mod_depth[v] > 0)) PUT(" F%d,%g", voice_freq_mod_osc[v], voice_freq_mod_depth[v]);
-  if (verbose || (voice_pan_mod_osc[v] >= 0 && voice_pan_mod_depth[v] > 0)) PUT(" P%d,%g", voice_pan_mod_osc[v], voice_pan_mod_depth[v]);
-  if (verbose || voice_disconnect[v]) PUT(" m%d", voice_disconnect[v]);
-  if (verbose || voice_record[v]) PUT(" r%d", voice_record[v]);
-  if ((verbose || voice_smoother_enable[v]) && voice_smoother_smoothing[v] != SMOOTH_K) PUT(" s%g", voice_smoother_smoothing[v]);
-  if (verbose || voice_glissando_enable[v]) PUT(" g%g", voice_glissando_speed[v]);
-  if (verbose || !envelope_is_flat(v)) PUT(" t%g,%g,%g,%g", e->a, e->d, e->s, e->r);
+  char *p = out + sprintf(out, "v%d w%d f%g a%g", v, voice_wave_table_index[v], voice_freq[v], voice_user_amp[v]);
+  for (size_t k = 0; k < sizeof(TOKENS) / sizeof(TOKENS[0]); k++) {
+    const token_t *t = &TOKENS[k];
+    if (!token_due(t, v, verbose)) continue;
+    for (int j = 0; j < 4 && t->val[j].lead; j++) p = put_value(p, &t->val[j], v);
+  }
   if (verbose) {
-    PUT("\n#");
-    PUT(" freq_scale:%g", voice_freq_scale[v]);
-    PUT(" finished:%d one_shot:%d", voice_finished[v], voice_one_shot[v]);
-    PUT(" sample:%g", voice_sample[v]);
-    PUT(" smoother:%g", voice_smoother_gain[v]);
-    PUT(" phase:%g phase_inc:%g", voice_phase[v], voice_phase_inc[v]);
-    PUT(" offset_hz:%g", voice_offset_hz[v]);
-    PUT(" latency:%gms", (double)ns_between(&voice_mark_a[v], &voice_mark_b[v]) / 1000000.0);
+    p += sprintf(p, "\n#");
+    for (size_t k = 0; k < sizeof(VERBOSE_TAIL) / sizeof(VERBOSE_TAIL[0]); k++) p = put_value(p, &VERBOSE_TAIL[k], v);
+    p += sprintf(p, " latency:%gms", (double)ns_between(&voice_mark_a[v], &voice_mark_b[v]) / 1000000.0);
   }
   return out;
 }
 
-void voice_show(int v, char c, int verbose) {               /* synth.c:811-817 */
+void voice_show(int v, char c, int verbose) {                 /* synth.c:811-817 */
   char s[1024];
   voice_format(v, s, verbose);
-  if (strlen(s)) printf("; %s%s\n", s, c != ' ' ? " # *" : "");
+  if (s[0]) printf("; %s%s\n", s, c != ' ' ? " # *" : "");
 }
 
-int voice_show_all(int voice, int verbose) {                /* synth.c:819-827 */
+int voice_show_all(int voice, int verbose) {                  /* every sounding voice; the console voice starred */
   for (int i = 0; i < NV; i++)
     if (voice_amp[i] != 0) voice_show(i, i == voice ? '*' : ' ', verbose);
   return 0;
 }
 
-void synth_voice_bench(int voice) {                         /* synth.c:495-500 */
+void synth_voice_bench(int voice) {                           /* `:m`: stamp now, synth() stamps the next callback */
   voice_mark_b[voice].tv_sec = 0; voice_mark_b[voice].tv_nsec = 0;
   clock_gettime(CLOCK_MONOTONIC_COARSE, &voice_mark_a[voice]);
   voice_mark_go[voice] = 1;
 }
+
+#define PUT(...) (p += sprintf(p, __VA_ARGS__))
 
 /* ================================================================== synth(): GPU render */
 

@@ -4,7 +4,7 @@
   /root/reference/notamy/{sine,triangle,impulse}_lutset.h        float pyramids
   /root/reference/notamy/{sine,triangle,impulse}_lutset_fxpt.h   int16 pyramids + log2 size + scale
 
--> tests/golden/notamy_luts.npz   (arrays only; no header text is kept)
+-> skred_amd/data/notamy_luts.npz  (arrays only; no header text is kept)
 
 These band-limited single-cycle tables (from shorepine/AMY) are INPUT DATA of the hot path
 (north_star: "wavetable lookup into the notamy/ sine/triangle/impulse LUTs"); no reference C file

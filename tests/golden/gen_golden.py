@@ -161,6 +161,10 @@ class Case:
 
     def segment(self, ref: Ref, frames, block=512, keep_stems=(), note=""):
         bank, tables = ref.snapshot()
+        # oracle/ref_driver.c owns an EMPTY pcm[] / pcm_map[] (the sample blob is absent from the mount), so the AMY
+        # slots 100-199 of this reference build hold no data: no fixture may stand on them
+        idx = bank.a["voice_wave_table_index"]
+        assert not ((idx >= 100) & (idx <= 199)).any(), f"case {self.name}: a voice sits on an AMY slot (100-199)"
         if self.tables is None:
             self.tables = tables
             self.out["tables"] = tables
@@ -276,7 +280,7 @@ def case_c2_mixed_filter(ref, Case):
 def case_c2_notamy(ref, Case):
     """Config 2/3 tables: the notamy float LUT pyramids installed into EXT slots (the reference
     itself never loads them: SURVEY D3), voices spread over all pyramid levels, filter on."""
-    luts = np.load(os.path.join(HERE, "notamy_luts.npz"))
+    luts = np.load(os.path.join(HERE, "..", "..", "skred_amd", "data", "notamy_luts.npz"))
     names = json.loads(str(luts["names"]))
     slot = 200
     slots = []
@@ -525,6 +529,39 @@ def case_wav_samples(ref, Case):
     c.save()
 
 
+def korg_lines():
+    """64 voices over the Korg DW-8000 single cycles (wave slots 32-62, synth.c:1251-1268): every slot at least once,
+    the slots the shipped patches use (w33, w36, w49 in 2/11/16/23/42.sk) also as FM carriers and modulators, filters,
+    envelopes, reverse playback."""
+    lines = []
+    for v in range(64):
+        slot = 32 + v % 31
+        f = 41.2 * 2.0 ** (v / 11.0)
+        ln = f"v{v} w{slot} f{f:.4f} a{0.4 + 0.02 * (v % 13):.2f} p{-0.9 + 1.8 * ((v * 29) % 64) / 63.0:.4f}"
+        if v % 4 == 1:
+            ln += f" J{1 + v % 5} K{180.0 + 55.0 * v:.1f} Q{0.7 + 0.1 * (v % 6):.1f}"
+        if v % 5 == 2:
+            ln += f" t0.005,0.05,0.6,0.08 l{0.6 + 0.1 * (v % 4):.1f}"
+        if v % 9 == 4:
+            ln += " b1"
+        lines.append(ln)
+    # the shapes of the shipped patches: carrier on w49 modulated by a muted slow sine above it; a muted w33 modulator
+    lines += ["v60 w49 f440 a4 p1 F61,100", "v61 w0 f0.125 a100 m1", "v62 w36 f220 a2 A63,1", "v63 w33 f25 a50 m1"]
+    return lines
+
+
+def case_korg_waves(ref, Case):
+    for ln in korg_lines():
+        ref.wire(ln)
+    c = Case("korg_waves", "64 voices on the Korg DW-8000 cycles of wave slots 32-62 (incl. w33/w36/w49 as the shipped "
+                           "patches use them: FM carrier, AM carrier, muted modulators), filters, envelopes, reverse")
+    c.segment(ref, 3072, 512, note="attack/decay/sustain")
+    for v in range(2, 60, 5):
+        ref.wire(f"v{v} l0")
+    c.segment(ref, 4096, 512, note="note-off, release ends (3528 frames)")
+    c.save()
+
+
 def bank256_lines(part):
     """The 64 voice lines of part `part` (0..3) of the bank256_sum case: same tables per voice index in every part
     (so that all four snapshots share one table pool), everything else different."""
@@ -574,6 +611,7 @@ CASES = {
     "edge_mod": case_edge_mod,
     "wav_samples": case_wav_samples,
     "bank256_sum": case_bank256_sum,
+    "korg_waves": case_korg_waves,
 }
 
 

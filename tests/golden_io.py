@@ -13,7 +13,7 @@ from skred_amd.bank import RW_FIELDS, GlobalsC, VoiceBank, globals_from_json
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["c0_0sk", "c1_sine_adsr64", "c2_mixed_filter64", "c2_notamy64", "c4_pcm_oneshot",
-         "edge_basic", "edge_mod", "wav_samples", "bank256_sum"]
+         "edge_basic", "edge_mod", "wav_samples", "bank256_sum", "korg_waves"]
 # cases whose voices are independent (no FM/AM/pan/CZ modulators)
 MOD_FREE_CASES = ["c1_sine_adsr64", "c2_mixed_filter64", "c2_notamy64", "c4_pcm_oneshot", "edge_basic",
                   "wav_samples", "bank256_sum"]

@@ -35,13 +35,51 @@ def declared():
     return sorted(set(data)), sorted(set(funcs))
 
 
+def reference_surface():
+    """Every function synth.h prototypes, every scalar it declares extern and every synth.def array, read from the
+    reference tree itself (SURVEY 8b "What a C-ABI replacement must export")."""
+    hdr = re.sub(r"/\*.*?\*/|//[^\n]*", "", open(os.path.join(REFERENCE, "synth.h")).read(), flags=re.S)
+    funcs = re.findall(r"^\s*(?:[\w\*]+\s+)+\**(\w+)\s*\([^;{]*\)\s*;", hdr, flags=re.M)
+    scalars = re.findall(r"^extern\s+[^;(]*?(\w+)\s*;", hdr, flags=re.M)
+    arrays = re.findall(r"^ARRAY\(\s*[^,]+,\s*(\w+)\s*,", open(os.path.join(REFERENCE, "synth.def")).read(), flags=re.M)
+    return sorted(set(funcs)), sorted(set(scalars)), sorted(set(arrays))
+
+
 def test_dropin_exports_synth_h_surface():
     import ctypes
     L = ctypes.CDLL(SYNTH_SO)
     data, funcs = declared()
-    assert len(data) >= 75 + 9 and len(funcs) >= 45, (len(data), len(funcs))
+    assert len(data) >= 75 + 9 and len(funcs) >= 53, (len(data), len(funcs))
     missing = [s for s in data + funcs if not hasattr(L, s)]
     assert not missing, missing
+    if os.path.isdir(REFERENCE):
+        rf, rs, ra = reference_surface()
+        assert len(rf) >= 53 and len(rs) == 9 and len(ra) == 75, (len(rf), len(rs), len(ra))
+        missing = [s for s in rf + rs + ra if not hasattr(L, s)]
+        assert not missing, f"synth.h / synth.def symbols the drop-in does not export: {missing}"
+        undeclared = [s for s in rf + rs + ra if s not in data + funcs]
+        assert not undeclared, f"exported but not declared in include/skred_synth_abi.h: {undeclared}"
+
+
+def persample(mode, case):
+    out = subprocess.run([sys.executable, os.path.join(HERE, "persample_replay.py"), mode, case],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+@pytest.mark.parametrize("case", ["edge_mod", "edge_basic", "c4_pcm_oneshot", "c1_sine_adsr64", "korg_waves"])
+def test_per_sample_functions_match_reference(case):
+    """The eight per-sample functions of synth.h (osc_next, cz_phasor, quantize_bits_int, mmf_process,
+    amp_envelope_step, audio_rng_*) and voice_format() of the drop-in against the compiled reference: same calls on the
+    same voice state (the libraries' own tables incl. the Korg slots, then the fixture's), every returned float, the
+    state left behind and the text, bit for bit."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libskred_ref.so")):
+        pytest.skip("oracle/_ref/libskred_ref.so not built (needs the reference tree)")
+    ref, mine = persample("ref", case), persample("mine", case)
+    assert mine["stateless"] == ref["stateless"]
+    assert mine["state_and_values"] == ref["state_and_values"]
+    assert mine["text"] == ref["text"], (mine["text_sample"], ref["text_sample"])
 
 
 def ensure_check_lib():

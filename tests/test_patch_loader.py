@@ -46,12 +46,7 @@ def test_reference_patches_in_subset_match_reference_wire():
         pytest.skip("needs the reference tree")
     patches = sorted(int(os.path.basename(f)[:-3]) for f in glob.glob(os.path.join(REF, "*.sk")))
     checked, skipped = [], []
-    import re
     for n in patches:
-        text = open(os.path.join(REF, f"{n}.sk")).read()
-        if any(32 <= int(w) <= 63 for w in re.findall(r"(?<![A-Za-z])w(\d+)", text)):
-            skipped.append((n, "Korg table data (retro/korg.h) is not bundled with this build"))
-            continue
         mine = run(n, "mine")
         if mine["unsupported"] != 0:
             skipped.append((n, "outside the voice subset"))
@@ -61,4 +56,5 @@ def test_reference_patches_in_subset_match_reference_wire():
         assert not diff, f"patch {n}.sk: state differs in {sorted(diff)}"
         checked.append(n)
     assert len(checked) >= 8, (checked, skipped)
+    assert {2, 11}.issubset(checked), f"patches on Korg slots (w33/w49) must be among the checked ones: {checked}"
     print(f"patches identical to reference wire(): {checked}; outside the subset: {skipped}")

@@ -170,7 +170,9 @@ int  skred_bank_n_voices(const skred_bank_t *bank);
 int  skred_bank_set_tables_f32(skred_bank_t *bank, const float *pool, size_t n_floats);
 
 /* Pack `count` voices starting at host index `src_first` into device slots
- * [dst_first, dst_first+count).  Host arrays stay the source of truth. */
+ * [dst_first, dst_first+count).  Host arrays stay the source of truth.
+ * Synchronous: waits for all work queued on the device (renders on any stream) before the planes are overwritten;
+ * so do skred_bank_set_globals, skred_bank_get_globals and skred_bank_download. */
 int  skred_bank_upload(skred_bank_t *bank, const skred_voice_bank_t *host,
                        int src_first, int dst_first, int count);
 /* Copy the read-write fields (marked rw above) back into the host view. */
@@ -183,7 +185,8 @@ int  skred_bank_get_globals(skred_bank_t *bank, skred_globals_t *g);
 /*
  * Render `num_frames` frames of every voice (the two nested loops of
  * synth.c:520-613) and leave this GPU's PRE-master-volume stereo sum in
- * `d_partial` (device pointer, float[num_frames][2]).  `d_stems` (device,
+ * `d_partial` (device pointer, float[num_frames][2]): one kernel launch (plus
+ * the envelope kernel of the two-voices-per-lane path while notes ramp).  `d_stems` (device,
  * float[num_frames][n_voices][2], the `user` buffer layout of synth.c:533-534,
  * 607-611) may be NULL.  Advances synth_sample_count and the noise LCG.
  * `stream` is a hipStream_t (NULL = default stream).  Asynchronous.
@@ -200,16 +203,14 @@ int  skred_bank_render(skred_bank_t *bank, int num_frames, int interp,
 int  skred_bank_master(skred_bank_t *bank, const float *d_sum, int num_frames,
                        int num_channels, float *d_out, void *stream);
 
-/* Single-GPU form of render + master: the last stage of the partial-mix reduction and the master stage run
- * as one kernel (one launch fewer per block; same samples as skred_bank_render + skred_bank_master).
- * `d_out` as for skred_bank_master.  Asynchronous. */
+/* Single-GPU form of render + master in ONE launch: the render kernel's last-arriving workgroups add the
+ * per-workgroup rows up and apply the master gain (same samples as skred_bank_render + skred_bank_master:
+ * both forms add the rows in the same fixed order).  `d_out` as for skred_bank_master.  Asynchronous. */
 int  skred_bank_render_mix(skred_bank_t *bank, int num_frames, int interp, float *d_out, int num_channels,
                            float *d_stems_or_null, void *stream);
 
-/* With SKRED_OPT_OVERLAP_TAIL set, skred_bank_render_mix returns with the block's last two kernels queued on an
- * internal stream: block k+1 (which needs block k's voice state, not its mix) renders while block k's rows are
- * reduced and scaled -- the way an audio pipeline consumes block k while k+1 is computed.  Before `d_out` of the
- * most recent block is read on `stream` (or by the host after synchronising `stream`), make it wait: */
+/* Kept for callers of the earlier two-stream form (SKRED_OPT_OVERLAP_TAIL): a block is one launch now, `d_out` is
+ * complete when the launch is; this call does nothing. */
 int  skred_bank_wait_mix(skred_bank_t *bank, void *stream);
 
 /* Whole synth() contract on host buffers: render + master + D2H (+ stems). Synchronous. */
@@ -272,11 +273,17 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
        SKRED_OPT_KERNEL_TIMING = 4 /* n: an event pair brackets the render kernels of every n-th launch (default 1: every
                                       launch; 0: none).  skred_bank_last_render_ms / _timing_summary report the bracketed
                                       launches; an event pair costs ~6 us of stream time on an MI355X, hence the knob */,
-       SKRED_OPT_OVERLAP_TAIL = 3 /* skred_bank_render_mix: run the block's reduction + master stage on an internal
-                                     stream so that the next block's render overlaps it (see skred_bank_wait_mix) */ };
+       SKRED_OPT_OVERLAP_TAIL = 3 /* accepted and ignored (the block's mix-down and master stage run inside the render
+                                     kernel: there is no tail left to overlap) */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */
+
+/* Self-check of the "no envelope in motion" latch of the two-voices-per-lane path ("Envelopes in motion"):
+ * the number of launches that skipped sk_render_env2_kernel although a 128-voice slice turned out to need it.  Must
+ * stay 0; a non-zero value means a voice left a constant envelope level without a control action reaching the bank
+ * (skred_amd_last_error() names the launch), after which the latch is re-armed by itself. */
+unsigned skred_bank_env_latch_misses(const skred_bank_t *bank);
 
 /* Timing of the most recent skred_bank_render() on its stream, via hipEvents
  * recorded around the render kernel itself (ms; <0 if unavailable). Synchronises. */

@@ -46,23 +46,9 @@ static int grow(float **buf, size_t *cap, size_t need) {
   return SKRED_OK;
 }
 
-int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
-  if (!out || n_voices <= 0) return fail(SKRED_E_BAD_ARG, "skred_bank_create: bad arguments");
-  *out = NULL;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(SKRED_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
-  if (device < 0 || device >= ndev) return fail(SKRED_E_BAD_ARG, "device %d of %d", device, ndev);
-  HIP_TRY(hipSetDevice(device));
-  skred_bank_t *b = (skred_bank_t *)calloc(1, sizeof(*b));
-  if (!b) return fail(SKRED_E_NO_MEM, "calloc");
-  b->device = device;
-  b->n_voices = n_voices;
-  b->n_groups = ((n_voices + 4 * SK_GROUP - 1) / (4 * SK_GROUP)) * 4;   /* multiple of 4: the two-per-lane kernel takes up to 1024 voices per pass */
-  b->fast2_min_voices = SK_FAST2_MIN_VOICES;
-  b->last_tail = -1;
-  b->timing_every = 1;
-  b->n_padded = b->n_groups * SK_GROUP;
+/* everything after the calloc: on any failure the caller destroys the partly built bank (skred_bank_destroy
+ * tolerates one), so neither the struct nor the HBM already allocated leaks */
+static int bank_build(skred_bank_t *b) {
   const size_t plane_bytes = (size_t)b->n_padded * sizeof(sk_plane_t);
   /* one slab, planes back to back (read-only planes first): a window of voices across all planes is one pitched copy */
   HIP_TRY(hipMalloc((void **)&b->d_planes, (size_t)(SKP_COUNT + SKS_COUNT) * plane_bytes));
@@ -93,20 +79,44 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   HIP_TRY(hipMemset(b->d_group_flag, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
   HIP_TRY(hipMalloc((void **)&b->d_env_list, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
   HIP_TRY(hipMemset(b->d_env_list, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
-  b->class_dirty = 1;
-  b->mod_dirty = 1;
   HIP_TRY(hipMalloc((void **)&b->d_gain_state, 4 * sizeof(float)));
   HIP_TRY(hipMemset(b->d_gain_state, 0, 4 * sizeof(float)));
+  /* arrival tickets of the in-kernel mix-down: zero once, every last arriver re-arms its own */
+  HIP_TRY(hipMalloc((void **)&b->d_tickets, (SK_FINISH_SLABS + 1) * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(b->d_tickets, 0, (SK_FINISH_SLABS + 1) * sizeof(uint32_t)));
   for (int i = 0; i < SK_TIMING_RING; i++) {
     HIP_TRY(hipEventCreate(&b->ev0[i]));
     HIP_TRY(hipEventCreate(&b->ev1[i]));
   }
+  return SKRED_OK;
+}
+
+int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
+  if (!out || n_voices <= 0) return fail(SKRED_E_BAD_ARG, "skred_bank_create: bad arguments");
+  *out = NULL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SKRED_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(SKRED_E_BAD_ARG, "device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  skred_bank_t *b = (skred_bank_t *)calloc(1, sizeof(*b));
+  if (!b) return fail(SKRED_E_NO_MEM, "calloc");
+  b->device = device;
+  b->n_voices = n_voices;
+  b->n_groups = ((n_voices + 4 * SK_GROUP - 1) / (4 * SK_GROUP)) * 4;   /* multiple of 4: the two-per-lane kernel takes up to 1024 voices per pass */
+  b->fast2_min_voices = SK_FAST2_MIN_VOICES;
+  b->timing_every = 1;
+  b->n_padded = b->n_groups * SK_GROUP;
+  b->class_dirty = 1;
+  b->mod_dirty = 1;
   /* synth.c:85-92 defaults: volume_user 1 * AMY_FACTOR, LCG seeded with 1 (synth.c:508) */
   b->g.synth_sample_count = 0;
   b->g.noise_rng = 1;
   b->g.volume_final = 0.025f;
   b->g.volume_smoother_gain = 0.0f;
   b->g.volume_smoother_smoothing = 0.002f;
+  const int rc = bank_build(b);
+  if (rc) { skred_bank_destroy(b); return rc; }      /* (the error text set by the failing step survives: destroy reports nothing) */
   *out = b;
   return SKRED_OK;
 }
@@ -116,17 +126,11 @@ void skred_bank_destroy(skred_bank_t *b) {
   hipSetDevice(b->device);
   if (b->d_planes) hipFree(b->d_planes);
   if (b->d_tables) hipFree(b->d_tables);
-  for (int i = 0; i < 2; i++) {
-    if (b->d_partial_buf[i]) hipFree(b->d_partial_buf[i]);
-    if (b->ev_rows[i]) hipEventDestroy(b->ev_rows[i]);
-    if (b->ev_tail[i]) hipEventDestroy(b->ev_tail[i]);
-  }
-  if (b->aux) hipStreamDestroy(b->aux);
+  if (b->d_partial) hipFree(b->d_partial);
+  if (b->d_tickets) hipFree(b->d_tickets);
   if (b->d_gain_state) hipFree(b->d_gain_state);
-  if (b->d_sum) hipFree(b->d_sum);
   if (b->d_out) hipFree(b->d_out);
   if (b->d_stems) hipFree(b->d_stems);
-  if (b->d_redtmp) hipFree(b->d_redtmp);
   free(b->h_class); free(b->h_mod); free(b->h_level);
   sk_queue_free(b);
   for (int i = 0; i < SK_UPD_RING; i++) {
@@ -174,6 +178,9 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
     return fail(SKRED_E_RANGE, "upload window [%d,+%d) -> [%d,+%d) outside bank", src_first, count, dst_first, count);
   if (count == 0) return SKRED_OK;
   HIP_TRY(hipSetDevice(b->device));
+  /* synchronous by contract: the planes are overwritten with a blocking copy, and a render still running on a
+   * non-blocking stream (the caller's, or the bank's own tail stream) is not ordered against that by itself */
+  HIP_TRY(hipDeviceSynchronize());
   const int NP = SKP_COUNT + SKS_COUNT;
   sk_plane_t *st = (sk_plane_t *)calloc((size_t)NP * (size_t)count, sizeof(sk_plane_t));
   sk_voice_meta_t *meta = (sk_voice_meta_t *)malloc((size_t)count * sizeof(sk_voice_meta_t));
@@ -191,8 +198,8 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
                                    hipMemcpyHostToDevice);
   free(st);
   if (e != hipSuccess) { free(meta); HIP_TRY(e); }
-  if (dst_first == 0 && count == b->n_voices) { b->features = 0; b->mod_escapes = 0; }   /* whole bank replaced */
-  for (int i = 0; i < count; i++) sk_apply_meta(b, dst_first + i, &meta[i]);
+  if (dst_first == 0 && count == b->n_voices) b->features = 0;                /* whole bank replaced */
+  for (int i = 0; i < count; i++) sk_apply_meta(b, dst_first + i, &meta[i], 1, 1);
   free(meta);
   sk_control_changed(b);
   return SKRED_OK;
@@ -202,9 +209,17 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
  * all voices that can sound: none is "exotic" (stopping one-shot, reverse, sample&hold, bit-crush,
  * noise, modulated, smoother off, non-finite phase data), and the biquad / the envelope are each used
  * by all of them or by none.  Anything else runs the generic kernel; both give identical samples. */
-static void classify(skred_bank_t *b) {
-  if (!b->class_dirty) return;
-  const int real = b->cnt_real, filt = b->cnt_filter, env = b->cnt_env, exotic = b->cnt_exotic;
+static int classify(skred_bank_t *b) {
+  if (b->cnt_future > 0 && b->g.synth_sample_count >= b->future_horizon) {
+    /* the clock has passed every note-on / note-off that was written ahead of it: those voices are ordinary again */
+    for (int v = 0; v < b->n_padded; v++) b->h_class[v] &= (uint8_t)~SKC_FUTURE;
+    b->cnt_future = 0;
+    b->class_dirty = 1;
+  }
+  if (!b->class_dirty) return SKRED_OK;
+  /* a voice whose envelope clock lies ahead of the bank's changes stage on its own in mid-launch (SKC_FUTURE): only
+   * the generic kernel, which evaluates the stage per frame from the integer clocks, renders that */
+  const int real = b->cnt_real, filt = b->cnt_filter, env = b->cnt_env, exotic = b->cnt_exotic + b->cnt_future;
   uint32_t m = 0;
   if (real > 0 && !exotic) {
     m = SKM_FAST;
@@ -217,7 +232,7 @@ static void classify(skred_bank_t *b) {
   b->fast_mode = m;
   b->class_dirty = 0;
   /* dependency levels for modulated banks (skred_render_generic.hip: sk_render_mod_kernel) */
-  if (!b->mod_dirty) return;
+  if (!b->mod_dirty) return SKRED_OK;
   b->mod_dirty = 0;
   b->max_level = 0;
   if (b->features & (SKB_ANY_MOD | SKB_ANY_FM)) {
@@ -232,8 +247,10 @@ static void classify(skred_bank_t *b) {
         if (lvl > b->max_level) b->max_level = lvl;
       }
     }
-    hipMemcpy(b->d_level, b->h_level, (size_t)b->n_padded * sizeof(int), hipMemcpyHostToDevice);
+    const hipError_t e = hipMemcpy(b->d_level, b->h_level, (size_t)b->n_padded * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { b->mod_dirty = 1; return fail(SKRED_E_NO_DEVICE, "dependency levels -> %s", hipGetErrorString(e)); }
   }
+  return SKRED_OK;
 }
 
 int skred_bank_set_option(skred_bank_t *b, int option, int value) {
@@ -242,15 +259,13 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
     case SKRED_OPT_FORCE_GENERIC: b->force_generic = value != 0; return SKRED_OK;
     case SKRED_OPT_FAST2_MIN_VOICES: b->fast2_min_voices = value; b->fast2_min_user = 1; return SKRED_OK;
     case SKRED_OPT_KERNEL_TIMING: b->timing_every = value < 0 ? 0 : value; return SKRED_OK;
-    case SKRED_OPT_OVERLAP_TAIL:
-      if (hipSetDevice(b->device) == hipSuccess) (void)hipDeviceSynchronize();   /* no tail in flight across the switch */
-      b->overlap_tail = value != 0;
-      return SKRED_OK;
+    case SKRED_OPT_OVERLAP_TAIL: return SKRED_OK;   /* accepted and ignored: a block is one launch, there is no tail to overlap */
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
 }
 
 int skred_bank_last_kernel(const skred_bank_t *b) { return b ? b->last_kernel : -1; }
+unsigned skred_bank_env_latch_misses(const skred_bank_t *b) { return b ? b->quiet_misses : 0u; }
 
 int skred_bank_download(skred_bank_t *b, skred_voice_bank_t *h, int src_first, int dst_first, int count) {
   if (!b || !h || count < 0) return fail(SKRED_E_BAD_ARG, "download: bad arguments");
@@ -291,8 +306,11 @@ int skred_bank_download(skred_bank_t *b, skred_voice_bank_t *h, int src_first, i
 int skred_bank_set_globals(skred_bank_t *b, const skred_globals_t *g) {
   if (!b || !g) return fail(SKRED_E_BAD_ARG, "set_globals");
   HIP_TRY(hipSetDevice(b->device));
+  /* the carried master gain lives on the device and a block's tail may still be writing it (on the caller's
+   * non-blocking stream, or on the bank's tail stream under SKRED_OPT_OVERLAP_TAIL): wait for the device first */
+  HIP_TRY(hipDeviceSynchronize());
   b->g = *g;
-  HIP_TRY(hipMemcpy(b->d_gain_state + b->gain_slot, &g->volume_smoother_gain, sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_gain_state, &g->volume_smoother_gain, sizeof(float), hipMemcpyHostToDevice));
   sk_control_changed(b);              /* the clock may have moved: envelope stages are a function of it */
   return SKRED_OK;
 }
@@ -301,7 +319,7 @@ int skred_bank_get_globals(skred_bank_t *b, skred_globals_t *g) {
   if (!b || !g) return fail(SKRED_E_BAD_ARG, "get_globals");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(&b->g.volume_smoother_gain, b->d_gain_state + b->gain_slot, sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&b->g.volume_smoother_gain, b->d_gain_state, sizeof(float), hipMemcpyDeviceToHost));
   *g = b->g;
   return SKRED_OK;
 }
@@ -315,42 +333,45 @@ static void poll_env_quiet(skred_bank_t *b) {
     if (hipEventQuery(b->quiet_ev[i]) != hipSuccess) return;         /* that launch has not finished yet */
     /* the kernel stores its launch ticket into the slot when it defers a group: an older ticket = none deferred;
      * the answer only holds if no control action reached the bank since that launch was issued */
-    if (b->h_quiet[i] != b->quiet_ticket[i] && b->quiet_epoch[i] == b->control_epoch) b->env_quiet = 1;
+    const int deferred = b->h_quiet[i] == b->quiet_ticket[i];
+    if (!deferred && b->quiet_epoch[i] == b->control_epoch) b->env_quiet = 1;
+    if (deferred && b->quiet_skipped[i]) {
+      /* self-check: a launch that ran WITHOUT sk_render_env2_kernel had a slice with an envelope in motion -- the
+       * premise of the latch ("stages only move towards a constant level between control actions") was violated.
+       * Re-arm at once and say so; that block's slice was silent. */
+      b->env_quiet = 0;
+      b->quiet_misses++;
+      (void)fail(SKRED_E_UNSUPPORTED, "launch %u skipped the envelope kernel but a slice had an envelope in motion", b->quiet_ticket[i]);
+    }
     b->quiet_tail++;
     b->quiet_pending--;
   }
 }
 
-/* everything up to the per-workgroup partial rows: picks and launches the render kernels, advances the timeline */
-static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_stems, hipStream_t s, int *n_wg_out) {
+/* One block: picks and launches the render kernel(s), whose last-arriving workgroups also add the per-workgroup rows
+ * up (skred_kernel_common.hpp: sk_finish_block) into `d_sum` (pre-master, may be NULL) and / or, scaled by the master
+ * gain of each frame, into `d_out`; advances the timeline. */
+static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_stems, float *d_sum, float *d_out,
+                        int num_channels, hipStream_t s) {
   if (interp != SKRED_INTERP_TRUNCATE && interp != SKRED_INTERP_LINEAR) return fail(SKRED_E_BAD_ARG, "render: interp %d", interp);
   if (!b->d_tables) return fail(SKRED_E_BAD_ARG, "render: no table pool set");
-  if ((b->features & (SKB_ANY_MOD | SKB_ANY_FM)) && b->mod_escapes)
+  if ((b->features & (SKB_ANY_MOD | SKB_ANY_FM)) && b->cnt_escapes > 0)
     return fail(SKRED_E_UNSUPPORTED, "a voice is modulated by a voice outside its aligned 64-voice group: "
                                      "keep modulator and carrier in the same group (SURVEY 8e)");
   HIP_TRY(hipSetDevice(b->device));
-  classify(b);
+  int rc = classify(b);
+  if (rc) return rc;
   /* the modulated kernel serves every kind of modulation; banks whose only modulation is previous-frame FM stay on
    * the one-per-lane kernel when they are otherwise clean */
   const int fast_ok = (b->fast_mode & SKM_FAST) && !b->force_generic;
   const int modulated = (b->features & SKB_ANY_MOD) != 0 || ((b->features & SKB_ANY_FM) && b->cnt_fm > 0 && !fast_ok);
   int n_wg = b->n_groups < SK_MAX_WORKGROUPS ? b->n_groups : SK_MAX_WORKGROUPS;   /* workgroups stride over 256-voice passes */
-  /* partial rows: alternate between two buffers (only the overlapped tail needs it; harmless otherwise) */
-  const int slot = b->partial_slot;
-  int rc = grow(&b->d_partial_buf[slot], &b->partial_buf_cap[slot], (size_t)n_wg * (size_t)num_frames * 2);
-  if (rc) return rc;
-  b->d_partial = b->d_partial_buf[slot];
-  if (b->tail_pending[slot]) {            /* the tail of two blocks ago may still be reading this buffer */
-    HIP_TRY(hipStreamWaitEvent(s, b->ev_tail[slot], 0));
-    b->tail_pending[slot] = 0;
-  }
 
   sk_render_args_t a;
   memset(&a, 0, sizeof(a));
   for (int p = 0; p < SKP_COUNT; p++) a.ro[p] = b->d_ro[p];
   for (int p = 0; p < SKS_COUNT; p++) a.rw[p] = b->d_rw[p];
   a.tables = b->d_tables;
-  a.partial = b->d_partial;
   a.stems = d_stems;
   a.group_flag = b->d_group_flag;
   a.env_list = b->d_env_list;
@@ -363,7 +384,6 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   a.lds_table_floats = b->table_floats_padded <= SK_LDS_TABLE_MAX_FLOATS ? (int32_t)b->table_floats_padded : 0;
   a.interp = interp;
   a.features = b->features;
-  classify(b);
   a.fast_mode = b->force_generic ? 0u : b->fast_mode;
   /* two voices per lane pay off for large LDS-table banks (packed fp32); banks whose tables stay in L2 / HBM do
    * better with one voice per lane at every size measured (2^16 .. 2^20: twice the waves to hide the window
@@ -373,27 +393,40 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
     a.fast_mode |= SKM_TWO_PER_LANE;        /* (voices that finish mid-launch are handled by the one-per-lane kernel only) */
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
-  if ((rc = grow(&b->d_redtmp, &b->redtmp_cap, (size_t)sk_reduce_tmp_floats(2 * num_frames)))) return rc;
-
-  const int tslot = b->n_timed % SK_TIMING_RING;
   if (!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) {
     /* passes of sk_render_fast2_kernel: 1024 voices each for LDS-table banks, 512 otherwise (skred_render_fast2.hip) */
     const int passes = a.lds_table_floats > 0 ? b->n_groups * 2 / SK_FAST2_NW_LDS : b->n_groups / 2;
     n_wg = passes < SK_MAX_WORKGROUPS ? passes : SK_MAX_WORKGROUPS;
   }
+  /* rows of the partial mix, the slab sums of the two-level mix-down and the per-frame master gains: one allocation */
+  const size_t row = (size_t)num_frames * 2;
+  if ((rc = grow(&b->d_partial, &b->partial_cap, ((size_t)n_wg + SK_FINISH_SLABS) * row + (size_t)num_frames))) return rc;
+  a.partial = b->d_partial;
+  a.slab_rows = b->d_partial + (size_t)n_wg * row;
+  a.gains = a.slab_rows + (size_t)SK_FINISH_SLABS * row;
+  a.n_rows = n_wg;
+  a.finish = 1;
+  a.wg_shift = d_out ? 1 : 0;               /* the gain workgroup only exists where the master stage is applied */
+  a.sum_out = d_sum;
+  a.mix_out = d_out;
+  a.num_channels = num_channels;
+  a.gain_state = b->d_gain_state;
+  a.tickets = b->d_tickets;
+  a.vol_target = b->g.volume_final;
+  a.vol_k = b->g.volume_smoother_smoothing;
+  if (getenv("SKRED_DEBUG_NO_FINISH")) { a.finish = 0; a.wg_shift = 0; }   /* timing experiments only: the block's output is then garbage */
+
+  const int tslot = b->n_timed % SK_TIMING_RING;
   /* two-per-lane banks with envelopes: sk_render_fast2_kernel hands groups with envelopes in motion to
    * sk_render_env2_kernel.  Envelope stages only move towards a constant level on their own, so once a launch
    * has deferred no group, none will be deferred until a control action arrives: the second launch is skipped. */
   const int two_env = !modulated && (a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
   if (two_env) poll_env_quiet(b);
   a.launch_ticket = ++b->launch_ticket;
-  a.skip_env2 = two_env && b->env_quiet;
+  /* a voice whose note-on / note-off clock lies ahead of the bank's (cnt_future) can leave a constant level on its own */
+  a.skip_env2 = two_env && b->env_quiet && b->cnt_future == 0;
   const int timed = b->timing_every > 0 && (b->launch_ticket % (uint32_t)b->timing_every) == 0;
-  if (timed) {
-    /* a bracketed launch is measured alone: the previous block's overlapped tail (if any) finishes first */
-    if (b->last_tail >= 0 && b->tail_pending[b->last_tail]) HIP_TRY(hipStreamWaitEvent(s, b->ev_tail[b->last_tail], 0));
-    HIP_TRY(hipEventRecord(b->ev0[tslot], s));
-  }
+  if (timed) HIP_TRY(hipEventRecord(b->ev0[tslot], s));
   hipError_t e;
   if (modulated) {
     b->last_kernel = SKRED_KERNEL_MODULATED;
@@ -406,8 +439,9 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
     HIP_TRY(hipEventRecord(b->ev1[tslot], s));
     b->n_timed++;
   }
-  if (two_env && !b->env_quiet && b->quiet_pending < SK_QUIET_RING) {
-    /* ask (asynchronously) whether this launch deferred any group */
+  if (two_env && (!a.skip_env2 || (a.launch_ticket & 63u) == 0) && b->quiet_pending < SK_QUIET_RING) {
+    /* ask (asynchronously) whether this launch deferred any group; while the latch holds, every 64th launch is
+     * still asked, as a self-check of the latch's premise (poll_env_quiet) */
     const int i = b->quiet_head % SK_QUIET_RING;
     if (!b->h_quiet) HIP_TRY(hipHostMalloc((void **)&b->h_quiet, SK_QUIET_RING * sizeof(uint32_t), hipHostMallocDefault));
     if (!b->quiet_ev[i]) HIP_TRY(hipEventCreateWithFlags(&b->quiet_ev[i], hipEventDisableTiming));
@@ -415,6 +449,7 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
     HIP_TRY(hipEventRecord(b->quiet_ev[i], s));
     b->quiet_ticket[i] = a.launch_ticket;
     b->quiet_epoch[i] = b->control_epoch;
+    b->quiet_skipped[i] = (uint8_t)a.skip_env2;
     b->quiet_head++;
     b->quiet_pending++;
   }
@@ -424,64 +459,25 @@ static int render_rows(skred_bank_t *b, int num_frames, int interp, float *d_ste
   uint64_t r = b->g.noise_rng;
   for (int i = 0; i < num_frames; i++) r = r * 6364136223846793005ULL + 1442695040888963407ULL;
   b->g.noise_rng = r;
-  *n_wg_out = n_wg;
   return SKRED_OK;
 }
 
 int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_partial, float *d_stems, void *stream) {
   if (!b || !d_partial || num_frames <= 0) return fail(SKRED_E_BAD_ARG, "render: bad arguments");
-  int n_wg = 0;
-  const int rc = render_rows(b, num_frames, interp, d_stems, (hipStream_t)stream, &n_wg);
-  if (rc) return rc;
-  if (b->last_tail >= 0 && b->tail_pending[b->last_tail])      /* an overlapped tail may still use the reduction scratch */
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, b->ev_tail[b->last_tail], 0));
-  const hipError_t e = (hipError_t)sk_launch_reduce(b->d_partial, b->d_redtmp, d_partial, n_wg, 2 * num_frames, (hipStream_t)stream);
-  if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "reduce launch -> %s", hipGetErrorString(e));
-  return SKRED_OK;
+  return render_block(b, num_frames, interp, d_stems, d_partial, NULL, 0, (hipStream_t)stream);
 }
 
 int skred_bank_render_mix(skred_bank_t *b, int num_frames, int interp, float *d_out, int num_channels,
                           float *d_stems, void *stream) {
   if (!b || !d_out || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "render_mix: bad arguments");
-  hipStream_t s = (hipStream_t)stream, tail = s;
-  int n_wg = 0;
-  const int rc = render_rows(b, num_frames, interp, d_stems, s, &n_wg);
-  if (rc) return rc;
-  const int slot = b->partial_slot;
-  if (b->overlap_tail) {
-    /* the tail only depends on this block's rows: hand it to the auxiliary stream so that the next block's
-     * render (which depends on this block's voice state, not on its mix) starts right behind this one */
-    if (!b->aux) HIP_TRY(hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
-      if (!b->ev_rows[i]) HIP_TRY(hipEventCreateWithFlags(&b->ev_rows[i], hipEventDisableTiming));
-      if (!b->ev_tail[i]) HIP_TRY(hipEventCreateWithFlags(&b->ev_tail[i], hipEventDisableTiming));
-    }
-    HIP_TRY(hipEventRecord(b->ev_rows[slot], s));
-    HIP_TRY(hipStreamWaitEvent(b->aux, b->ev_rows[slot], 0));
-    tail = b->aux;
-  }
-  /* the carried master gain alternates between two device slots (see sk_reduce_master_kernel) */
-  const hipError_t e = (hipError_t)sk_launch_reduce_master(b->d_partial, b->d_redtmp, n_wg, d_out, num_frames, num_channels,
-                                                           b->g.volume_final, b->g.volume_smoother_smoothing,
-                                                           b->d_gain_state + b->gain_slot, b->d_gain_state + (b->gain_slot ^ 1),
-                                                           tail);
-  if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "reduce+master launch -> %s", hipGetErrorString(e));
-  b->gain_slot ^= 1;
-  if (b->overlap_tail) {
-    HIP_TRY(hipEventRecord(b->ev_tail[slot], b->aux));
-    b->tail_pending[slot] = 1;
-    b->last_tail = slot;
-    b->partial_slot ^= 1;
-  }
-  return SKRED_OK;
+  return render_block(b, num_frames, interp, d_stems, NULL, d_out, num_channels, (hipStream_t)stream);
 }
 
+/* (since the mix-down moved into the render kernel a block has no tail left to overlap: kept for callers of the
+ * earlier form, nothing to wait for) */
 int skred_bank_wait_mix(skred_bank_t *b, void *stream) {
+  (void)stream;
   if (!b) return fail(SKRED_E_BAD_ARG, "wait_mix");
-  if (b->overlap_tail && b->last_tail >= 0 && b->ev_tail[b->last_tail]) {
-    HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, b->ev_tail[b->last_tail], 0));
-  }
   return SKRED_OK;
 }
 
@@ -489,7 +485,7 @@ int skred_bank_master(skred_bank_t *b, const float *d_sum, int num_frames, int n
   if (!b || !d_sum || !d_out || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "master: bad arguments");
   HIP_TRY(hipSetDevice(b->device));
   hipError_t e = (hipError_t)sk_launch_master(d_sum, d_out, num_frames, num_channels, b->g.volume_final,
-                                              b->g.volume_smoother_smoothing, b->d_gain_state + b->gain_slot, (hipStream_t)stream);
+                                              b->g.volume_smoother_smoothing, b->d_gain_state, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "master launch -> %s", hipGetErrorString(e));
   return SKRED_OK;
 }

@@ -34,23 +34,13 @@ struct skred_bank {
   float *d_tables;
   size_t table_floats;        /* real pool size       */
   size_t table_floats_padded; /* rounded up to 4      */
-  float *d_partial;           /* [n_wg][F][2]: the rows the current launch writes (one of d_partial_buf) */
-  float *d_partial_buf[2];    /* two row buffers: with SKRED_OPT_OVERLAP_TAIL block k+1 renders while block k's rows are reduced */
-  size_t partial_buf_cap[2];
-  int partial_slot;
-  int overlap_tail;           /* SKRED_OPT_OVERLAP_TAIL */
+  float *d_partial;           /* [n_wg][F][2] workgroup rows, then [SK_FINISH_SLABS][F][2] slab sums, then [F] master gains */
+  size_t partial_cap;         /* floats */
+  uint32_t *d_tickets;        /* [SK_FINISH_SLABS + 1] arrival counters of the in-kernel mix-down */
   int timing_every;           /* SKRED_OPT_KERNEL_TIMING: bracket every n-th launch's render kernels with an event pair (0: none) */
-  hipStream_t aux;            /* the tail (reduction + master) of skred_bank_render_mix runs here when overlapping */
-  hipEvent_t ev_rows[2], ev_tail[2];
-  int tail_pending[2];        /* ev_tail[i] has been recorded and not yet waited for by a render into buffer i */
-  int last_tail;              /* buffer whose tail was issued last (-1: none) */
-  size_t partial_cap;         /* floats               */
-  float *d_gain_state;        /* master smoother gain: two slots, gain_slot is the current one */
-  int gain_slot;
-  float *d_redtmp;            /* second-stage scratch of the partial-mix reduction */
-  size_t redtmp_cap;
-  float *d_sum, *d_out, *d_stems; /* scratch of skred_bank_render_host */
-  size_t sum_cap, out_cap, stems_cap;
+  float *d_gain_state;        /* master smoother gain carried between blocks */
+  float *d_out, *d_stems;     /* scratch of skred_bank_render_host */
+  size_t out_cap, stems_cap;
   uint8_t *h_class;           /* per-voice SKC_* bits, shadow used to pick the kernel */
   int8_t *h_mod;              /* [4][n_padded] modulator lane inside the 64-voice group (fm, am, pm, cz) or -1 */
   int *h_level;               /* [n_padded] dependency level of each voice (modulated banks) */
@@ -58,9 +48,11 @@ struct skred_bank {
   int32_t *d_env_list;        /* the flagged slices, compacted (sk_compact_flags_kernel) */
   int32_t *d_group_flag;      /* per 128-voice wave slice: left to sk_render_env2_kernel; one more slot: the ticket */
   int max_level;
-  int mod_escapes;            /* some modulator lies outside its carrier's 64-voice group */
   int class_dirty;
   int cnt_real, cnt_filter, cnt_env, cnt_exotic, cnt_stops, cnt_fm;   /* voices per SKC_* bit (kept incrementally) */
+  int cnt_escapes;            /* voices naming a modulator outside their aligned 64-voice group (SKC_ESCAPES) */
+  uint64_t future_horizon;    /* the latest such clock value: once the bank's clock reaches it, no voice is "future" any more */
+  int cnt_future;             /* enveloped voices whose note-on / note-off clock lay ahead of the bank's when they were written (SKC_FUTURE) */
   int mod_dirty;              /* modulator lanes changed: dependency levels must be recomputed */
   uint32_t fast_mode;         /* SKM_* from classify() */
   int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
@@ -78,7 +70,9 @@ struct skred_bank {
   uint32_t *h_quiet;          /* pinned: SK_QUIET_RING tickets read back from d_group_flag[n_groups*2] */
   hipEvent_t quiet_ev[SK_QUIET_RING];
   uint32_t quiet_ticket[SK_QUIET_RING], quiet_epoch[SK_QUIET_RING];
+  uint8_t quiet_skipped[SK_QUIET_RING];   /* that launch ran with skip_env2 (a deferral it reports was NOT rendered) */
   int quiet_head, quiet_tail, quiet_pending;
+  uint32_t quiet_misses;      /* launches that ran without sk_render_env2_kernel although a slice needed it (self-check; must stay 0) */
   struct sk_queue_item *queue;  /* deferred updates (skred_bank_update.c), singly linked in arrival order */
   struct sk_queue_item *queue_tail;
   int queue_len;
@@ -94,6 +88,10 @@ struct skred_bank {
 #define SKC_EXOTIC 8u   /* needs the generic kernel: see classify() */
 #define SKC_FM    32u   /* carrier of a higher-indexed modulator of its 64-voice group, nothing else modulated */
 #define SKC_STOPS 16u   /* one-shot without loop (plays to its table end and finishes) or reverse playback: the one-per-lane kernel's extended instantiation */
+#define SKC_FUTURE 64u  /* uses the envelope and its sample_start / sample_release lay AHEAD of the bank's clock when written: its stage
+                           is not monotone (the unsigned clock difference wraps to "sustain" until the clock catches up, synth.c:401),
+                           so "no envelope in motion" may not be latched while such a voice exists */
+#define SKC_ESCAPES 128u /* names a modulator outside its aligned 64-voice group: the bank cannot be rendered until that is fixed */
 
 
 int skred_amd_set_error(int code, const char *fmt, ...);
@@ -110,15 +108,17 @@ int skred_amd_set_error(int code, const char *fmt, ...);
  * written.  phase_known: the host's voice_phase is the voice's current phase (an upload); 0 when only
  * parameters are being pushed and the phase lives on the device. */
 typedef struct {
-  uint8_t cls;          /* SKC_* */
+  uint8_t cls;          /* SKC_* (SKC_FUTURE as the HOST's envelope clocks say: only applied when those clocks travel) */
   int8_t mod_lane[4];   /* modulator lane inside the 64-voice group (fm, am, pan, cz) or -1 */
-  uint8_t escapes;      /* some modulator lies outside the voice's 64-voice group */
   uint32_t features;    /* SKB_* this voice needs */
+  uint64_t future_until;/* SKC_FUTURE: the later of the voice's two envelope clocks */
 } sk_voice_meta_t;
 
 int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int dst, int phase_known,
                   sk_plane_t ro[SKP_COUNT], sk_plane_t rw[SKS_COUNT], sk_voice_meta_t *meta);
-void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *meta);
+/* clock_travels: the voice's sample_start / sample_release were written too (upload, SKRED_DIRTY_ENV_CLOCK), so SKC_FUTURE
+ * follows the host's values; otherwise the bit the voice had is kept.  params_travel: everything else of `meta` applies. */
+void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *meta, int params_travel, int clock_travels);
 void sk_queue_free(skred_bank_t *b);
 /* a control action reached the bank: what earlier launches reported about envelope activity no longer holds */
 static inline void sk_control_changed(skred_bank_t *b) { b->control_epoch++; b->env_quiet = 0; }

@@ -90,6 +90,16 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
     if ((has_mod && !fm_only) || (!finite && !noise))        /* (a noise voice never runs its oscillator: synth.c:543-546) */
       c |= SKC_EXOTIC;
     if (fm_only) c |= SKC_FM;
+    {
+      /* a note-on or note-off stamped AHEAD of the clock (a host scheduling a note by writing sample_start itself): until
+       * the clock catches up the reference reads the wrapped difference as a huge elapsed time (synth.c:401,422) */
+      const skred_envelope_t *e = &h->voice_amp_envelope[v];
+      const uint64_t now = b->g.synth_sample_count;
+      if (h->voice_use_amp_envelope[v] && (e->sample_start > now || e->sample_release > now)) {
+        c |= SKC_FUTURE;
+        meta->future_until = e->sample_start > e->sample_release ? e->sample_start : e->sample_release;
+      }
+    }
     meta->cls = c;
   }
   meta->features = features;
@@ -121,7 +131,7 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
       int lane_k = -1;
       if (src[k] >= 0) {
         const int md = src[k] + (dst - v);
-        if (md < 0 || md >= b->n_voices || (md >> 6) != (dst >> 6)) meta->escapes = 1;
+        if (md < 0 || md >= b->n_voices || (md >> 6) != (dst >> 6)) meta->cls |= SKC_ESCAPES;
         else lane_k = md & 63;
       }
       meta->mod_lane[k] = (int8_t)lane_k;
@@ -143,19 +153,26 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
 }
 
 /* what voice `dst` now means for kernel selection (counters instead of a scan: a bank has up to millions of voices) */
-void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m) {
-  const uint8_t old = b->h_class[dst], now = m->cls;
+void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m, int params_travel, int clock_travels) {
+  const uint8_t old = b->h_class[dst];
+  uint8_t now = params_travel ? (uint8_t)(m->cls & ~SKC_FUTURE) : (uint8_t)(old & ~SKC_FUTURE);
+  now |= clock_travels ? (m->cls & SKC_FUTURE) : (old & SKC_FUTURE);
   if (old != now) {
     if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; if (old & SKC_STOPS) b->cnt_stops--; if (old & SKC_FM) b->cnt_fm--; }
     if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; if (now & SKC_STOPS) b->cnt_stops++; if (now & SKC_FM) b->cnt_fm++; }
+    /* per-voice bits that are not kernel classes: counted whether or not the voice can sound, and recounted whenever the
+     * voice is written again -- a routing that escaped its group stops blocking the bank once it is fixed */
+    b->cnt_escapes += ((now & SKC_ESCAPES) != 0) - ((old & SKC_ESCAPES) != 0);
+    b->cnt_future += ((now & SKC_FUTURE) != 0) - ((old & SKC_FUTURE) != 0);
+    if (now & SKC_FUTURE) { if (m->future_until > b->future_horizon) b->future_horizon = m->future_until; }
     b->h_class[dst] = now;
     b->class_dirty = 1;
   }
+  if (!params_travel) return;
   for (int k = 0; k < 4; k++) {
     int8_t *slot = &b->h_mod[(size_t)k * b->n_padded + dst];
     if (*slot != m->mod_lane[k]) { *slot = m->mod_lane[k]; b->mod_dirty = 1; b->class_dirty = 1; }
   }
-  if (m->escapes) b->mod_escapes = 1;
   if ((b->features | m->features) != b->features) { b->features |= m->features; b->class_dirty = 1; b->mod_dirty = 1; }
 }
 
@@ -166,7 +183,7 @@ typedef struct sk_queue_item {
   uint64_t when;
   int n;
   sk_update_t *rec;          /* device-format records */
-  sk_voice_meta_t *meta;     /* NULL unless the batch carries SKRED_DIRTY_PARAMS */
+  sk_voice_meta_t *meta;     /* NULL unless the batch carries SKRED_DIRTY_PARAMS or SKRED_DIRTY_ENV_CLOCK */
 } sk_queue_item_t;
 
 #define SK_STAMP_ONLY(d) (((d) & ~(uint32_t)(SKRED_STAMP_TRIGGER | SKRED_STAMP_RELEASE)) == 0)
@@ -177,8 +194,9 @@ static int build_batch(const skred_bank_t *b, const skred_voice_bank_t *h, const
   *meta_out = NULL;
   if ((dirty & ~(uint32_t)SKRED_DIRTY_VALID_MASK) || !dirty) return fail(SKRED_E_BAD_ARG, "update: dirty mask 0x%x", dirty);
   sk_update_t *rec = (sk_update_t *)calloc((size_t)n, sizeof(sk_update_t));
-  sk_voice_meta_t *meta = (dirty & SKRED_DIRTY_PARAMS) ? (sk_voice_meta_t *)calloc((size_t)n, sizeof(sk_voice_meta_t)) : NULL;
-  if (!rec || ((dirty & SKRED_DIRTY_PARAMS) && !meta)) { free(rec); free(meta); return fail(SKRED_E_NO_MEM, "update staging"); }
+  const int wants_meta = (dirty & (SKRED_DIRTY_PARAMS | SKRED_DIRTY_ENV_CLOCK)) != 0;
+  sk_voice_meta_t *meta = wants_meta ? (sk_voice_meta_t *)calloc((size_t)n, sizeof(sk_voice_meta_t)) : NULL;
+  if (!rec || (wants_meta && !meta)) { free(rec); free(meta); return fail(SKRED_E_NO_MEM, "update staging"); }
   const int stamp_only = SK_STAMP_ONLY(dirty);        /* note-on / note-off stamps carry no values: nothing to pack */
   for (int i = 0; i < n; i++) {
     const int v = voices[i];
@@ -261,7 +279,7 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
     start = end;
   }
   HIP_TRY(hipEventRecord(sl->ev, s));
-  if (meta) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i]);
+  if (meta) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i], (dirty & SKRED_DIRTY_PARAMS) != 0, (dirty & SKRED_DIRTY_ENV_CLOCK) != 0);
   sk_control_changed(b);
   return SKRED_OK;
 }

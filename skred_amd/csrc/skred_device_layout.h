@@ -140,6 +140,25 @@ typedef struct {
   uint32_t fast_mode;      /* SKM_* : which specialised kernel the host picked */
   uint32_t launch_ticket;  /* this launch's number (see group_flag) */
   uint32_t skip_env2;      /* host knows no group can be deferred: sk_render_env2_kernel is not launched */
+  /* ---- the block's mix-down, inside the last render kernel of the block (skred_kernel_common.hpp: sk_finish_block) ----
+   * Every workgroup leaves its partial-mix row in `partial`; with `finish` set the workgroup that arrives LAST at a
+   * ticket adds the rows up in a fixed order (slab by slab when there are many), writes the pre-master sum and, in
+   * the single-GPU form, applies the master volume -- one launch per block, no reduction kernels behind it. */
+  int32_t n_rows;          /* workgroups that render (rows of `partial`); the grid has wg_shift more */
+  int32_t wg_shift;        /* 1: workgroup 0 is the gain workgroup (walks the master-volume recurrence), renderers are blockIdx.x - 1 */
+  int32_t finish;          /* this kernel is the last one of the block that writes rows */
+  int32_t num_channels;    /* of mix_out */
+  float *slab_rows;        /* [SK_FINISH_SLABS][num_frames][2]: sums of the rows w = slab (mod SK_FINISH_SLABS), ascending */
+  float *sum_out;          /* [num_frames][2] pre-master sum of all rows (the operand of the multi-GPU reduce), or NULL */
+  float *mix_out;          /* [num_frames][num_channels] post-master output (channels 0, 1 written), or NULL */
+  float *gains;            /* [num_frames] master gain per frame (synth.c:616-620), written by the gain workgroup */
+  float *gain_state;       /* the smoother's carried gain: read before frame 0, written after the last frame */
+  uint32_t *tickets;       /* [SK_FINISH_SLABS + 1] arrival counters; the last arriver re-arms its counter to 0 */
+  float vol_target, vol_k; /* volume_final, volume_smoother_smoothing */
 } sk_render_args_t;
+
+#define SK_FINISH_SLABS 32     /* slabs of the two-level mix-down (a multiple of 8: the workgroups of a slab share an XCD's L2
+                                  under round-robin placement -- speed only) */
+#define SK_FINISH_FLAT_MAX 64  /* up to this many rows the last arriver adds the rows directly */
 
 #endif

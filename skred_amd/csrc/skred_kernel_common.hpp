@@ -71,6 +71,153 @@ __device__ __forceinline__ void wave_sum4_to_lane63(float &l0, float &r0, float 
 #undef SK_DPP4
 }
 
+// ---------------------------------------------------------------- the block's mix-down, in the render kernel
+//
+// Every workgroup of a render kernel owns one row of a.partial ([n_rows][F][2], pre-master).  Instead of reduction
+// kernels behind the render, the workgroup that ARRIVES LAST does the adding -- no workgroup ever waits for another,
+// so nothing here can spin or hang.  Many rows go in two levels: rows w = s (mod 32) form slab s, the last arriver
+// of a slab adds its rows (ascending w) into slab_rows[s]; the last slab to finish adds the slab rows (ascending s),
+// writes the pre-master sum and, when asked (single-GPU form), multiplies by the master gain of each frame.  The
+// order of the additions is fixed by the indices, not by who arrives when: the output is bit-reproducible.
+// The master gain (synth.c:616-620: vg += k * (target - vg) per frame, a serial float recurrence) is walked by one
+// extra workgroup (blockIdx.x == 0 when a.wg_shift) while the others render; it arrives at the last ticket too.
+//
+// Visibility follows the guide's write-through recipe (cdna_hip_programming.md, Guideline 16, R1): the bytes another
+// workgroup will read are stored WRITE-THROUGH (sc1: 8-byte agent-scope relaxed atomic stores), every storing wave
+// drains them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier and ONE lane adds to the ticket -- no release
+// fence, which would write back the XCD's whole L2 (full of voice-state lines here) once per workgroup.  The last
+// arriver acquires at agent scope (its CU's L1 lines dropped), drains, barrier, then plain loads.
+typedef __attribute__((address_space(1))) unsigned long long sk_gu64;
+typedef __attribute__((address_space(1))) unsigned int sk_gu32;
+__device__ __forceinline__ void sk_store_through(float2 *p, float2 v) {
+  const unsigned long long bits = ((unsigned long long)__float_as_uint(v.y) << 32) | (unsigned long long)__float_as_uint(v.x);
+  __hip_atomic_store((sk_gu64 *)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sk_store_through(float *p, float v) {
+  __hip_atomic_store((sk_gu32 *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every wave of the workgroup calls this after its write-through stores; true in the workgroup that arrived last.
+__device__ __forceinline__ bool sk_arrive_last(uint32_t *ticket, uint32_t expected, int tid, int *flag_lds) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's published bytes have left the CU
+  __syncthreads();                                            // (also: every wave is done with the LDS word used below)
+  if (tid == 0) {
+    const uint32_t before = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = before + 1u == expected;
+    if (last) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch (stream-ordered)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag_lds = last ? 1 : 0;
+  }
+  __syncthreads();
+  return *flag_lds != 0;
+}
+
+// One float of the workgroup's own row, at the end of a chunk: overwritten in the workgroup's first pass over the bank,
+// accumulated in later ones (plain accesses: this CU's own lines); in the pass that completes the row (`publish`) the
+// value leaves as a write-through store -- that is the copy another workgroup may read (sk_finish_block).
+__device__ __forceinline__ void sk_row_store(float *p, float s, bool first_pass, bool publish) {
+  const float v = first_pass ? s : *p + s;
+  if (publish) sk_store_through(p, v); else *p = v;
+}
+
+// Sum of `n` rows (`step` rows apart, starting at row `first`) for one column group, ascending, up to 16 loads in
+// flight: the rows sit behind the memory side (write-through stores drop them from the writers' L2), so what this
+// costs is round trips, not bytes.  V = float4 (two (L,R) columns) or float2.
+template <typename V> __device__ __forceinline__ void sk_acc(V &a, const V &t);
+template <> __device__ __forceinline__ void sk_acc<float4>(float4 &a, const float4 &t) { a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+template <> __device__ __forceinline__ void sk_acc<float2>(float2 &a, const float2 &t) { a.x += t.x; a.y += t.y; }
+template <typename V>
+__device__ __forceinline__ V sk_add_rows(const V *__restrict__ rows, size_t ncolv, int c, int first, int n, int step) {
+  V acc = rows[(size_t)first * ncolv + c];
+  int i = 1;
+  for (; i + 16 <= n; i += 16) {
+    V t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = rows[(size_t)(first + (i + k) * step) * ncolv + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sk_acc<V>(acc, t[k]);
+  }
+  if (i < n) {
+    V t[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) if (i + k < n) t[k] = rows[(size_t)(first + (i + k) * step) * ncolv + c];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) if (i + k < n) sk_acc<V>(acc, t[k]);
+  }
+  return acc;
+}
+
+// Called by EVERY workgroup of the block's last row-writing kernel, after its last store into a.partial (renderers:
+// bid = their row; the gain workgroup: bid < 0).  `published`: the row's final values already left as write-through
+// stores (sk_row_store in the completing pass); otherwise it is copied in place that way here.
+// `flag_lds`: one LDS word the workgroup no longer needs.
+template <typename V>
+__device__ __forceinline__ void sk_finish_cols(const sk_render_args_t &a, int bid, int tid, int nthreads, int *flag_lds, bool published) {
+  constexpr int PER = sizeof(V) / sizeof(float2);             // (L,R) columns per V
+  const size_t ncolv = (size_t)a.num_frames / PER;
+  const bool two_level = a.n_rows > SK_FINISH_FLAT_MAX;
+  const int n_last = two_level ? SK_FINISH_SLABS : a.n_rows;  // rows the last arriver adds
+  V *rows = reinterpret_cast<V *>(a.partial);
+  if (bid < 0) {
+    if (tid == 0) {                                           // the master gain of every frame, serially as the reference does
+      float vg = a.gain_state[0];
+      for (int i = 0; i < a.num_frames; ++i) {
+        vg += a.vol_k * (a.vol_target - vg);
+        sk_store_through(&a.gains[i], vg);
+      }
+      a.gain_state[0] = vg;                                   // (read by the next launch only)
+    }
+  } else {
+    if (!published) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      float2 *mine = reinterpret_cast<float2 *>(a.partial) + (size_t)bid * a.num_frames;
+      for (int c = tid; c < a.num_frames; c += nthreads) sk_store_through(&mine[c], mine[c]);
+    }
+    if (two_level) {
+      const int slab = bid % SK_FINISH_SLABS;
+      const int members = (a.n_rows - slab + SK_FINISH_SLABS - 1) / SK_FINISH_SLABS;
+      if (!sk_arrive_last(a.tickets + slab, (uint32_t)members, tid, flag_lds)) return;
+      float2 *dst = reinterpret_cast<float2 *>(a.slab_rows) + (size_t)slab * a.num_frames;
+      for (int c = tid; c < (int)ncolv; c += nthreads) {
+        const V s = sk_add_rows<V>(rows, ncolv, c, slab, members, SK_FINISH_SLABS);
+        const float2 *h = reinterpret_cast<const float2 *>(&s);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) sk_store_through(&dst[(size_t)c * PER + k], h[k]);
+      }
+    }
+  }
+  const uint32_t arrivals = (uint32_t)n_last + (a.wg_shift ? 1u : 0u);
+  if (!sk_arrive_last(a.tickets + SK_FINISH_SLABS, arrivals, tid, flag_lds)) return;
+  if (two_level) rows = reinterpret_cast<V *>(a.slab_rows);
+  for (int c = tid; c < (int)ncolv; c += nthreads) {
+    const V s = sk_add_rows<V>(rows, ncolv, c, 0, n_last, 1);
+    const float2 *h = reinterpret_cast<const float2 *>(&s);
+    if (a.sum_out) reinterpret_cast<V *>(a.sum_out)[c] = s;
+    if (a.mix_out) {                                          // synth.c:621-624
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const size_t f = (size_t)c * PER + k;
+        const float vg = a.gains[f];
+        a.mix_out[f * a.num_channels + 0] = h[k].x * vg;
+        a.mix_out[f * a.num_channels + 1] = h[k].y * vg;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void sk_finish_block(const sk_render_args_t &a, int bid, int tid, int nthreads, int *flag_lds,
+                                                bool published = false) {
+  // two columns per load when the rows (num_frames * 8 bytes each) and sum_out keep 16-byte alignment
+  if ((a.num_frames & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.sum_out) & 15) == 0))
+    sk_finish_cols<float4>(a, bid, tid, nthreads, flag_lds, published);
+  else
+    sk_finish_cols<float2>(a, bid, tid, nthreads, flag_lds, published);
+}
+
 // ---------------------------------------------------------------- small exact helpers
 
 // fmodf for x >= 0, y > 0, exact.  x - y is exact for y <= x < 2y (Sterbenz), which is the

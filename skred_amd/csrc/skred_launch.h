@@ -5,7 +5,7 @@
  *   skred_render_generic.hip  sk_launch_render (dispatcher), sk_launch_render_mod
  *   skred_render_fast.hip     sk_launch_render_fast
  *   skred_render_fast2.hip    sk_launch_render_fast2
- *   skred_mix_kernels.hip     sk_launch_reduce, sk_reduce_tmp_floats, sk_launch_master, sk_launch_reduce_master
+ *   skred_mix_kernels.hip     sk_launch_master
  *   skred_update_kernels.hip  sk_launch_update
  *   skred_rec_kernels.hip     sk_launch_rec_minmax, sk_rec_partial_floats, sk_launch_rec_convert
  *
@@ -36,12 +36,6 @@ int sk_launch_render_mod(const sk_render_args_t *args, int n_workgroups, const i
 int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 
-/* partial[W][ncols] -> out[ncols], fixed order; `tmp` holds sk_reduce_tmp_floats(ncols) floats */
-int sk_launch_reduce(const float *partial, float *tmp, float *out, int W, int ncols, hipStream_t stream);
-int sk_reduce_tmp_floats(int ncols);
-/* single-GPU: partial[W][2F] -> out[F][channels], last reduction stage fused with the master stage */
-int sk_launch_reduce_master(const float *partial, float *tmp, int W, float *out, int num_frames, int num_channels,
-                            float target, float k, const float *gain_in, float *gain_out, hipStream_t stream);
 int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels, float target, float k,
                      float *gain_state, hipStream_t stream);
 

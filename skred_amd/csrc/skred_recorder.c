@@ -112,6 +112,9 @@ static int convert_on_device(skred_recorder_t *r, const int *record, int *n_sel_
   *n_sel_out = n_sel;
   if (n_sel == 0 || r->frames == 0) { free(sel); return SKRED_OK; }
   hipError_t e = hipSetDevice(r->device);
+  /* the appends (and the renders that produced the stems) were queued on the caller's stream, which may be
+   * non-blocking: nothing else orders the two passes below, on the null stream, behind them */
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(r->d_sel, sel, (size_t)n_sel * sizeof(int), hipMemcpyHostToDevice);
   free(sel);
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "selection upload -> %s", hipGetErrorString(e));

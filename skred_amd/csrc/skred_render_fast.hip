@@ -485,6 +485,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
   float2 *xp = reinterpret_cast<float2 *>(win);       // LDS-table banks: the same per-wave region holds the
   float2 *xq = xp + 8 * 65;                            // transposition tiles of SK_FAST_LDS_BLOCK (8*65 + 64 float2 <= SK_WIN*64 floats)
   (void)win; (void)xp; (void)xq;
+  const int bid = (int)blockIdx.x - a.wg_shift;        // row of the partial mix; -1: the gain workgroup (sk_finish_block)
+  if (bid < 0) { sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds)); return; }
 
   if (TAB_LDS) {
     const int n4 = a.lds_table_floats >> 2;           // padded to a multiple of 4 by the host
@@ -494,12 +496,13 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     __syncthreads();
   }
 
-  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;
+  const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;
   bool first_pass = true;
   const bool stems_on = a.stems != nullptr;          // (launch-uniform: one scalar branch per frame)
 
-  for (int g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+  for (int g = bid; g < a.n_groups; g += a.n_rows) {
     const int v = g * SK_GROUP + tid;
+    const bool publish = a.finish && g + a.n_rows >= a.n_groups;   // the pass that completes this workgroup's row
     FastRegs r;
     bool dead, silent;            // dead: skipped by synth.c:531-542; silent: dead or muted
     bool muted = false;           // voice_disconnect
@@ -703,8 +706,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         s += w[1 * 2 * SK_CHUNK + tid];
         s += w[2 * 2 * SK_CHUNK + tid];
         s += w[3 * 2 * SK_CHUNK + tid];
-        float *p = a.partial + part_base + (size_t)c0 * 2 + tid;
-        if (first_pass) *p = s; else *p += s;
+        sk_row_store(a.partial + part_base + (size_t)c0 * 2 + tid, s, first_pass, publish);
       }
       __syncthreads();
     }
@@ -728,6 +730,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = make_uint4(misc_xy.x, misc_xy.y, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r));
     first_pass = false;
   }
+  if (a.finish) sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds), true);
 }
 
 // ---------------------------------------------------------------- launcher (C linkage)
@@ -737,7 +740,7 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
                                      hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
   lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);   // per wave: one table window, or the reduction tiles of SK_FAST_LDS_BLOCK
-  dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
+  dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block(SK_GROUP);
   const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
 #define SK_FAST_CASE(K, T, F, E, I)                                                                                        \

@@ -427,7 +427,8 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
                 if (j < cn) SK_FAST2_ONE(j, EM_, false) }                       \
   }
 #endif
-// wave sums of the chunk -> this workgroup's partial-mix row (ACCUM_: add to what is there).  wsum is double
+// wave sums of the chunk -> this workgroup's partial-mix row (ACCUM_: add to what is there; `publish`, a bool in scope:
+// this pass completes the row, so the values leave as write-through stores -- sk_row_store).  wsum is double
 // buffered: the waves go on writing the next chunk into the other half while the first 2*cn threads drain this
 // one, so one barrier per chunk is enough (a wave can only reach the half being drained after the NEXT barrier,
 // which the draining threads reach after their reads).
@@ -437,8 +438,7 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
     const float *w_ = reinterpret_cast<const float *>(wsum);                    \
     float s_ = w_[0 * 2 * SK_CHUNK + tid];                                      \
     _Pragma("unroll") for (int w2_ = 1; w2_ < NW; ++w2_) s_ += w_[w2_ * 2 * SK_CHUNK + tid]; \
-    float *p_ = a.partial + part_base + (size_t)c0 * 2 + tid;                   \
-    if (ACCUM_) *p_ += s_; else *p_ = s_;                                       \
+    sk_row_store(a.partial + part_base + (size_t)c0 * 2 + tid, s_, !(ACCUM_), publish);   \
   }                                                                             \
   wsum = (wsum == wsum0) ? wsum0 + NW * SK_CHUNK : wsum0;
 
@@ -560,6 +560,8 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
   /* global-table banks: the same LDS holds the wave's table windows instead (2 voices x SK_WIN x 64 lanes) */ \
   float *win = reinterpret_cast<float *>(wsum0 + 2 * NW * SK_CHUNK) + wave * (2 * SK_WIN * 64);      \
   (void)xp; (void)xq; (void)win;                                                                     \
+  const int bid = (int)blockIdx.x - a.wg_shift;   /* row of the partial mix; -1: the gain workgroup */ \
+  if (bid < 0) { sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds)); return; }      \
   if (TAB_LDS) {                                                                                     \
     const int n4 = a.lds_table_floats >> 2;                                                          \
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);                                 \
@@ -567,7 +569,7 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
     for (int i = tid; i < n4; i += NW * 64) dst4[i] = src4[i];                                       \
     __syncthreads();                                                                                 \
   }                                                                                                  \
-  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;                            \
+  const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;                                   \
   const int n_groups2 = a.n_groups >> 1;   /* 512-voice groups: one pass of sk_render_env2_kernel */ \
   const int n_pass = (a.n_groups * SK_GROUP) / (NW * 128);   /* workgroup passes over the (padded) bank */ \
   const int n_flags = a.n_groups * 2;      /* one hand-over flag per 128-voice wave slice; [n_flags] = the ticket slot */
@@ -589,7 +591,9 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
   SK_FAST2_PROLOGUE()
   (void)n_groups2; (void)n_flags;
   bool first_pass = true;
-  for (int g = blockIdx.x; g < n_pass; g += gridDim.x) {
+  bool row_published = false;
+  for (int g = bid; g < n_pass; g += a.n_rows) {
+    const bool publish = a.finish && g + a.n_rows >= n_pass;      // the pass that completes this workgroup's row
     Fast2Regs r;
     Env2Regs e;
     bool dead[2], silent[2], released[2];
@@ -634,10 +638,14 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     }
     if (wave_ok) fast2_store<MIXED>(a, r, dead, vidx);
     first_pass = false;
+    row_published = publish;
   }
   if (first_pass) {   // every group of this workgroup was deferred: its partial-mix row must still exist
     for (int i = tid; i < 2 * a.num_frames; i += NW * 64) a.partial[part_base + i] = 0.0f;
   }
+  // (row_published is false when the completing pass was skipped as a whole -- every wave deferred: the row is then
+  // copied out by sk_finish_block)
+  if (a.finish) sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds), row_published);
 }
 
 // Groups with envelopes in motion (flagged by sk_render_fast2_kernel, which ran just before on the stream).
@@ -652,7 +660,8 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
   // the slices sk_render_fast2_kernel left to this kernel, compacted in ascending order (sk_compact_flags_kernel): every
   // workgroup pass takes four of them, so the launch costs what the flagged share of the bank costs
   const int n_mine = a.env_list[n_flags];
-  for (int g = blockIdx.x; g * 4 < n_mine; g += gridDim.x) {
+  constexpr bool publish = false;   // (a workgroup of this kernel may have no pass at all: sk_finish_block copies every row out)
+  for (int g = bid; g * 4 < n_mine; g += a.n_rows) {
     const bool mine = g * 4 + wave < n_mine;
     const int slice = mine ? a.env_list[g * 4 + wave] : 0;
     Fast2Regs r;
@@ -741,6 +750,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
     }
     if (mine) fast2_store<MIXED>(a, r, dead, vidx);
   }
+  if (a.finish) sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds));
 }
 
 // ---------------------------------------------------------------- launcher (C linkage)
@@ -777,23 +787,29 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
   const int nw = tab_lds ? Fast2Shape<true>::NW : Fast2Shape<false>::NW;
   const size_t lds_fast2 = tab_bytes + (size_t)nw * (2 * SK_CHUNK * sizeof(float2) + per_wave);
   const size_t lds_env2 = tab_bytes + (size_t)4 * (2 * SK_CHUNK * sizeof(float2) + per_wave);
-  dim3 grid((unsigned)n_workgroups), block((unsigned)nw * 64), block_env(SK_GROUP);
+  dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block((unsigned)nw * 64), block_env(SK_GROUP);
+  // the block's mix-down (sk_finish_block) belongs to the LAST kernel that writes rows: sk_render_env2_kernel when it
+  // runs (it adds into the rows sk_render_fast2_kernel left), else sk_render_fast2_kernel itself
+  sk_render_args_t first = *args, second = *args;
+  const bool env_follows = (args->fast_mode & SKM_ENV_ALL) && !args->skip_env2;
+  if (env_follows) { first.finish = 0; first.wg_shift = 0; }
+  dim3 grid_first((unsigned)(n_workgroups + first.wg_shift));
   const bool mixed = (args->fast_mode & SKM_MIXED) != 0;     // filter / envelope on some voices only: per-lane flags
   const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
     if (mixed) {                                                                                        \
-      hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, true>), grid, block, lds_fast2, stream, *args);  \
+      hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, true>), grid_first, block, lds_fast2, stream, first);  \
       if (E && !args->skip_env2) {                                                                      \
         hipLaunchKernelGGL(sk_compact_flags_kernel, dim3(1), dim3(256), 0, stream, args->group_flag, args->n_groups * 2, args->env_list); \
-        hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, true>), grid, block_env, lds_env2, stream, *args); \
+        hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, true>), grid, block_env, lds_env2, stream, second); \
       }                                                                                                 \
     } else {                                                                                            \
-      hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, false>), grid, block, lds_fast2, stream, *args); \
+      hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, false>), grid_first, block, lds_fast2, stream, first); \
       if (E && !args->skip_env2) {                                                                      \
         hipLaunchKernelGGL(sk_compact_flags_kernel, dim3(1), dim3(256), 0, stream, args->group_flag, args->n_groups * 2, args->env_list); \
-        hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, false>), grid, block_env, lds_env2, stream, *args); \
+        hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, false>), grid, block_env, lds_env2, stream, second); \
       }                                                                                                 \
     }                                                                                                   \
     break;

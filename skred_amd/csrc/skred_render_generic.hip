@@ -38,6 +38,8 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_kernel(const sk_render_arg
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int bid = (int)blockIdx.x - a.wg_shift;             // this workgroup's row of the partial mix; -1: the gain workgroup
+  if (bid < 0) { sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds)); return; }
 
   if (TAB_LDS) {
     // stage the whole pool; float4 when aligned, coalesced
@@ -49,11 +51,12 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_kernel(const sk_render_arg
     __syncthreads();
   }
 
-  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;
+  const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;
   bool first_pass = true;
 
-  for (int g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+  for (int g = bid; g < a.n_groups; g += a.n_rows) {
     const int v = g * SK_GROUP + tid;
+    const bool publish = a.finish && g + a.n_rows >= a.n_groups;   // the pass that completes this workgroup's row
     VoiceRegs r;
     load_voice(a, v, r);
 
@@ -86,14 +89,14 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_kernel(const sk_render_arg
         s += w[1 * 2 * SK_CHUNK + tid];
         s += w[2 * 2 * SK_CHUNK + tid];
         s += w[3 * 2 * SK_CHUNK + tid];
-        float *p = a.partial + part_base + (size_t)c0 * 2 + tid;
-        if (first_pass) *p = s; else *p += s;
+        sk_row_store(a.partial + part_base + (size_t)c0 * 2 + tid, s, first_pass, publish);
       }
       __syncthreads();
     }
     store_voice(a, v, r);
     first_pass = false;
   }
+  if (a.finish) sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds), true);
 }
 
 // ---------------------------------------------------------------- modulated banks
@@ -282,6 +285,8 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float *xch0 = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * 192;               // wave-private: xch[2][64], incs[64]
   float *incs = xch0 + 128;
+  const int bid = (int)blockIdx.x - a.wg_shift;        // row of the partial mix; -1: the gain workgroup (sk_finish_block)
+  if (bid < 0) { sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds)); return; }
   if (TAB_LDS) {
     const int n4 = a.lds_table_floats >> 2;
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);
@@ -289,11 +294,12 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render
     for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];
     __syncthreads();
   }
-  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;
+  const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;
   const int n_pass = a.n_groups;                       // passes of 256 voices = 4 groups of 64
   bool first_pass = true;
-  for (int g = blockIdx.x; g < n_pass; g += gridDim.x) {
+  for (int g = bid; g < n_pass; g += a.n_rows) {
     const int v = g * SK_GROUP + tid;
+    const bool publish = a.finish && g + a.n_rows >= n_pass;       // the pass that completes this workgroup's row
     VoiceRegs r;
     load_voice(a, v, r);
     ModRegs m;
@@ -352,14 +358,14 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render
         s += w[1 * 2 * SK_CHUNK + tid];
         s += w[2 * 2 * SK_CHUNK + tid];
         s += w[3 * 2 * SK_CHUNK + tid];
-        float *p = a.partial + part_base + (size_t)c0 * 2 + tid;
-        if (first_pass) *p = s; else *p += s;
+        sk_row_store(a.partial + part_base + (size_t)c0 * 2 + tid, s, first_pass, publish);
       }
       __syncthreads();
     }
     store_voice(a, v, r);
     first_pass = false;
   }
+  if (a.finish) sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds), true);
 }
 // ---------------------------------------------------------------- launchers (C linkage)
 
@@ -372,7 +378,7 @@ extern "C" int sk_launch_render(const sk_render_args_t *args, int n_workgroups, 
   if ((args->fast_mode & SKM_FAST) && (!stems || !(args->fast_mode & SKM_TWO_PER_LANE)))   // (stems: the one-voice kernel has them)
     return (args->fast_mode & SKM_TWO_PER_LANE) ? sk_launch_render_fast2(args, n_workgroups, lds_bytes, stream)
                                                 : sk_launch_render_fast(args, n_workgroups, lds_bytes, stream);
-  dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
+  dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block(SK_GROUP);
   if (tab_lds) {
     if (stems) hipLaunchKernelGGL((sk_render_kernel<true, true>), grid, block, lds_bytes, stream, *args);
     else       hipLaunchKernelGGL((sk_render_kernel<true, false>), grid, block, lds_bytes, stream, *args);
@@ -388,7 +394,7 @@ extern "C" int sk_launch_render_mod(const sk_render_args_t *args, int n_workgrou
   const bool tab_lds = args->lds_table_floats > 0;
   const size_t lds_bytes = (size_t)(tab_lds ? args->lds_table_floats : 0) * sizeof(float) +
                            (size_t)4 * SK_CHUNK * sizeof(float2) + (size_t)4 * 192 * sizeof(float);
-  dim3 grid((unsigned)n_workgroups), block(SK_GROUP);
+  dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block(SK_GROUP);
 #define SK_MOD_LAUNCH(T, S) hipLaunchKernelGGL((sk_render_mod_kernel<T, S>), grid, block, lds_bytes, stream, *args, levels, max_level)
   if (tab_lds) { if (args->stems) SK_MOD_LAUNCH(true, true); else SK_MOD_LAUNCH(true, false); }
   else         { if (args->stems) SK_MOD_LAUNCH(false, true); else SK_MOD_LAUNCH(false, false); }

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "skred_bank_set_globals", "skred_bank_get_globals",
     "skred_bank_render", "skred_bank_master", "skred_bank_render_mix", "skred_bank_wait_mix", "skred_bank_render_host",
     "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
-    "skred_bank_set_option", "skred_bank_last_kernel",
+    "skred_bank_set_option", "skred_bank_last_kernel", "skred_bank_env_latch_misses",
     "skred_bank_update", "skred_bank_defer", "skred_bank_run_queue", "skred_bank_queue_pending",
 ]
 
@@ -79,6 +79,8 @@ def load() -> C.CDLL:
     L.skred_bank_last_render_ms.restype = C.c_float
     L.skred_bank_set_option.argtypes = [vp, i32, i32]
     L.skred_bank_last_kernel.argtypes = [vp]
+    L.skred_bank_env_latch_misses.argtypes = [vp]
+    L.skred_bank_env_latch_misses.restype = C.c_uint
     L.skred_bank_timing_reset.argtypes = [vp]
     L.skred_bank_timing_reset.restype = None
     L.skred_bank_timing_summary.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]
@@ -146,12 +148,12 @@ class DeviceBank:
                "skred_bank_render")
 
     def render_mix(self, frames: int, d_out: int, channels: int = 2, d_stems: int = 0, interp: int = 0, stream: int = 0):
-        """Single-GPU render + master with the last reduction stage fused into the master kernel."""
+        """Single-GPU render + mix-down + master volume: one launch."""
         _check(self.L.skred_bank_render_mix(self.h, frames, interp, d_out, channels, d_stems, stream),
                "skred_bank_render_mix")
 
     def overlap_tail(self, on: bool = True):
-        """SKRED_OPT_OVERLAP_TAIL: render_mix queues the block's reduction + master on an internal stream."""
+        """SKRED_OPT_OVERLAP_TAIL: accepted and ignored (a block is one launch; nothing is left to overlap)."""
         _check(self.L.skred_bank_set_option(self.h, 3, 1 if on else 0), "skred_bank_set_option")
 
     def kernel_timing(self, every: int = 1):
@@ -203,6 +205,10 @@ class DeviceBank:
     def last_kernel(self) -> int:
         """0 = generic kernel, 1 = specialised fast kernel (SKRED_KERNEL_*)."""
         return int(self.L.skred_bank_last_kernel(self.h))
+
+    def env_latch_misses(self) -> int:
+        """Launches that skipped the envelope kernel although a slice needed it (self-check; must be 0)."""
+        return int(self.L.skred_bank_env_latch_misses(self.h))
 
     def last_render_ms(self) -> float:
         return float(self.L.skred_bank_last_render_ms(self.h))

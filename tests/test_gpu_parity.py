@@ -81,6 +81,8 @@ def test_golden_case(dev, case):
     ("c4", 20000, 512, 0),        # PCM pool too large for LDS -> L2/HBM gather path
     ("c4", 20000, 512, 1),        # linear interpolation (defined by cpu_ref, unpinned upstream)
     ("c2", 4096, 512, 1),
+    ("c4", 262144, 512, 1),       # BASELINE config 4 at the size bench.py times it (linear: unpinned upstream)
+    ("c4", 262144, 512, 0),       # ... and with the reference's truncating lookup
 ])
 def test_synthetic_bank_vs_oracle(dev, recipe, n, frames, interp):
     """Seeded BASELINE banks at (or near) full size against the oracle on identical inputs."""
@@ -173,7 +175,7 @@ def test_256_voices_against_four_reference_runs(dev):
 
 
 def test_fused_mix_equals_render_plus_master(dev):
-    """skred_bank_render_mix (last reduction stage fused into the master kernel) against skred_bank_render +
+    """skred_bank_render_mix (mix-down and master stage inside the render kernel) against skred_bank_render +
     skred_bank_master on the same bank: same samples, bit for bit, for small and large workgroup counts."""
     import torch
     for n, frames in ((300, 77), (40000, 512), (300000, 1500)):
@@ -199,8 +201,8 @@ def test_fused_mix_equals_render_plus_master(dev):
 
 
 def test_overlapped_tail_gives_the_same_blocks(dev):
-    """SKRED_OPT_OVERLAP_TAIL: the reduction + master stage of block k runs on an internal stream while block k+1
-    renders.  Six consecutive blocks, each into its own buffer: same bytes as the in-order path."""
+    """Six consecutive asynchronous blocks, each into its own buffer, with and without SKRED_OPT_OVERLAP_TAIL (an option
+    of the earlier two-stream form, still accepted: a block is one launch now): same bytes, same state."""
     import torch
     n, frames, blocks = 70000, 300, 6
     bank, tables, g = banks.bank_c2(n)
@@ -776,6 +778,123 @@ def test_two_per_lane_kernel_matches_oracle(dev, recipe, interp):
     assert kernels == [3] * len(segs), kernels
     assert not host.rw_equal(ref_state), host.rw_equal(ref_state)
     assert rel_rms(np.concatenate(mixes), ref_mix) <= 1e-5
+
+
+@pytest.mark.parametrize("recipe,interp,fast2", [("c2", 0, True), ("c2", 0, False), ("c1", 1, True), ("c4", 1, True), ("c4", 1, False)])
+def test_envelope_ramps_segment_by_segment(dev, recipe, interp, fast2):
+    """The envelope ramps of the block paths (sk_render_env2_kernel's refined-reciprocal ramp e = C*(A + B*q) in place
+    of the reference's per-sample divisions, and the one-voice kernel's clock-as-float path) checked where a slip
+    would show: the read-write state of every voice -- voice_smoother_gain follows the envelope within a few frames --
+    is downloaded and compared bit for bit with the oracle after EVERY one of 48 short ragged segments (7..97 frames)
+    that walk through attack, decay, sustain, note-off, release and its end, with re-triggers in between."""
+    n = 5200
+    bank, tables, g = banks.RECIPES[recipe](n)
+    e = bank["voice_amp_envelope"]
+    now0 = g.synth_sample_count
+    # short, different stage lengths per voice so that every segment catches voices in every stage, and stage changes
+    # fall inside 8-frame blocks as well as on their edges; all notes start within the last 40 frames
+    v = np.arange(n)
+    e["attack_time"][:] = (3.0 + (v % 89) * 1.37).astype(np.float32)
+    e["decay_time"][:] = (5.0 + (v % 61) * 2.11).astype(np.float32)
+    e["release_time"][:] = (11.0 + (v % 131) * 3.3).astype(np.float32)
+    e["sustain_level"][:] = (0.15 + 0.8 * ((v * 7) % 19) / 19.0).astype(np.float32)
+    e["sample_start"][:] = (now0 - (v % 40)).astype(np.uint64)
+    e["sample_release"][:] = 0
+    e["is_active"][:] = 1
+    e["attack_time"][::53] = 0.0                      # no attack at all
+    e["decay_time"][3::59] = 0.0                      # ... no decay
+    e["release_time"][5::67] = 0.0                    # release that ends at once
+    bank["voice_disconnect"][::7] = 1
+    bank["voice_amp"][::11] = 0.0
+    lengths = [7 + (k * 37) % 91 for k in range(48)]
+    assert min(lengths) >= 7 and max(lengths) <= 97
+
+    def event_for(k):
+        if k == 9:
+            return _release_odd_voices
+        if k == 20:
+            def retrigger(host, now):                 # == amp_envelope_trigger (synth.c:383-388) on a third of the bank
+                ev = host["voice_amp_envelope"]
+                ev["sample_start"][::3] = now
+                ev["sample_release"][::3] = 0
+                ev["is_active"][::3] = 1
+            return retrigger
+        if k == 30:
+            def release_all(host, now):
+                ev = host["voice_amp_envelope"]
+                live = ev["is_active"] != 0
+                ev["sample_release"][live] = now
+            return release_all
+        return None
+
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    host = bank.copy()
+    db.upload(host)
+    db.set_globals(g)
+    db.fast2_min_voices(0 if fast2 else 1 << 30)
+    ref_host, ref_g = bank.copy(), g.copy()
+    mixes, ref_mixes = [], []
+    for k, frames in enumerate(lengths):
+        ev = event_for(k)
+        if ev is not None:
+            db.download(host)
+            ev(host, db.get_globals().synth_sample_count)
+            db.upload(host)
+            ev(ref_host, ref_g.synth_sample_count)
+        mixes.append(db.render_host(frames, 2, interp)[0])
+        assert db.last_kernel() == (3 if fast2 else 1)
+        r = cpuref.render(ref_host, ref_g, tables, frames, interp)
+        ref_mixes.append(cpuref.master(ref_g, r["sum64"].astype(np.float32)))
+        db.download(host)
+        bad = host.rw_equal(ref_host)
+        assert not bad, f"segment {k} ({frames} frames): state differs from the oracle: {bad}"
+    assert db.env_latch_misses() == 0
+    db.close()
+    act = ref_host["voice_amp_envelope"]["is_active"]
+    assert int((act == 0).sum()) > n // 2                    # the releases did run out
+    assert rel_rms(np.concatenate(mixes), np.concatenate(ref_mixes)) <= 1e-5
+
+
+def test_note_on_ahead_of_the_clock_is_not_lost_by_the_envelope_latch(dev):
+    """A host that schedules a note by writing sample_start AHEAD of the clock: the reference reads the wrapped clock
+    difference as a huge elapsed time (sustain) until the clock catches up, then the attack starts (synth.c:401) -- the
+    one way an envelope changes stage on its own in mid-launch.  The specialised kernels decide the stage per launch or per
+    chunk, and the two-per-lane path stops launching sk_render_env2_kernel once a launch deferred no slice, so a bank
+    with such voices is rendered by the generic kernel (integer clocks, every frame) until the clock has passed them, and
+    goes back to the specialised ones afterwards.  Against the oracle, block by block, through the attacks' start."""
+    n = 6000
+    bank, tables, g = banks.bank_c2(n)
+    e = bank["voice_amp_envelope"]
+    now0 = g.synth_sample_count
+    e["sample_start"][:] = np.uint64(now0 - 20000)            # everyone long in sustain ...
+    e["sample_release"][:] = 0
+    e["is_active"][:] = 1
+    late = np.arange(17, n, 97)
+    e["sample_start"][late] = (now0 + 2500 + (late % 7) * 300).astype(np.uint64)     # ... but these start 5-9 blocks from now
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    host = bank.copy()
+    db.upload(host)
+    db.set_globals(g)
+    db.fast2_min_voices(0)
+    ref_host, ref_g = bank.copy(), g.copy()
+    import torch
+    out = torch.zeros(512, 2, device="cuda")
+    kernels = []
+    for k in range(14):
+        db.render_mix(512, out.data_ptr(), 2, 0, 0)           # asynchronous blocks: the way the latch gets its answers
+        kernels.append(db.last_kernel())
+        torch.cuda.synchronize()
+        r = cpuref.render(ref_host, ref_g, tables, 512, 0)
+        ref_mix = cpuref.master(ref_g, r["sum64"].astype(np.float32))
+        assert rel_rms(out.cpu().numpy(), ref_mix) <= 1e-5, f"block {k}"
+    db.download(host)
+    assert db.env_latch_misses() == 0
+    db.close()
+    assert not host.rw_equal(ref_host), host.rw_equal(ref_host)
+    # the latest note-on is at now0 + 2500 + 6*300 = block 8: generic up to there, two per lane from the next block on
+    assert kernels[:9] == [0] * 9 and kernels[9:] == [3] * 5, kernels
 
 
 @pytest.mark.parametrize("interp,fast2", [(0, True), (1, True), (0, False), (1, False)])

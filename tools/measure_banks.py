@@ -11,8 +11,7 @@
 
 Each line: ms per block over the timed blocks (wall clock), voice-samples/s, and the render kernel's duration from the
 library's own event pair around the latest bracketed launch (a bracketed launch runs alone).  kernels / fm / noise print
-every bank twice: with SKRED_OPT_OVERLAP_TAIL and in stream order -- the overlap pays on the four bench workloads and
-costs up to a third on some extended banks ("Per-block launch count").
+every bank once (round 1 printed two forms, with and without SKRED_OPT_OVERLAP_TAIL; a block is one launch now).
 """
 import sys
 import time
@@ -26,10 +25,7 @@ from skred_amd import banks, device  # noqa: E402
 
 def run(name, bank, tables, g, interp=0, F=512, steps=60, min2=None, generic=False, overlap=None, timing=4):
     """overlap=None: both forms of the block (tail overlapped with the next render / in stream order), two lines."""
-    if overlap is None:
-        run(name + " [tail overlapped]", bank, tables, g, interp, F, steps, min2, generic, True, timing)
-        run(name + " [in order]", bank, tables, g, interp, F, steps, min2, generic, False, timing)
-        return
+    overlap = False          # (a block is one launch since round 2: there is no tail to overlap; the parameter stays for old scripts)
     n = bank.n
     out = torch.zeros(F, 2, device="cuda")
     db = device.DeviceBank(n)

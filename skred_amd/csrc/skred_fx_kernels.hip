@@ -9,7 +9,7 @@
 
 #include "skred_fx_layout.h"
 
-// integer wave sum of two values into lane 63 (see skred_kernel_common.hpp: wave_sum2_to_lane63)
+// integer wave sum of two values into lane 63 (the float kernels fold L/R first: skred_kernel_common.hpp)
 __device__ __forceinline__ void wave_isum2_to_lane63(int &l, int &r) {
   asm volatile(
       "s_nop 1\n\t"

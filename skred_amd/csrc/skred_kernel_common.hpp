@@ -15,60 +15,69 @@
 #define LCG_A 6364136223846793005ULL
 #define LCG_C 1442695040888963407ULL
 
-// ---------------------------------------------------------------- wave reduction (DPP)
+// ---------------------------------------------------------------- wave reduction (fold L/R, then DPP)
 //
-// Sum over the 64 lanes of a wavefront, total in lane 63, fixed association order:
-//   quad_perm [1,0,3,2]; quad_perm [2,3,0,1]; row_half_mirror; row_mirror (every lane now holds its
-//   16-lane row sum); row_bcast:15 into rows 1,3; row_bcast:31 into rows 2,3.
+// Per frame every lane holds its voice's (L, R).  v_permlane32_swap exchanges the upper half of one register with
+// the lower half of another, so ONE swap + ONE add leave, in a single register, L pair sums (lane i + lane i+32) in
+// lanes 0..31 and R pair sums in lanes 32..63.  From there one 5-step DPP butterfly over 32 lanes
+//   quad_perm [1,0,3,2]; quad_perm [2,3,0,1]; row_half_mirror; row_mirror (every lane now holds its 16-lane row
+//   sum); row_bcast:15 into rows 1 and 3
+// sums both channels at once: the frame's L total ends in lane 31, its R total in lane 63 -- 7 VALU instructions per
+// frame where two separate 6-step butterflies took 12.  Fixed association order: bit-reproducible run to run.
 //
-// The same two reductions (L and R) as 12 v_add_f32 with the lane permutation folded into the
-// add's DPP operand.  Written as one asm block because hipcc otherwise SLP-packs L/R into
-// v_pk_add_f32, which cannot take a DPP operand, and then spends 5 instructions per stage
-// (2 x v_mov 0, 2 x v_mov_dpp, v_pk_add) = 30 per frame.  The two chains are interleaved and padded
-// with s_nop so that every DPP read sits >= 2 wait states behind the VALU write of its source
-// (hipcc pads nothing inside an asm statement).  Rows masked off by row_mask keep their value.
-__device__ __forceinline__ void wave_sum2_to_lane63(float &l, float &r) {
+// The butterflies are asm: every DPP read must sit >= 2 wait states behind the VALU write of its source and hipcc pads
+// nothing inside an asm statement, so single chains are spaced with s_nop 1 and the two-chain form interleaves
+// (s_nop 0 between stages).  Rows masked off by row_mask keep their value.
+__device__ __forceinline__ float fold_lr(float l, float r) {
+  const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(r), false, false);
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);      // lanes 0..31: l[i] + l[i+32]; lanes 32..63: r[i-32] + r[i]
+}
+
+// x: folded value of one frame; afterwards lane 31 holds the L total, lane 63 the R total
+__device__ __forceinline__ void half_sum_to_lanes_31_63(float &x) {
   asm volatile(
       "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
+      "s_nop 1\n\t"
       "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 0\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
       "s_nop 1"
-      : "+v"(l), "+v"(r));
+      : "+v"(x));
 }
 
-// Two frames at once: four independent chains (L0, R0, L1, R1), so every DPP read already sits three
-// instructions behind the write of its source and no s_nop padding is needed between the stages.
-__device__ __forceinline__ void wave_sum4_to_lane63(float &l0, float &r0, float &l1, float &r1) {
-#define SK_DPP4(CTRL)                                                \
+// x + (x of the lane 8 further in the same 16-lane row, cyclically): one DPP add
+__device__ __forceinline__ float row_ror8_add(float x) {
+  float y;
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "=v"(y) : "v"(x));
+  return y;
+}
+
+// rows 0+1 and rows 2+3 (lane by lane): every lane of rows 0,1 ends with x[row 0] + x[row 1], of rows 2,3 with x[row 2] + x[row 3]
+__device__ __forceinline__ float row_pair_add(float x) {
+  const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+
+// two frames at once (two independent chains)
+__device__ __forceinline__ void half_sum2_to_lanes_31_63(float &x0, float &x1) {
+#define SK_DPP2(CTRL)                                                \
   "v_add_f32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"              \
   "v_add_f32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"              \
-  "v_add_f32_dpp %2, %2, %2 " CTRL " bank_mask:0xf\n\t"              \
-  "v_add_f32_dpp %3, %3, %3 " CTRL " bank_mask:0xf\n\t"
+  "s_nop 0\n\t"
   asm volatile("s_nop 1\n\t"
-               SK_DPP4("quad_perm:[1,0,3,2] row_mask:0xf")
-               SK_DPP4("quad_perm:[2,3,0,1] row_mask:0xf")
-               SK_DPP4("row_half_mirror row_mask:0xf")
-               SK_DPP4("row_mirror row_mask:0xf")
-               SK_DPP4("row_bcast:15 row_mask:0xa")
-               SK_DPP4("row_bcast:31 row_mask:0xc")
-               "s_nop 1"
-               : "+v"(l0), "+v"(r0), "+v"(l1), "+v"(r1));
-#undef SK_DPP4
+               SK_DPP2("quad_perm:[1,0,3,2] row_mask:0xf")
+               SK_DPP2("quad_perm:[2,3,0,1] row_mask:0xf")
+               SK_DPP2("row_half_mirror row_mask:0xf")
+               SK_DPP2("row_mirror row_mask:0xf")
+               SK_DPP2("row_bcast:15 row_mask:0xa")
+               "s_nop 0"
+               : "+v"(x0), "+v"(x1));
+#undef SK_DPP2
 }
 
 // ---------------------------------------------------------------- the block's mix-down, in the render kernel
@@ -436,18 +445,26 @@ __device__ __forceinline__ float slow_wrap(float ph, float lo, float hi, float s
   return ph;
 }
 
+// One frame / two frames of a wave -> wsum[wave][J] (float2 per frame: lane 31 stores .x, lane 63 stores .y).
 // (timing experiments only: -DSK_ABLATE_REDUCE drops the cross-lane sum; outputs are then wrong)
 #ifdef SK_ABLATE_REDUCE
 #define SK_REDUCE_AND_STORE(J) asm volatile("" ::"v"(l), "v"(rr));
-#else
-#define SK_REDUCE_AND_STORE(J)       \
-  wave_sum2_to_lane63(l, rr);        \
-  if (lane == 63) wsum[wave * SK_CHUNK + (J)] = make_float2(l, rr);
-#endif
-#ifdef SK_ABLATE_REDUCE
 #define SK_REDUCE4_AND_STORE(J) asm volatile("" ::"v"(l0), "v"(r0), "v"(l1), "v"(r1));
 #else
-#define SK_REDUCE4_AND_STORE(J)                      \
-  wave_sum4_to_lane63(l0, r0, l1, r1);               \
-  if (lane == 63) *reinterpret_cast<float4 *>(&wsum[wave * SK_CHUNK + (J)]) = make_float4(l0, r0, l1, r1);
+#define SK_REDUCE_AND_STORE(J)                                                                    \
+  {                                                                                               \
+    float x_ = fold_lr(l, rr);                                                                    \
+    half_sum_to_lanes_31_63(x_);                                                                  \
+    if ((lane & 31) == 31) reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (J)])[lane >> 5] = x_; \
+  }
+#define SK_REDUCE4_AND_STORE(J)                                                                   \
+  {                                                                                               \
+    float x0_ = fold_lr(l0, r0), x1_ = fold_lr(l1, r1);                                           \
+    half_sum2_to_lanes_31_63(x0_, x1_);                                                           \
+    if ((lane & 31) == 31) {                                                                      \
+      float *w_ = reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (J)]) + (lane >> 5);          \
+      w_[0] = x0_;                                                                                \
+      w_[2] = x1_;                                                                                \
+    }                                                                                             \
+  }
 #endif

@@ -201,6 +201,43 @@ __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float
   out_r = s * r.pan_r;
 }
 
+// The same rest-of-frame for the steady block paths, with the delay line and its coefficients held as register PAIRS so
+// that the two feed-forward and the two feedback products are one v_pk_mul_f32 each and the pan is a third: 7 + 1 + 1
+// instructions for biquad, gain and pan, no register moves (left to itself hipcc also SLP-packs these products, but
+// pays 2-3 v_mov per frame to line the operands up).  Same products, same order of the four additions, hence the same
+// bits as fast_post.  NEWEST_X: the newest delay-line entries sit in .x (frames alternate, as in fast_post's role swap).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct FastPk {
+  v2f b12, b21, a12, a21;       // (b1,b2) (b2,b1) (a1,a2) (a2,a1)
+  v2f pan;                      // (pan_left, pan_right)
+};
+
+template <bool FILTER, bool ENV, bool STALL, bool EXT, bool NEWEST_X>
+__device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float s, v2f &xx, v2f &yy, float &out_l, float &out_r) {
+  if (FILTER) {
+    const v2f t = (NEWEST_X ? k.b12 : k.b21) * xx;
+    const v2f u = (NEWEST_X ? k.a12 : k.a21) * yy;
+    float y = r.b0 * s;
+    y = y + (NEWEST_X ? t.x : t.y);                 // + b1 * newest x
+    y = y + (NEWEST_X ? t.y : t.x);                 // + b2 * older x
+    y = y - (NEWEST_X ? u.x : u.y);                 // - a1 * newest y
+    y = y - (NEWEST_X ? u.y : u.x);                 // - a2 * older y
+    if (!EXT || r.filt) {                           // the new entries overwrite the OLDER slots
+      if (NEWEST_X) { xx.y = s; yy.y = y; } else { xx.x = s; yy.x = y; }
+      s = y;
+    }
+  }
+  if (!STALL) {
+    const float gain = ENV ? r.gain_sustain : r.amp;   // (an un-enveloped voice of a mixed bank carries amp in gain_sustain)
+    r.sgain += r.k * (gain - r.sgain);
+  }
+  s *= r.sgain;
+  r.sample = s;
+  const v2f lr = k.pan * (v2f){s, s};
+  out_l = lr.x;
+  out_r = lr.y;
+}
+
 // A one-pole smoother towards a constant gain stops moving once k*(gain - g) rounds away (see
 // skred_render_fast2.hip: fast2_smoother_stalled); wave-uniform, tested on the expression fast_post evaluates.
 template <bool ENV>
@@ -360,17 +397,21 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     float l0, r0, l1, r1;                                                                                \
     const float sa_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
     const float sb_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
-    fast_post<FILTER, ENV, true, false, STOPS, true>(r, sa_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);        \
-    fast_post<FILTER, ENV, true, false, STOPS, true>(r, sb_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);        \
+    fast_post_v<FILTER, ENV, false, STOPS, true>(r, pk, sa_, xx, yy, l0, r0);                            \
+    fast_post_v<FILTER, ENV, false, STOPS, false>(r, pk, sb_, xx, yy, l1, r1);                           \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
 // Eight steady frames (J..J+7) of a tame wave of an LDS-table bank with the cross-lane sum through LDS instead of
-// the VALU (the same tile as skred_render_fast2.hip: SK_FAST2_LDS_BLOCK_Z): every lane parks its (L,R) of the 8
-// frames in the wave-private tile xp[8][65]; lane (f = lane&7, seg = lane>>3) adds the 8 lanes of segment seg for
-// frame f, the segment sums cross through xq[8][8], lanes 0..7 finish one frame each.  ~1.75 VALU + 3.25 LDS
-// instructions per frame instead of the 12 v_add_dpp of the pair reduction -- which is most of what a bank too
-// small to give every SIMD a second wave spends per frame.  All traffic stays inside one wavefront: no s_barrier.
+// the VALU.  Every lane folds its (L,R) of a frame into one float (fold_lr: L pair sums in lanes 0..31, R pair sums in
+// lanes 32..63) and parks it in the wave-private tile xt[8 frames][SK_XT]: one ds_write_b32 per frame.  Then lane
+// (f = lane&7, seg = lane>>3) adds the 8 floats of segment seg of frame f (two ds_read_b128), segments 0..3 (L) and
+// 4..7 (R) are added across lanes in registers (one DPP add inside the 16-lane row, one v_permlane16_swap + add across
+// the row pair), and lanes 0..7 / 32..39 store the frame's L / R total.  Per frame 2 VALU + one 4-byte LDS write, per
+// block ~12 VALU + 3 LDS instructions -- against 12 v_add_dpp per frame for the butterfly, and half the LDS bytes of
+// the (L,R)-pair tile this replaces (with 2 waves per SIMD the CU's one LDS pipe was as busy as its VALUs).
+// All traffic stays inside one wavefront (LDS executes a wave's accesses in order): no s_barrier.
+#define SK_XT 68   /* floats per tile row: 64 + 4 keeps the 16-byte reads aligned and spreads the rows over the banks */
 #define SK_FAST_WAVE_SYNC()                                 \
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
@@ -381,18 +422,14 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_TILE_REDUCE(JP)                                                                          \
   {                                                                                                      \
     SK_FAST_WAVE_SYNC()                                                                                  \
+    float t_;                                                                                            \
     {                                                                                                    \
-      const float2 *src_ = xp + (lane & 7) * 65 + (lane >> 3) * 8;                                       \
-      float2 a0_ = src_[0];                                                                              \
-      _Pragma("unroll") for (int i_ = 1; i_ < 8; ++i_) { const float2 t_ = src_[i_]; a0_.x += t_.x; a0_.y += t_.y; } \
-      xq[lane] = a0_; /* == xq[seg * 8 + f] */                                                           \
+      const float4 *src_ = reinterpret_cast<const float4 *>(xt + (lane & 7) * SK_XT + (lane >> 3) * 8);  \
+      const float4 a_ = src_[0], b_ = src_[1];                                                           \
+      t_ = ((((((a_.x + a_.y) + a_.z) + a_.w) + b_.x) + b_.y) + b_.z) + b_.w;                            \
     }                                                                                                    \
-    SK_FAST_WAVE_SYNC()                                                                                  \
-    if (lane < 8) {                                                                                      \
-      float2 t0_ = xq[lane];                                                                             \
-      _Pragma("unroll") for (int g_ = 1; g_ < 8; ++g_) { const float2 t_ = xq[g_ * 8 + lane]; t0_.x += t_.x; t0_.y += t_.y; } \
-      wsum[wave * SK_CHUNK + (JP) + lane] = t0_;                                                         \
-    }                                                                                                    \
+    t_ = row_pair_add(row_ror8_add(t_));       /* segments 0..3 -> lanes 0..7 (L), 4..7 -> lanes 32..39 (R) */ \
+    if ((lane & 24) == 0) reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (JP) + (lane & 7)])[lane >> 5] = t_; \
     SK_FAST_WAVE_SYNC()                                                                                  \
   }
 #define SK_FAST_LDS_BLOCK(J, STALL_)                                                                     \
@@ -403,14 +440,93 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
-      fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, smp_[q_], r.x1, r.x2, r.y1, r.y2, released, l0, r0);     \
-      fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, smp_[q_ + 1], r.x2, r.x1, r.y2, r.y1, released, l1, r1); \
-      xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
-      xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, smp_[q_], xx, yy, l0, r0);                    \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, smp_[q_ + 1], xx, yy, l1, r1);               \
+      xt[q_ * SK_XT + lane] = fold_lr(l0, r0);                                                           \
+      xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                     \
     }                                                                                                    \
     pend_j = (J);                                                                                        \
   }
 #define SK_FAST_LDS_FLUSH() if (pend_j >= 0) { SK_FAST_TILE_REDUCE(pend_j) pend_j = -1; }
+// All 8-frame blocks of a chunk, software-pipelined one block deep: while the biquad / gain chains of block b run
+// (a serial recurrence over its 8 frames), the oscillator of block b+1 advances and gathers (another serial recurrence,
+// independent of the first) and the tile of block b-1 -- read at the top, before block b's outputs overwrite it -- is
+// added up.  The three strands sit in ONE scheduling region (the wave-level fences only bracket the tile reads), so the
+// instruction scheduler can weave them: with one or two waves per SIMD there is nothing else to fill the dependent-issue
+// gaps of a single recurrence with.
+#ifndef SK_FAST_PIPE
+#define SK_FAST_PIPE 1
+#endif
+#define SK_FAST_OSC8(DST)                                                                                \
+  _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                       \
+    DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));
+#define SK_FAST_POST8(SRC, STALL_)                                                                       \
+  _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
+    float l0, r0, l1, r1;                                                                                \
+    fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0, r0);                       \
+    fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1, r1);                  \
+    xt[q_ * SK_XT + lane] = fold_lr(l0, r0);                                                             \
+    xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                       \
+  }
+/* the two strands written frame pair by frame pair, the way they should issue: oscillator of the NEXT block, chains of this one */
+#define SK_FAST_OSC_POST8(DST, SRC, STALL_)                                                              \
+  _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
+    float l0, r0, l1, r1;                                                                                \
+    DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));             \
+    fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0, r0);                       \
+    DST[q_ + 1] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));         \
+    fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1, r1);                  \
+    xt[q_ * SK_XT + lane] = fold_lr(l0, r0);                                                             \
+    xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                       \
+  }
+#define SK_FAST_TILE_LOAD(TA, TB)                                                                        \
+  {                                                                                                      \
+    SK_FAST_WAVE_SYNC()                                                                                  \
+    const float4 *src_ = reinterpret_cast<const float4 *>(xt + (lane & 7) * SK_XT + (lane >> 3) * 8);    \
+    TA = src_[0]; TB = src_[1];                                                                          \
+    SK_FAST_WAVE_SYNC()                                                                                  \
+  }
+#define SK_FAST_TILE_FINISH(TA, TB, JP)                                                                  \
+  {                                                                                                      \
+    float t_ = ((((((TA.x + TA.y) + TA.z) + TA.w) + TB.x) + TB.y) + TB.z) + TB.w;                        \
+    t_ = row_pair_add(row_ror8_add(t_));                                                                 \
+    if ((lane & 24) == 0) reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (JP) + (lane & 7)])[lane >> 5] = t_; \
+  }
+#define SK_FAST_LDS_CHUNK(STALL_)                                                                        \
+  {                                                                                                      \
+    const int nblk_ = cn >> 3;                                                                           \
+    if (nblk_ > 0) {                                                                                     \
+      float sa_[8], sb_[8];                                                                              \
+      float4 ta_, tb_;                                                                                   \
+      SK_FAST_OSC8(sa_)                                                                                  \
+      if (nblk_ > 1) {                                                                                   \
+        SK_FAST_OSC_POST8(sb_, sa_, STALL_)                                             /* block 0 */    \
+        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) sa_[q_] = sb_[q_];                              \
+        for (int b_ = 1; b_ + 1 < nblk_; ++b_) {                                                         \
+          SK_FAST_TILE_LOAD(ta_, tb_)                                                                    \
+          SK_FAST_OSC_POST8(sb_, sa_, STALL_) SK_FAST_TILE_FINISH(ta_, tb_, (b_ - 1) * 8)                \
+          _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) sa_[q_] = sb_[q_];                            \
+        }                                                                                                \
+        SK_FAST_TILE_LOAD(ta_, tb_)                                                                      \
+        SK_FAST_POST8(sa_, STALL_) SK_FAST_TILE_FINISH(ta_, tb_, (nblk_ - 2) * 8)       /* last block */ \
+      } else {                                                                                           \
+        SK_FAST_POST8(sa_, STALL_)                                                                       \
+      }                                                                                                  \
+      SK_FAST_TILE_LOAD(ta_, tb_)                                                                        \
+      SK_FAST_TILE_FINISH(ta_, tb_, (nblk_ - 1) * 8)                                                     \
+      SK_FAST_WAVE_SYNC()                                                                                \
+    }                                                                                                    \
+    j = nblk_ << 3;                                                                                      \
+  }
+// the steady block paths keep the delay line in register pairs (fast_post_v): in at the start of such a chunk, out at its
+// end (an even number of frames later the newest entries are back in .x = x1 / y1)
+#define SK_FAST_PACK_IN()                                                                 \
+  v2f xx = {r.x1, r.x2}, yy = {r.y1, r.y2};                                               \
+  FastPk pk;   /* (built per chunk: a lane that finished meanwhile carries inert numbers in r) */ \
+  pk.b12 = (v2f){r.b1, r.b2}; pk.b21 = (v2f){r.b2, r.b1};                                 \
+  pk.a12 = (v2f){r.a1, r.a2}; pk.a21 = (v2f){r.a2, r.a1};                                 \
+  pk.pan = (v2f){r.pan_l, r.pan_r};   /* (the block paths run only in waves without pan modulation) */
+#define SK_FAST_PACK_OUT() { r.x1 = xx.x; r.x2 = xx.y; r.y1 = yy.x; r.y2 = yy.y; }
 // Eight steady frames of the extended frame loop (modulation exchange, finish test, sample & hold ... per frame) with
 // the same tile reduction instead of 12 v_add_dpp per frame; the per-wave LDS region is free here (no table windows
 // in such a wave).
@@ -422,7 +538,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
     SK_FAST_STEM(Q, l, rr)                                                                               \
     if (STOPS && (xf & XF_STOP) && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, SWAPPED_, c0 + (Q) == a.num_frames - 1, misc_xy); \
-    xp[((Q) & 7) * 65 + lane] = make_float2(l, rr);                                                      \
+    xt[((Q) & 7) * SK_XT + lane] = fold_lr(l, rr);                                                       \
   }
 #define SK_FAST_X_BLOCK(J)                                                                               \
   {                                                                                                      \
@@ -482,9 +598,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
   const int lane = tid & 63;
   const int wave = tid >> 6;
   float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (SK_WIN * 64);   // global-table banks: table windows
-  float2 *xp = reinterpret_cast<float2 *>(win);       // LDS-table banks: the same per-wave region holds the
-  float2 *xq = xp + 8 * 65;                            // transposition tiles of SK_FAST_LDS_BLOCK (8*65 + 64 float2 <= SK_WIN*64 floats)
-  (void)win; (void)xp; (void)xq;
+  float *xt = win;                                     // LDS-table banks: the same per-wave region holds the reduction
+  (void)win; (void)xt;                                 // tile of SK_FAST_LDS_BLOCK (8 * SK_XT floats <= SK_WIN * 64)
   const int bid = (int)blockIdx.x - a.wg_shift;        // row of the partial mix; -1: the gain workgroup (sk_finish_block)
   if (bid < 0) { sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds)); return; }
 
@@ -647,10 +762,17 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         // an extended bank, but nothing in THIS wave needs the frame loop now (e.g. only some voices filtered, or one-shots
         // still far from their end): frame pairs
         int j = 0, pend_j = -1;
+        SK_FAST_PACK_IN()
+#if SK_FAST_PIPE
+        if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
+        (void)pend_j;
+#else
         if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, true)
         else for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, false)
         SK_FAST_LDS_FLUSH()
+#endif
         for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
+        SK_FAST_PACK_OUT()
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (STOPS && (!ENV || steady)) {
         int j = 0;
@@ -669,18 +791,28 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         if (!TAB_LDS) {
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
+          SK_FAST_PACK_IN()
+          for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
+          SK_FAST_PACK_OUT()
         } else {
           int pend_j = -1;
+          SK_FAST_PACK_IN()
+#if SK_FAST_PIPE
+          if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
+          (void)pend_j;
+#else
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, false)
           SK_FAST_LDS_FLUSH()
+#endif
+          for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
+          SK_FAST_PACK_OUT()
         }
-        for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (!ENV || steady) {
         int j = 0;
         if (stems_on) for (; j + 1 < cn; j += 2) { SK_FAST_EVEN(j, true) SK_FAST_ODD(j + 1, true) }   // frame by frame, stems written
-        else for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, false)
+        else { SK_FAST_PACK_IN() for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, false) SK_FAST_PACK_OUT() }
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (exact) {
         int j = 0;
@@ -699,7 +831,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
           SK_FAST_FIX_ODD_TAIL()
         }
       }
+#ifndef SK_ABLATE_BARRIERS   /* (timing experiments only: without the barriers the flush races) */
       __syncthreads();
+#endif
       if (tid < 2 * cn) {
         const float *w = reinterpret_cast<const float *>(wsum);
         float s = w[0 * 2 * SK_CHUNK + tid];
@@ -708,7 +842,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         s += w[3 * 2 * SK_CHUNK + tid];
         sk_row_store(a.partial + part_base + (size_t)c0 * 2 + tid, s, first_pass, publish);
       }
+#ifndef SK_ABLATE_BARRIERS
       __syncthreads();
+#endif
     }
 
     // store the recurrences; skipped voices keep their state and get voice_sample = 0 (synth.c:532,538)

@@ -731,8 +731,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
               fast2_frame<TAB_LDS, FILTER, 2, true, INTERP, MIXED>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);
               e.tf[0] += 1.0f; e.trf[0] += 1.0f; e.tf[1] += 1.0f; e.trf[1] += 1.0f;
               fast2_frame<TAB_LDS, FILTER, 2, true, INTERP, MIXED>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);
-              { const int J_ = jb + q; wave_sum4_to_lane63(l0, r0, l1, r1);
-                if (lane == 63) *reinterpret_cast<float4 *>(&wsum[wave * SK_CHUNK + J_]) = make_float4(l0, r0, l1, r1); }
+              { const int J_ = jb + q; SK_REDUCE4_AND_STORE(J_) }
             }
           }
         }

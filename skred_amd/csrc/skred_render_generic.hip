@@ -14,8 +14,8 @@
 //     dwordx4 load per plane per launch, one dwordx4 store per read-write plane;
 //   * wavetables are staged into LDS once per workgroup when the pool fits (gather = ds_read);
 //     larger pools (PCM) are gathered from L2/HBM;
-//   * per frame the 64 lanes' L/R are summed with a fixed-order DPP reduction (no LDS traffic,
-//     no atomics: results are bit-reproducible run to run); wave sums meet in LDS every
+//   * per frame the 64 lanes' L/R are folded into one register (v_permlane32_swap) and summed with a fixed-order
+//     DPP butterfly (no LDS traffic, no atomics: results are bit-reproducible run to run); wave sums meet in LDS every
 //     SK_CHUNK frames and leave as coalesced stores into a per-workgroup partial mix;
 //   * no MFMA: this is gather + multiply-add along a serial recurrence, not a contraction.
 //
@@ -78,9 +78,7 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_kernel(const sk_render_arg
             reinterpret_cast<float2 *>(a.stems)[(size_t)i * (size_t)a.n_voices + (size_t)v] =
                 make_float2(l, rr);
         }
-        float sl = l, sr = rr;
-        wave_sum2_to_lane63(sl, sr);
-        if (lane == 63) wsum[wave * SK_CHUNK + j] = make_float2(sl, sr);
+        SK_REDUCE_AND_STORE(j)
       }
       __syncthreads();
       if (tid < 2 * cn) {
@@ -346,9 +344,7 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render
           if (v < a.n_voices)
             reinterpret_cast<float2 *>(a.stems)[(size_t)i * (size_t)a.n_voices + (size_t)v] = make_float2(l, rr);
         }
-        float sl = l, sr = rr;
-        wave_sum2_to_lane63(sl, sr);
-        if (lane == 63) wsum[wave * SK_CHUNK + j] = make_float2(sl, sr);
+        SK_REDUCE_AND_STORE(j)
         cur_i ^= 1;
       }
       __syncthreads();

@@ -2,18 +2,20 @@
 """bench.py -- throughput of the MI355X render path on BASELINE's synthetic voice banks.
 
 Metric (BASELINE.json): voice-samples/s = voices x frames rendered / wall seconds, whole job.
-One "step" = one pass of the hot path over the whole bank: one render launch of F frames for
-every voice (+ the partial-mix reduction, + for N>1 GPUs the RCCL sum of the per-GPU partial
-mixes, + the master-volume stage on rank 0).  State and tables are resident in HBM before the
+One "step" = one pass of the hot path over the whole bank: ONE launch that renders F frames of every voice, adds the
+per-workgroup partial mixes up and applies the master volume (N = 1); for N > 1 GPUs: render + mix-down on every GPU,
+one RCCL reduce(sum) of float[F][2] onto rank 0, master volume there.  State and tables are resident in HBM before the
 timed region starts; the output frames stay in HBM (a real-time host would copy 8*F bytes).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c2|c3|c4] [--frames F]
 
-Default workload: the BASELINE config-3 bank -- 2^20 voices (mixed notamy LUTs + biquad + ADSR) per
-GPU, F = 512 frames per launch (the reference's callback size, skred.h:12), 48 kHz.  N>1 is
-launched by the driver through torch.distributed.run, one rank per GPU; every GPU holds a bank of
-that size (weak scaling), voices never cross GPUs, the only collective is one reduce of float[F][2].
-`--scaling strong` splits ONE 2^20-voice bank over the GPUs instead (the literal config 3).
+Default workload: BASELINE config 3 -- ONE bank of 2^20 voices (mixed notamy LUTs + biquad + ADSR), F = 512 frames
+per launch (the reference's callback size, skred.h:12), 48 kHz.  With N > 1 (the driver launches one rank per GPU
+through torch.distributed.run) that bank is SPLIT over the GPUs -- the literal config 3, "scaling": "strong" -- and the
+line also carries `weak_scaling` (a 2^20-voice bank per GPU) for comparison.  With N = 1 the line also carries the
+other BASELINE workloads (`c1`, `c2`, `c4`), two other block lengths (`low_latency`, `long_block`), the recipe from its
+first frame (`envelopes_in_motion`), a bank under control traffic (`live_control`), the fixed-point path and the CPU
+baseline.
 """
 from __future__ import annotations
 
@@ -44,6 +46,7 @@ DESCR = {
     "c4": "C4: 262144 PCM voices (pcm_map geometry, synthetic samples), linear interpolation, 48 kHz, fp32",
 }
 KERNELS = {0: "sk_render_kernel", 1: "sk_render_fast_kernel", 2: "sk_render_mod_kernel", 3: "sk_render_fast2_kernel"}
+RECIPE_WARMUP_S = 0.11     # attack + decay of the recipe's ADSR: after that every voice sits in its sustain stage
 
 
 def cpu_baseline(recipe, interp, seconds_per_leg=8.0):
@@ -112,16 +115,36 @@ print("RATE", 64 * 512 * n / (time.perf_counter() - t0))
         return None
 
 
-def pmc_traffic(workload, voices, frames):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), when
-    one exists for exactly this workload shape; bench.py itself cannot collect PMC counters."""
+def pmc_entry(workload):
+    """What the committed rocprofv3 PMC passes measured for this workload shape (profiles/pmc_traffic.json: HBM bytes
+    per launch, L2 read requests per launch); bench.py itself cannot collect PMC counters."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
-        if d["frames_per_launch"] == frames and d["voices"] == voices:
-            return d["hbm_bytes_per_launch"]
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
     except Exception:
-        pass
-    return None
+        return None
+
+
+def roofline(workload, voices, frames, gather_bytes, k_mean, k_min, k_cnt, kernel):
+    B = gather_bytes + (STATE_READ + STATE_WRITE) / frames       # algorithmic bytes / voice-sample, SURVEY §8(d)
+    launch_bytes = B * voices * frames
+    achieved = launch_bytes / (k_mean * 1e-3)
+    pm = pmc_entry(workload)
+    traffic = pm["hbm_bytes_per_launch"] if pm and pm.get("frames_per_launch") == frames and pm.get("voices") == voices else None
+    out = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK, "traffic": traffic,
+           "traffic_rate": None if traffic is None else traffic / (k_mean * 1e-3) / 1e9,   # measured HBM GB/s of this kernel
+           "traffic_frac": None if traffic is None else traffic / (k_mean * 1e-3) / HBM_PEAK,
+           "kernel": kernel, "frames_per_launch": frames,
+           "kernel_ms_mean": k_mean, "kernel_ms_min": k_min, "launches_timed": k_cnt,
+           "algorithmic_bytes_per_voice_sample": B, "algorithmic_bytes_per_launch": launch_bytes,
+           "kernel_voice_samples_per_s": voices * frames / (k_mean * 1e-3)}
+    if traffic is not None and pm.get("l2_read_requests_per_launch") and pm.get("l2_request_peak_per_s"):
+        # the resource that binds a bank whose tables live in L2: line requests from the CUs' texture-address units
+        req = pm["l2_read_requests_per_launch"]
+        out["l2_requests"] = {"bound": "l2_read_requests", "achieved": req / (k_mean * 1e-3), "peak": pm["l2_request_peak_per_s"],
+                              "unit": "requests/s", "frac": req / (k_mean * 1e-3) / pm["l2_request_peak_per_s"],
+                              "requests_per_launch": req, "peak_source": pm.get("l2_request_peak_source", "")}
+    return out
 
 
 def main():
@@ -136,36 +159,29 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=512, help="frames per launch (reference callback size, skred.h:12)")
-    ap.add_argument("--voices", type=int, default=0, help="override the per-bank voice count")
-    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
-                    help="weak (default): every GPU gets a whole bank of the workload size; strong: one bank is split over the GPUs")
+    ap.add_argument("--voices", type=int, default=0, help="override the bank's voice count")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1 -- strong (default): ONE bank of the workload size split over the GPUs (BASELINE config 3 as written); "
+                         "weak: a bank of that size on every GPU.  The default run reports both (`weak_scaling`)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-fixed-point", action="store_true", help="skip the fixed-point leg (N=1 only)")
-    ap.add_argument("--no-low-latency", action="store_true", help="skip the secondary F=64 measurement")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: only the main line (no other workloads / block lengths / legs)")
+    ap.add_argument("--no-low-latency", action="store_true", help="(older name of --no-extra)")
+    ap.add_argument("--no-fixed-point", action="store_true", help="skip the fixed-point leg")
     ap.add_argument("--no-recipe-warmup", action="store_true",
                     help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
-    ap.add_argument("--time-every", type=int, default=8,
-                    help="bracket the render kernels of every n-th launch with HIP events (kernel duration for the roofline)")
-    ap.add_argument("--tail-overlap", action="store_true",
-                    help="one GPU: run every block's reduction + master stage on the bank's internal stream so that the next "
-                         "block's render overlaps them (SKRED_OPT_OVERLAP_TAIL).  Off by default: measured at these very settings "
-                         "it is worth -4..+0.5 % on the four workloads (DESIGN.md, 'Per-block launch count')")
-    ap.add_argument("--no-tail-overlap", action="store_true", help="(the default; kept for the scripts under tools/)")
+    ap.add_argument("--time-every", type=int, default=0,
+                    help="bracket the render kernel of every n-th launch with HIP events (kernel duration for the roofline); "
+                         "0 = choose so that at least 8 launches of the timed region are bracketed")
+    ap.add_argument("--spinup-ms", type=float, default=40.0,
+                    help="untimed rendering before the W warm-up steps until this much wall time has passed: a GPU taken from idle "
+                         "needs ~25 ms of work before clocks and caches settle (20 steps right after first touch time ~10 %% slow)")
     ap.add_argument("--rehearse-dist", action="store_true",
-                    help="with one process: still create a (1-rank) process group and run the N>1 code path through it "
-                         "(exercises the RCCL calls on a single-GPU box)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="N>1: double-buffered step, the reduce of block k (RCCL's stream) overlaps the render of block k+1 "
-                         "(ShardedRender.step_overlapped).  Default: the sequential step render -> reduce -> master; measured "
-                         "through a one-rank RCCL group the overlapped form costs 17 us more per block than it hides "
-                         "(0.293 vs 0.276 ms: the collective's kernel dispatched in turns with the render), DESIGN.md section 5")
-    ap.add_argument("--no-overlap", action="store_true", help="(the default; kept for older command lines)")
-    ap.add_argument("--backend", default=os.environ.get("SKRED_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
-                    help="nccl (= RCCL, default).  gloo is only for rehearsing the N>1 code path on a box with fewer "
-                         "GPUs than ranks (ranks then share devices and the partial mix is reduced through host memory)")
+                    help="with one process: run the N > 1 code path (the shard's RCCL reduce, with one rank) on a single-GPU box")
     ap.add_argument("--fast2-min-voices", type=int, default=-1,
                     help="override the bank size from which the two-voices-per-lane kernel is used (-1: library default)")
     a = ap.parse_args()
+    if a.no_low_latency:
+        a.no_extra = True
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,60 +189,30 @@ def main():
     if world != a.gpus and world > 1:
         a.gpus = world
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     from skred_amd import banks, device
-    from skred_amd.sharded import ShardedRender
+    from skred_amd.sharded import Shard
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     ndev = torch.cuda.device_count()
-    if a.backend == "nccl" and local >= ndev:
+    if local >= ndev:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible")
-    local = local % ndev                       # gloo rehearsal: ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or a.rehearse_dist       # the N>1 code path (collectives, barrier, max-over-ranks timing)
+    use_dist = world > 1 or a.rehearse_dist       # the N>1 code path (collective, barrier, max-over-ranks timing)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
-
-    recipe, bank_voices, interp, gather_bytes = WORKLOADS[a.workload]
-    if a.voices:
-        bank_voices = a.voices
-    total = bank_voices * world if a.scaling == "weak" else bank_voices
-    sh = ShardedRender(total, rank, world, always_reduce=a.rehearse_dist)
-    F = a.frames
-
-    # seeded banks: weak scaling gives every rank its own bank of the workload size (seed + rank);
-    # strong scaling generates the one global bank on every rank and keeps this rank's block
-    if a.scaling == "weak":
-        shard, tables, g = banks.RECIPES[recipe](bank_voices, seed=banks.SEED + rank)
-    else:
-        full, tables, g = banks.RECIPES[recipe](total)
-        shard = full.take(slice(sh.lo, sh.hi)) if world > 1 else full
-        del full
-    assert shard.n == sh.n_local
-    db = device.DeviceBank(shard.n, local)
-    db.set_tables(tables)
-    db.upload(shard)
-    db.set_globals(g)
-    if a.fast2_min_voices >= 0:
-        db.fast2_min_voices(a.fast2_min_voices)
-    # the render kernels of every 8th launch are bracketed by an event pair (roofline.kernel_ms_*): a pair costs ~6 us
-    # of stream time, so bracketing every launch would tax the very throughput being measured
-    db.kernel_timing(max(1, min(a.time_every, a.steps)))
-    if world == 1 and not a.rehearse_dist and a.tail_overlap and not a.no_tail_overlap:
-        db.overlap_tail(True)          # block k's reduction + master overlap block k+1's render (all inside the timed region)
+        dist.init_process_group("nccl", device_id=dev)
 
     stream = torch.cuda.current_stream().cuda_stream
+    every = a.time_every if a.time_every > 0 else min(8, max(1, a.steps // 10))
 
     def fence():
         torch.cuda.synchronize()
@@ -234,139 +220,243 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(frames, steps, warmup):
-        partial = torch.zeros(frames, 2, device=dev, dtype=torch.float32)
-        out = torch.zeros(frames, 2, device=dev, dtype=torch.float32)
+    def recipe_warmup(render_block, frames):
+        """BASELINE.md §4 / SURVEY §8(d): "render 1 s after 0.1 s warm-up".  The recipe's note-ons are staggered over the
+        last second and attack+decay last 0.11 s, so those first frames are rendered untimed: the timed region then
+        starts with every voice in its sustain stage, as the recipe intends (`envelopes_in_motion` times the rest)."""
+        done = 0
+        while done < int(RECIPE_WARMUP_S * 48000):
+            render_block(frames)
+            done += frames
+        return done
 
-        def render_partial(p):
-            db.render(frames, p.data_ptr(), 0, interp, stream)
+    def spinup(render_block, frames):
+        """untimed blocks until --spinup-ms of wall time have passed (reported as config.spinup_blocks)"""
+        n, t0 = 0, time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < a.spinup_ms:
+            for _ in range(8):
+                render_block(frames)
+            torch.cuda.synchronize()
+            n += 8
+        return n
 
-        def master(p, o):
-            db.master(p.data_ptr(), frames, o.data_ptr(), 2, stream)
-
-        if use_dist and a.backend == "gloo":     # rehearsal only: reduce through host memory
-            host = torch.zeros(frames, 2, dtype=torch.float32)
-            dev_render = render_partial
-
-            def render_partial(p):                 # noqa: F811
-                dev_render(partial)
-                torch.cuda.synchronize()
-                p.copy_(partial)
-
-            dev_master = master
-
-            def master(p, o):                      # noqa: F811
-                partial.copy_(p)
-                dev_master(partial, o)
-
-            red = host
-        else:
-            red = partial
-        if use_dist and a.overlap and not a.no_overlap:
-            # double-buffered: the reduce of block k (RCCL, its own stream) overlaps the render of block k+1;
-            # every block is still rendered, reduced and mastered inside the region it is counted in (drain)
-            sh.begin([red, torch.zeros_like(red)])
-
-            def run(n):
-                for _ in range(n):
-                    sh.step_overlapped(render_partial, master, out)
-                sh.drain(master, out)                       # leaves the pair of buffers in place
-        elif use_dist:
-            def run(n):
-                for _ in range(n):
-                    sh.step(render_partial, master, red, out)   # render -> RCCL reduce -> master on rank 0
-        else:
-            def run(n):                                         # one GPU: render + (last reduction stage fused with) master
-                for _ in range(n):
-                    db.render_mix(frames, out.data_ptr(), 2, 0, interp, stream)
-                db.wait_mix(stream)                             # the last block's tail joins the stream before the fence
-        run(warmup)
+    def timed(render_block, db, frames, steps, warmup, timing_every):
+        """warm-up launches, then EXACTLY `steps` launches between two fences; max over ranks."""
+        db.kernel_timing(timing_every)
+        for _ in range(warmup):
+            render_block(frames)
         fence()
         db.timing_reset()
         t0 = time.perf_counter()
-        run(steps)
+        for _ in range(steps):
+            render_block(frames)
         fence()
         dt = time.perf_counter() - t0
         if use_dist:
-            tt = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         k_mean, k_min, k_cnt = db.timing_summary()
-        finite = bool(torch.isfinite(out).all().item()) if rank == 0 else True
-        return dt, k_mean, k_min, k_cnt, finite
+        return dt, k_mean, k_min, k_cnt
 
-    def roofline(frames, k_mean, k_min, k_cnt):
-        B = gather_bytes + (STATE_READ + STATE_WRITE) / frames       # algorithmic bytes / voice-sample
-        launch_bytes = B * shard.n * frames
-        achieved = launch_bytes / (k_mean * 1e-3)
-        traffic = pmc_traffic(a.workload, shard.n, frames)      # HBM bytes per launch from the PMC passes (profiles/)
-        return {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": traffic,
-                "traffic_rate": None if traffic is None else traffic / (k_mean * 1e-3) / 1e9,   # measured HBM GB/s of this kernel
-                "traffic_frac": None if traffic is None else traffic / (k_mean * 1e-3) / HBM_PEAK,
-                "kernel": KERNELS.get(db.last_kernel(), "?"), "frames_per_launch": frames,
-                "kernel_ms_mean": k_mean, "kernel_ms_min": k_min, "launches_timed": k_cnt,
-                "algorithmic_bytes_per_voice_sample": B, "algorithmic_bytes_per_launch": launch_bytes,
-                "kernel_voice_samples_per_s": shard.n * frames / (k_mean * 1e-3)}
+    # ------------------------------------------------------------------ the main line
+    recipe, bank_voices, interp, gather_bytes = WORKLOADS[a.workload]
+    if a.voices:
+        bank_voices = a.voices
+    F = a.frames
 
-    # BASELINE.md §4 / SURVEY §8(d): "render 1 s after 0.1 s warm-up".  The recipe's note-ons are staggered over
-    # the last second and attack+decay last 0.11 s, so those first 5280 frames are rendered here, untimed and
-    # independent of --warmup: the timed region then starts with every voice in its sustain stage, as the
-    # recipe intends (launches with voices still in attack/decay are ~3.5x slower: DESIGN.md §4).
-    recipe_warmup_frames = 0
-    if not a.no_recipe_warmup:
-        scratch = torch.zeros(F, 2, device=dev, dtype=torch.float32)
-        while recipe_warmup_frames < int(0.11 * 48000):
-            db.render(F, scratch.data_ptr(), 0, interp, stream)
-            recipe_warmup_frames += F
+    def sharded_leg(total, scaling):
+        """One bank of `total` voices split over the ranks (strong) or one bank of `total / world`... see caller."""
+        sh = Shard(total, rank, world, local)
+        if scaling == "strong" or world == 1:
+            whole, tables, g = banks.RECIPES[recipe](total)          # the one global bank, generated on every rank
+            sh.bank.set_tables(tables)
+            sh.upload(whole)
+            del whole
+        else:                                                        # weak: every rank holds its own bank (seed + rank)
+            mine, tables, g = banks.RECIPES[recipe](sh.n_local, seed=banks.SEED + rank)
+            sh.bank.set_tables(tables)
+            sh.bank.upload(mine)
+            del mine
+        sh.bank.set_globals(g)
+        if a.fast2_min_voices >= 0:
+            sh.bank.fast2_min_voices(a.fast2_min_voices)
+        if world > 1 or a.rehearse_dist:
+            ids = [Shard.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            sh.init_rccl(ids[0])
+            if a.rehearse_dist and world == 1:
+                sh.set_reduce(None, always_reduce=True)
+        out = torch.zeros(F, 2, device=dev, dtype=torch.float32)
+
+        def block(frames):
+            sh.render_mix(frames, out.data_ptr(), 2, interp, stream)
+        warm = 0 if a.no_recipe_warmup else recipe_warmup(block, F)
+        spun = spinup(block, F)
         fence()
-    dt, k_mean, k_min, k_cnt, finite = timed(F, a.steps, a.warmup)
+        dt, k_mean, k_min, k_cnt = timed(block, sh.bank, F, a.steps, a.warmup, every)
+        finite = bool(torch.isfinite(out).all().item()) if rank == 0 else True
+        res = {"dt": dt, "k": (k_mean, k_min, k_cnt), "kernel": KERNELS.get(sh.bank.last_kernel(), "?"), "finite": finite,
+               "warm": warm, "spun": spun, "n_local": sh.n_local}
+        sh.close()
+        return res
 
     res = None
-    if rank == 0:
-        value = total * F * a.steps / dt
-        rl = roofline(F, k_mean, k_min, k_cnt)
-        rl["note"] = ("LUTs are LDS-resident and the recurrences live in registers, so compulsory HBM traffic is one "
-                      "state sweep per launch: at F=512 the kernel is bound by fp32 VALU issue (72% VALU-busy, "
-                      "profiles/r01_v9_c3_pmc_summary.json), not by HBM; the HBM fraction grows as F shrinks (low_latency). "
-                      "PCM banks (c4) gather from an L2-resident pool: profiles/r01_v9_c4_pmc_summary.json")
-        where = ""
-        if world > 1:
-            where = f"; one such bank per GPU ({world} GPUs)" if a.scaling == "weak" else f"; split over {world} GPUs"
-        res = {
-            "metric": "voice-samples/s", "value": value, "unit": "voice-samples/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": DESCR[a.workload] + (f" [voices overridden: {bank_voices} per bank]" if a.voices else "") + where,
-                       "voices_total": total, "voices_per_gpu": shard.n,
-                       "frames_per_launch": F, "sample_rate": 48000, "interp": "linear" if interp else "truncate",
-                       "parallelism": f"voices block-partitioned over {world} GPU(s)" + ("; one RCCL reduce(sum) of float[F][2] per launch" + (", overlapped with the next launch's render" if a.overlap and not a.no_overlap else "") if world > 1 else ""),
-                       "seed": "0x5EED", "recipe_warmup_frames": recipe_warmup_frames},
-            "realtime_factor_48k": value / (total * 48000.0),
-            "output_finite": finite,
-            "roofline": rl,
-        }
-    # secondary operating point: short callbacks (F = 64 frames = 1.33 ms at 48 kHz), where the per-launch
-    # state sweep dominates and the kernel approaches the HBM roofline (single GPU only)
-    if world == 1 and not a.no_low_latency and F != 64:
-        k2 = max(50, a.steps)
-        dt2, km2, kn2, kc2, _ = timed(64, k2, 20)
-        ll = roofline(64, km2, kn2, kc2)
-        ll["value"] = total * 64 * k2 / dt2
-        ll["realtime_factor_48k"] = ll["value"] / (total * 48000.0)
-        res["low_latency"] = ll
-    # SURVEY 8(d) also asks for F = 4800 (100 ms blocks): the state sweep is amortised further, B = G + 292/4800
-    if world == 1 and not a.no_low_latency and F != 4800:
-        k3 = max(10, a.steps // 10)
-        dt3, km3, kn3, kc3, _ = timed(4800, k3, 2)
-        lb = roofline(4800, km3, kn3, kc3)
-        lb["value"] = total * 4800 * k3 / dt3
-        lb["realtime_factor_48k"] = lb["value"] / (total * 48000.0)
-        res["long_block"] = lb
-    # the fixed-point LUT path (include/skred_amd_fxpt.h; integer mix, exact): same voice count, int16 LUT pyramids in LDS,
-    # linear interpolation, ADSR + smoother, no biquad (section 6 of DESIGN.md)
-    if world == 1 and not a.no_low_latency and not a.no_fixed_point and a.workload != "c4":
+    if use_dist:
+        total = bank_voices if a.scaling == "strong" else bank_voices * world
+        m = sharded_leg(total, a.scaling)
+        if rank == 0:
+            value = total * F * a.steps / m["dt"]
+            rl = roofline(a.workload, m["n_local"], F, gather_bytes, *m["k"], m["kernel"])
+            res = {
+                "metric": "voice-samples/s", "value": value, "unit": "voice-samples/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": m["dt"] / a.steps * 1e3, "higher_is_better": True,
+                "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": DESCR[a.workload] + (f" [voices overridden: {bank_voices}]" if a.voices else "") +
+                                       (f"; split over {world} GPUs" if a.scaling == "strong" else f"; one such bank per GPU ({world} GPUs)"),
+                           "voices_total": total, "voices_per_gpu": m["n_local"], "frames_per_launch": F, "sample_rate": 48000,
+                           "interp": "linear" if interp else "truncate",
+                           "parallelism": f"voices block-partitioned over {world} GPU(s); one RCCL reduce(sum) of float[F][2] per launch "
+                                          "(skred_shard_render_mix: render + mix-down on every GPU -> ncclReduce -> master volume on rank 0)",
+                           "seed": "0x5EED", "recipe_warmup_frames": m["warm"], "spinup_blocks": m["spun"]},
+                "realtime_factor_48k": value / (total * 48000.0), "output_finite": m["finite"], "roofline": rl,
+            }
+        if world > 1 and not a.no_extra:
+            other = "weak" if a.scaling == "strong" else "strong"
+            total2 = bank_voices * world if other == "weak" else bank_voices
+            m2 = sharded_leg(total2, other)
+            if rank == 0:
+                v2 = total2 * F * a.steps / m2["dt"]
+                res[other + "_scaling"] = {"value": v2, "unit": "voice-samples/s", "scaling": other, "voices_total": total2,
+                                           "voices_per_gpu": m2["n_local"], "ms_per_step": m2["dt"] / a.steps * 1e3,
+                                           "kernel": m2["kernel"], "kernel_ms_mean": m2["k"][0], "launches_timed": m2["k"][2]}
+        if rank == 0:
+            os.write(result_fd, (json.dumps(res) + "\n").encode())
+        dist.destroy_process_group()
+        return
+
+    # ------------------------------------------------------------------ one GPU
+    def single_leg(wl, frames, steps, warmup, timing_every, voices=0, warm_recipe=True):
+        rec, n, itp, gbytes = WORKLOADS[wl]
+        n = voices or n
+        bank, tables, g = banks.RECIPES[rec](n)
+        db = device.DeviceBank(n, local)
+        db.set_tables(tables)
+        db.upload(bank)
+        db.set_globals(g)
+        if a.fast2_min_voices >= 0:
+            db.fast2_min_voices(a.fast2_min_voices)
+        out = torch.zeros(frames, 2, device=dev, dtype=torch.float32)
+
+        def block(fr):
+            db.render_mix(fr, out.data_ptr(), 2, 0, itp, stream)
+        warm = recipe_warmup(block, frames) if warm_recipe else 0
+        spun = spinup(block, frames)
+        fence()
+        dt, k_mean, k_min, k_cnt = timed(block, db, frames, steps, warmup, timing_every)
+        r = roofline(wl, n, frames, gbytes, k_mean, k_min, k_cnt, KERNELS.get(db.last_kernel(), "?"))
+        r["value"] = n * frames * steps / dt
+        r["ms_per_step"] = dt / steps * 1e3
+        r["realtime_factor_48k"] = r["value"] / (n * 48000.0)
+        r["voices"] = n
+        finite = bool(torch.isfinite(out).all().item())
+        return r, dt, (warm, spun), finite, (db, bank, tables, g, out)
+
+    rl, dt, warm, finite, keep = single_leg(a.workload, F, a.steps, a.warmup, every, bank_voices, not a.no_recipe_warmup)
+    db, bank, tables, g, out = keep
+    value = bank_voices * F * a.steps / dt
+    rl.pop("value"); rl.pop("ms_per_step"); rl.pop("realtime_factor_48k"); rl.pop("voices")
+    rl["note"] = ("LUTs are LDS-resident and the recurrences live in registers, so compulsory HBM traffic is one state sweep per "
+                  "launch: at F=512 the kernel is bound by fp32 VALU issue (profiles/), not by HBM; the HBM fraction grows as F "
+                  "shrinks (low_latency).  PCM banks (c4) gather from an L2-resident pool: see c4.l2_requests")
+    res = {
+        "metric": "voice-samples/s", "value": value, "unit": "voice-samples/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+        "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": DESCR[a.workload] + (f" [voices overridden: {bank_voices}]" if a.voices else ""),
+                   "voices_total": bank_voices, "voices_per_gpu": bank_voices, "frames_per_launch": F, "sample_rate": 48000,
+                   "interp": "linear" if interp else "truncate",
+                   "parallelism": "one GPU: one launch per block (render + mix-down + master volume in the render kernel)",
+                   "seed": "0x5EED", "recipe_warmup_frames": warm[0], "spinup_blocks": warm[1]},
+        "realtime_factor_48k": value / (bank_voices * 48000.0), "output_finite": finite, "roofline": rl,
+    }
+    if not a.no_extra:
+        # ---- other block lengths on the same bank (state keeps running): F = 64 (1.33 ms callbacks: the per-launch state
+        # sweep dominates and the kernel approaches the HBM roofline) and F = 4800 (100 ms blocks), SURVEY §8(d)
+        for key, fr, steps, warmup, te in (("low_latency", 64, max(50, a.steps), 20, min(8, max(1, max(50, a.steps) // 10))),
+                                           ("long_block", 4800, max(12, a.steps // 10), 2, 2)):
+            if fr == F:
+                continue
+            o2 = torch.zeros(fr, 2, device=dev, dtype=torch.float32)
+
+            def block2(frames, _o=o2):
+                db.render_mix(frames, _o.data_ptr(), 2, 0, interp, stream)
+            dt2, km, kn, kc = timed(block2, db, fr, steps, warmup, te)
+            r2 = roofline(a.workload, bank_voices, fr, gather_bytes, km, kn, kc, KERNELS.get(db.last_kernel(), "?"))
+            r2["value"] = bank_voices * fr * steps / dt2
+            r2["ms_per_step"] = dt2 / steps * 1e3
+            r2["realtime_factor_48k"] = r2["value"] / (bank_voices * 48000.0)
+            res[key] = r2
+
+        # ---- the recipe from its FIRST frame: ~11 % of the voices are in attack / decay at t0 and reach sustain over the
+        # first 0.11 s; these are the launches the main line renders untimed (sk_render_env2_kernel takes the slices with a
+        # moving envelope).  Fresh state per repetition; the blocks of the first 0.117 s are timed.
+        n_blocks = -(-int(RECIPE_WARMUP_S * 48000) // F)
+        reps = []
+        for _ in range(3):
+            db.upload(bank)
+            db.set_globals(g)
+            db.kernel_timing(0)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(n_blocks):
+                db.render_mix(F, out.data_ptr(), 2, 0, interp, stream)
+            fence()
+            reps.append((time.perf_counter() - t0) / n_blocks)
+        reps.sort()
+        res["envelopes_in_motion"] = {"value": bank_voices * F / reps[1], "unit": "voice-samples/s", "ms_per_step": reps[1] * 1e3,
+                                      "ms_per_step_min": reps[0] * 1e3, "blocks_timed": n_blocks, "repetitions": 3,
+                                      "what": f"the first {n_blocks} blocks of the recipe (note-ons staggered over the last second, "
+                                              "attack + decay 0.11 s): launches with envelope ramps in flight, no recipe warm-up"}
+
+        # ---- control traffic: every block 0.05 % of the voices get a note-off (stamped on the device) or a note-on with
+        # new parameters, through skred_bank_update on the render stream (DESIGN.md section 8)
+        for _ in range(12):                                    # back to the all-sustain state
+            db.render_mix(F, out.data_ptr(), 2, 0, interp, stream)
+        k_ev = max(2, int(bank_voices * 0.0005))
+        rng = np.random.default_rng(1)
+        D = device
+
+        def control_block(frames):
+            vs = rng.choice(bank_voices, k_ev, replace=False).astype(np.int32)
+            db.update(bank, vs[:k_ev // 2], D.STAMP_RELEASE, stream)
+            db.update(bank, vs[k_ev // 2:], D.STAMP_TRIGGER | D.DIRTY_PHASE | D.DIRTY_PARAMS, stream)
+            db.render_mix(frames, out.data_ptr(), 2, 0, interp, stream)
+        steps_c = max(60, a.steps)
+        dtc, kmc, knc, kcc = timed(control_block, db, F, steps_c, 20, 0)
+        res["live_control"] = {"value": bank_voices * F * steps_c / dtc, "unit": "voice-samples/s", "ms_per_step": dtc / steps_c * 1e3,
+                               "voices_touched_per_block": k_ev, "note_events_per_s": k_ev * steps_c / dtc,
+                               "what": "0.05 % of the voices per block: half note-offs (SKRED_STAMP_RELEASE), half note-ons with new "
+                                       "parameters (SKRED_STAMP_TRIGGER | DIRTY_PHASE | DIRTY_PARAMS) via skred_bank_update, then the block"}
+    db.close()
+    del bank
+
+    if not a.no_extra:
+        # ---- the other BASELINE workloads, each on its own bank at BASELINE's size, F = 512
+        for wl in ("c1", "c2", "c3", "c4"):
+            if wl == a.workload or (wl == "c3" and a.workload == "c3"):
+                continue
+            steps_w = max(100, a.steps)
+            r, _, _, fin, kp = single_leg(wl, 512, steps_w, 20, min(8, max(1, steps_w // 10)))
+            kp[0].close()
+            r["workload"] = DESCR[wl]
+            r["output_finite"] = fin
+            res[wl] = r
+
+    # ---- the fixed-point LUT path (include/skred_amd_fxpt.h; integer mix, exact)
+    if not a.no_extra and not a.no_fixed_point and a.workload != "c4":
         from skred_amd import fxbank
         fb, fpool, fcount0 = fxbank.bank_fx(bank_voices)
         fdb = fxbank.DeviceFxBank(bank_voices, local)
@@ -378,24 +468,18 @@ def main():
             fdb.render(F, fmix.data_ptr(), 1, 0, stream)
         fence()
         t0 = time.perf_counter()
-        kms = []
         for _ in range(a.steps):
             fdb.render(F, fmix.data_ptr(), 1, 0, stream)
         fence()
         fdt = time.perf_counter() - t0
-        kms.append(fdb.last_render_ms())
-        res["fixed_point"] = {"value": bank_voices * F * a.steps / fdt, "unit": "voice-samples/s", "dtype": "q15/u32/i64",
+        res["fixed_point"] = {"value": bank_voices * F * a.steps / fdt, "unit": "voice-samples/s", "dtype": fxbank.DTYPE_NOTE,
                               "frames_per_launch": F, "ms_per_step": fdt / a.steps * 1e3, "kernel": "sk_fx_render_kernel",
-                              "kernel_ms_last": kms[-1], "mix_nonzero": bool((fmix != 0).any().item()),
-                              "workload": "fixed-point analogue of the C2 recipe without the biquad (fxbank.bank_fx), linear interpolation"}
+                              "kernel_ms_last": fdb.last_render_ms(), "mix_nonzero": bool((fmix != 0).any().item()),
+                              "workload": fxbank.WORKLOAD_NOTE}
         fdb.close()
-    if rank == 0:
-        if world == 1 and not a.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(recipe, interp)
-        os.write(result_fd, (json.dumps(res) + "\n").encode())
-    db.close()
-    if use_dist:
-        dist.destroy_process_group()
+    if not a.no_cpu:
+        res["cpu_baseline"] = cpu_baseline(recipe, interp)
+    os.write(result_fd, (json.dumps(res) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -285,6 +285,45 @@ int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of th
  * (skred_amd_last_error() names the launch), after which the latch is re-armed by itself. */
 unsigned skred_bank_env_latch_misses(const skred_bank_t *bank);
 
+/* ---- voices sharded over the GPUs of one node (BASELINE config 3) -----------------------------------
+ *
+ * One process per GPU.  Rank r of `world` owns the contiguous block [lo, hi) of the bank's voices and renders its
+ * PRE-master partial mix float[F][2]; the one exchange step of the path is the sum of those partials on `root` (one
+ * RCCL reduce of 8*F bytes per block, over xGMI), after which the root applies the master volume stage once.  This is
+ * the host side of BASELINE config 3 in C: what the reference's audio callback (skred.c:107-116: synth() then the
+ * output) becomes when the voices of one bank live on several GPUs.  A cut is only legal where no voice is modulated
+ * across it (skred_shard_cut_ok; skred_shard_upload refuses otherwise).
+ *
+ * The three steps of a block are function pointers so that the same sequencing runs elsewhere: skred_shard_create()
+ * wires them to the bank-mode entry points and to ncclReduce (after skred_shard_init_rccl); a program with its own
+ * communicator replaces `reduce`; the CPU tests (tests/test_sharded_gloo.py) supply all three. */
+typedef struct skred_shard skred_shard_t;
+typedef struct skred_shard_ops {
+  void *ctx;            /* passed to render and master */
+  int (*render)(void *ctx, int num_frames, int interp, float *partial, void *stream);   /* this rank's pre-master sum -> partial[F][2] */
+  int (*master)(void *ctx, const float *sum, int num_frames, int num_channels, float *out, void *stream);   /* root only: synth.c:616-624 */
+  void *reduce_ctx;     /* passed to reduce */
+  int (*reduce)(void *reduce_ctx, float *partial, size_t n_floats, int root, void *stream);   /* sum over ranks, in place on the root */
+} skred_shard_ops_t;
+
+int  skred_shard_partition(int total_voices, int world, int rank, int *lo, int *hi);   /* blocks differ by at most one voice */
+int  skred_shard_cut_ok(const skred_voice_bank_t *whole_bank, int lo, int hi);         /* 1: no modulation crosses the cut */
+int  skred_shard_create(int device, int rank, int world, int root, int total_voices, skred_shard_t **out);   /* + this rank's bank on `device` */
+int  skred_shard_create_custom(int rank, int world, int root, int total_voices, const skred_shard_ops_t *ops, skred_shard_t **out);
+void skred_shard_destroy(skred_shard_t *shard);
+skred_bank_t *skred_shard_bank(skred_shard_t *shard);        /* tables, globals, options, updates: through the bank ABI above */
+int  skred_shard_range(const skred_shard_t *shard, int *lo, int *hi);
+int  skred_shard_upload(skred_shard_t *shard, const skred_voice_bank_t *whole_bank);   /* this rank's block of the WHOLE bank */
+int  skred_shard_set_ops(skred_shard_t *shard, const skred_shard_ops_t *ops, int always_reduce);   /* NULL members keep the current step */
+/* RCCL owned by the library: rank 0 draws an id, the host program carries its 128 bytes to the other ranks, every
+ * rank initialises with it (collective call). */
+int  skred_shard_rccl_unique_id(void *out128);
+int  skred_shard_init_rccl(skred_shard_t *shard, const void *unique_id128);
+/* One block: render -> reduce -> master on the root.  `partial`: float[num_frames][2] scratch in the memory the steps
+ * work on (NULL: the shard's own device scratch); `out` ([num_frames][num_channels]) is written on the root only.
+ * Asynchronous on `stream` with the bank-backed steps. */
+int  skred_shard_render_mix(skred_shard_t *shard, int num_frames, int interp, float *partial, float *out, int num_channels, void *stream);
+
 /* Timing of the most recent skred_bank_render() on its stream, via hipEvents
  * recorded around the render kernel itself (ms; <0 if unavailable). Synchronises. */
 float skred_bank_last_render_ms(skred_bank_t *bank);

@@ -527,6 +527,12 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
   pk.a12 = (v2f){r.a1, r.a2}; pk.a21 = (v2f){r.a2, r.a1};                                 \
   pk.pan = (v2f){r.pan_l, r.pan_r};   /* (the block paths run only in waves without pan modulation) */
 #define SK_FAST_PACK_OUT() { r.x1 = xx.x; r.x2 = xx.y; r.y1 = yy.x; r.y2 = yy.y; }
+/* after fast_finish rewrote a finishing lane's numbers (rare): the pairs again */
+#define SK_FAST_REPACK()                                                                  \
+  { xx = (v2f){r.x1, r.x2}; yy = (v2f){r.y1, r.y2};                                       \
+    pk.b12 = (v2f){r.b1, r.b2}; pk.b21 = (v2f){r.b2, r.b1};                               \
+    pk.a12 = (v2f){r.a1, r.a2}; pk.a21 = (v2f){r.a2, r.a1};                               \
+    pk.pan = (v2f){r.pan_l, r.pan_r}; }
 // Eight steady frames of the extended frame loop (modulation exchange, finish test, sample & hold ... per frame) with
 // the same tile reduction instead of 12 v_add_dpp per frame; the per-wave LDS region is free here (no table windows
 // in such a wave).
@@ -557,11 +563,11 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, s0_, r.x1, r.x2, r.y1, r.y2, released, l0, r0);            \
-      if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, s0_, xx, yy, l0, r0);                         \
+      if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); SK_FAST_REPACK() } \
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post<FILTER, ENV, true, STALL_, STOPS, true>(r, s1_, r.x2, r.x1, r.y2, r.y1, released, l1, r1);            \
-      if (STOPS && __any(r.fin)) fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, s1_, xx, yy, l1, r1);                        \
+      if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); SK_FAST_REPACK() } \
       { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
     }                                                                                                    \
   }
@@ -777,8 +783,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       } else if (STOPS && (!ENV || steady)) {
         int j = 0;
         if (!TAB_LDS && tame && !any_fm && !stems_on) {   // a voice about to finish is `direct` in its window block; the block checks per frame
+          SK_FAST_PACK_IN()
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
+          SK_FAST_PACK_OUT()
         } else {
           int pend_j = -1;
           for (; j + 8 <= cn; j += 8) SK_FAST_X_BLOCK(j)
@@ -789,9 +797,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       } else if ((!ENV || steady) && tame && !stems_on) {
         int j = 0;
         if (!TAB_LDS) {
+          SK_FAST_PACK_IN()
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
-          SK_FAST_PACK_IN()
           for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
           SK_FAST_PACK_OUT()
         } else {

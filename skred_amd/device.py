@@ -26,6 +26,9 @@ ABI_SYMBOLS = [
     "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
     "skred_bank_set_option", "skred_bank_last_kernel", "skred_bank_env_latch_misses",
     "skred_bank_update", "skred_bank_defer", "skred_bank_run_queue", "skred_bank_queue_pending",
+    "skred_shard_partition", "skred_shard_cut_ok", "skred_shard_create", "skred_shard_create_custom", "skred_shard_destroy",
+    "skred_shard_bank", "skred_shard_range", "skred_shard_upload", "skred_shard_set_ops", "skred_shard_rccl_unique_id",
+    "skred_shard_init_rccl", "skred_shard_render_mix",
 ]
 
 # SKRED_DIRTY_* / SKRED_STAMP_* of include/skred_amd.h
@@ -109,9 +112,21 @@ class DeviceBank:
         _check(self.L.skred_bank_create(device, self.n, C.byref(h)), "skred_bank_create")
         self.h = h
 
+    @classmethod
+    def borrowed(cls, handle, n_voices: int, device: int = 0) -> "DeviceBank":
+        """A view of a bank somebody else owns (skred_shard_bank): close() does not destroy it."""
+        self = cls.__new__(cls)
+        self.L = load()
+        self.n = int(n_voices)
+        self.device = device
+        self.h = C.c_void_p(handle)
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "h", None):
-            self.L.skred_bank_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.L.skred_bank_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -158,6 +158,11 @@ def fx_lut_pool() -> Tuple[np.ndarray, dict]:
     return np.concatenate(parts).astype(np.int16), info
 
 
+# what bench.py's `fixed_point` leg says about itself
+DTYPE_NOTE = "q15/u32/i64"
+WORKLOAD_NOTE = "fixed-point analogue of the C2 recipe without the biquad (fxbank.bank_fx), linear interpolation"
+
+
 def bank_fx(n: int = 65536, sample_rate: int = 48000, seed: int = banks.SEED):
     """Fixed-point analogue of the C2 recipe without the filter: v mod 3 -> sine / triangle / impulse
     int16 pyramids (level by frequency), ADSR 0.01/0.1/0.7/0.2 s, staggered note-ons, smoother k=0.02."""

@@ -1,102 +1,179 @@
-"""Voices sharded over the GPUs of one node: one process per GPU, one RCCL reduce per launch.
+"""Voices sharded over the GPUs of one node: ctypes image of skred_amd/csrc/skred_shard.c (include/skred_amd.h:
+skred_shard_*).  One process per GPU; rank r renders the contiguous block [lo, hi) of the bank into a PRE-master
+partial mix float[F][2]; the only exchange step is ONE reduce(sum) of 8*F bytes per block onto the root (RCCL over
+xGMI, owned by the C library), after which the root applies the master-volume stage (synth.c:616-624) once.
 
-The render loop shards naturally: voices are independent unless they name each
-other as modulators, so rank r renders the contiguous block [lo, hi) of the bank and produces a
-PRE-master partial mix float[F][2].  The only exchange step of the path is the sum of those
-partials -- `torch.distributed.reduce(SUM, dst=0)` (backend "nccl" == RCCL over xGMI; 8*F bytes,
-latency-bound) -- after which rank 0 runs the serial master-volume stage (synth.c:616-624) once.
-
-The same class drives the GPU path (bench.py: callables wrap the C ABI) and the world_size-2
-gloo tests on CPU (tests/test_sharded_gloo.py: callables wrap the oracle).
+No logic lives here: the partition rule, the check that no modulation crosses a cut and the per-block sequence
+render -> reduce -> master are the C library's.  `Shard` is the GPU form bench.py drives; `ShardedRender` plugs Python
+callables into the same C sequencing so that the world_size-2/3 gloo tests rehearse it on CPUs with the oracle as the
+renderer (tests/test_sharded_gloo.py).
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence, Tuple
+import ctypes as C
+from typing import Callable, Optional, Tuple
 
-import torch
-import torch.distributed as dist
+import numpy as np
+
+from . import device
+from .bank import VoiceBank
+
+RENDER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+MASTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+
+class ShardOps(C.Structure):
+    """== skred_shard_ops_t"""
+    _fields_ = [("ctx", C.c_void_p), ("render", RENDER_FN), ("master", MASTER_FN),
+                ("reduce_ctx", C.c_void_p), ("reduce", REDUCE_FN)]
+
+
+def _lib():
+    L = device.load()
+    if not getattr(L, "_shard_ready", False):
+        vp, i32 = C.c_void_p, C.c_int
+        L.skred_shard_partition.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+        L.skred_shard_cut_ok.argtypes = [vp, i32, i32]
+        L.skred_shard_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+        L.skred_shard_create_custom.argtypes = [i32, i32, i32, i32, C.POINTER(ShardOps), C.POINTER(vp)]
+        L.skred_shard_destroy.argtypes = [vp]
+        L.skred_shard_destroy.restype = None
+        L.skred_shard_bank.argtypes = [vp]
+        L.skred_shard_bank.restype = vp
+        L.skred_shard_range.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+        L.skred_shard_upload.argtypes = [vp, vp]
+        L.skred_shard_set_ops.argtypes = [vp, C.POINTER(ShardOps), i32]
+        L.skred_shard_rccl_unique_id.argtypes = [vp]
+        L.skred_shard_init_rccl.argtypes = [vp, vp]
+        L.skred_shard_render_mix.argtypes = [vp, i32, i32, vp, vp, i32, vp]
+        L._shard_ready = True
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise device.SkredAmdError(f"{what} failed (rc={rc}): {_lib().skred_amd_last_error().decode(errors='replace')}")
 
 
 def partition(total: int, world: int, rank: int) -> Tuple[int, int]:
-    """Contiguous block of voices for `rank`: [lo, hi).  Blocks differ by at most one voice."""
-    return total * rank // world, total * (rank + 1) // world
+    """Contiguous block of voices for `rank`: [lo, hi) (skred_shard_partition)."""
+    lo, hi = C.c_int(), C.c_int()
+    _check(_lib().skred_shard_partition(total, world, rank, C.byref(lo), C.byref(hi)), "skred_shard_partition")
+    return lo.value, hi.value
 
 
-def modulation_components_ok(bank, lo: int, hi: int) -> bool:
-    """A cut is only legal where no voice inside [lo,hi) is modulated by one outside (and vice versa)."""
-    a = bank.a
-    for key in ("voice_freq_mod_osc", "voice_amp_mod_osc", "voice_pan_mod_osc", "voice_cz_mod_osc"):
-        m = a[key][lo:hi]
-        used = m >= 0
-        if key == "voice_cz_mod_osc":
-            used &= a["voice_cz_mode"][lo:hi] != 0
-        if (used & ((m < lo) | (m >= hi))).any():
-            return False
-    return True
+def modulation_components_ok(bank: VoiceBank, lo: int, hi: int) -> bool:
+    """A cut is only legal where no voice inside [lo,hi) is modulated by one outside (skred_shard_cut_ok)."""
+    cb = bank.as_c()
+    return bool(_lib().skred_shard_cut_ok(C.byref(cb), lo, hi))
 
 
-class ShardedRender:
-    def __init__(self, total_voices: int, rank: int = 0, world: int = 1, root: int = 0, always_reduce: bool = False):
+class Shard:
+    """The GPU form: this rank's block of the bank on `device_index`, the library's own RCCL reduce between the ranks."""
+
+    def __init__(self, total_voices: int, rank: int = 0, world: int = 1, device_index: int = 0, root: int = 0):
+        self.L = _lib()
         self.total, self.rank, self.world, self.root = total_voices, rank, world, root
-        self.reduce = world > 1 or always_reduce        # always_reduce: rehearse the collective with one rank
-        self.lo, self.hi = partition(total_voices, world, rank)
-        self._bufs: Optional[Sequence[torch.Tensor]] = None
-        self._work: List[Optional[object]] = [None, None]
-        self._k = 0
+        h = C.c_void_p()
+        _check(self.L.skred_shard_create(device_index, rank, world, root, total_voices, C.byref(h)), "skred_shard_create")
+        self.h = h
+        lo, hi = C.c_int(), C.c_int()
+        self.L.skred_shard_range(self.h, C.byref(lo), C.byref(hi))
+        self.lo, self.hi = lo.value, hi.value
+        self.bank = device.DeviceBank.borrowed(self.L.skred_shard_bank(self.h), self.hi - self.lo, device_index)
+        self._keep = None
 
     @property
     def n_local(self) -> int:
         return self.hi - self.lo
 
-    def step(self, render_partial: Callable[[torch.Tensor], None],
-             master: Callable[[torch.Tensor, torch.Tensor], None],
-             partial: torch.Tensor, out: torch.Tensor) -> None:
-        """One pass of the hot path: local render -> (sum over ranks) -> master on the root."""
-        render_partial(partial)
-        if self.reduce:
-            dist.reduce(partial, dst=self.root, op=dist.ReduceOp.SUM)
-        if self.rank == self.root:
-            master(partial, out)
+    def upload(self, whole: VoiceBank):
+        cb = whole.as_c()
+        _check(self.L.skred_shard_upload(self.h, C.byref(cb)), "skred_shard_upload")
 
-    # ---- overlapped form ("launch k+1 renders while launch k reduces") ----
-    #
-    # Two partial buffers alternate.  Block k is rendered into buffer k&1 and its reduce is started
-    # asynchronously; the root runs the master stage for block k-1 meanwhile, so a block's mix is
-    # delivered one call later (and the last one by drain()).  With RCCL, Work.wait() only makes the
-    # current HIP stream wait for the collective -- the host never blocks -- so render k+1 and
-    # reduce k run concurrently on the device.  Output samples are identical to step()'s.
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(_lib().skred_shard_rccl_unique_id(buf), "skred_shard_rccl_unique_id")
+        return buf.raw
 
-    def begin(self, partials: Sequence[torch.Tensor]) -> None:
-        assert len(partials) == 2 and self._k == 0
-        self._bufs = partials
+    def init_rccl(self, unique_id: bytes):
+        assert len(unique_id) == 128
+        _check(self.L.skred_shard_init_rccl(self.h, C.create_string_buffer(unique_id, 128)), "skred_shard_init_rccl")
 
-    def _deliver(self, j: int, master, out) -> None:
-        if self._work[j] is not None:
-            self._work[j].wait()
-            self._work[j] = None
-        if self.rank == self.root:
-            master(self._bufs[j], out)
+    def set_reduce(self, reduce: Optional[Callable[[int, int, int], None]], always_reduce: bool = False):
+        """Replace the collective: reduce(ptr, n_floats, root) sums the ranks' buffers in place on the root (rehearsals)."""
+        ops = ShardOps()
+        if reduce is not None:
+            def _red(_ctx, ptr, n, root, _stream):
+                reduce(ptr, n, root)
+                return 0
+            ops.reduce = REDUCE_FN(_red)
+        self._keep = ops
+        _check(self.L.skred_shard_set_ops(self.h, C.byref(ops), int(always_reduce)), "skred_shard_set_ops")
 
-    def step_overlapped(self, render_partial: Callable[[torch.Tensor], None],
-                        master: Callable[[torch.Tensor, torch.Tensor], None], out: torch.Tensor) -> bool:
-        """Render block k, start its reduce, finish block k-1.  True when `out` now holds block k-1."""
-        i = self._k & 1
-        if self._work[i] is not None:          # the reduce of block k-2 still owns this buffer
-            self._work[i].wait()
-            self._work[i] = None
-        render_partial(self._bufs[i])
-        if self.reduce:
-            self._work[i] = dist.reduce(self._bufs[i], dst=self.root, op=dist.ReduceOp.SUM, async_op=True)
-        delivered = self._k > 0
-        if delivered:
-            self._deliver(1 - i, master, out)
-        self._k += 1
-        return delivered
+    def render_mix(self, frames: int, d_out: int, channels: int = 2, interp: int = 0, stream: int = 0, d_partial: int = 0):
+        _check(self.L.skred_shard_render_mix(self.h, frames, interp, d_partial or None, d_out or None, channels, stream or None),
+               "skred_shard_render_mix")
 
-    def drain(self, master: Callable[[torch.Tensor, torch.Tensor], None], out: torch.Tensor) -> bool:
-        """Finish the block still in flight.  True when `out` now holds it."""
-        if self._k == 0:
-            return False
-        self._deliver((self._k - 1) & 1, master, out)
-        self._k = 0
-        return True
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.skred_shard_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedRender:
+    """The C sequencing with caller-supplied steps (host memory): render(frames, interp, partial[F,2]),
+    reduce(partial[F,2], root), master(sum[F,2], out[F,ch]).  Used by the CPU rehearsal with the oracle."""
+
+    def __init__(self, total_voices: int, rank: int, world: int, render, master, reduce=None, root: int = 0):
+        self.L = _lib()
+        self.total, self.rank, self.world, self.root = total_voices, rank, world, root
+        self.lo, self.hi = partition(total_voices, world, rank)
+
+        def arr(ptr, rows, cols):
+            return np.ctypeslib.as_array((C.c_float * (rows * cols)).from_address(ptr)).reshape(rows, cols)
+
+        def _render(_ctx, frames, interp, partial, _stream):
+            render(frames, interp, arr(partial, frames, 2))
+            return 0
+
+        def _master(_ctx, total, frames, channels, out, _stream):
+            master(arr(total, frames, 2), arr(out, frames, channels))
+            return 0
+
+        def _reduce(_ctx, partial, n, root_, _stream):
+            reduce(arr(partial, n // 2, 2), root_)
+            return 0
+
+        self._ops = ShardOps()
+        self._ops.render = RENDER_FN(_render)
+        self._ops.master = MASTER_FN(_master)
+        if reduce is not None:
+            self._ops.reduce = REDUCE_FN(_reduce)
+        h = C.c_void_p()
+        _check(self.L.skred_shard_create_custom(rank, world, root, total_voices, C.byref(self._ops), C.byref(h)),
+               "skred_shard_create_custom")
+        self.h = h
+
+    @property
+    def n_local(self) -> int:
+        return self.hi - self.lo
+
+    def step(self, partial: np.ndarray, out: np.ndarray, interp: int = 0) -> None:
+        """One block: render -> reduce -> master on the root, sequenced by skred_shard_render_mix."""
+        assert partial.dtype == np.float32 and out.dtype == np.float32 and partial.flags.c_contiguous and out.flags.c_contiguous
+        _check(self.L.skred_shard_render_mix(self.h, partial.shape[0], interp, partial.ctypes.data, out.ctypes.data,
+                                             out.shape[1], None), "skred_shard_render_mix")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.skred_shard_destroy(self.h)
+            self.h = None

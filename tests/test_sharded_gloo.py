@@ -1,6 +1,6 @@
-"""N>1 path on CPU: world_size-2 (and 3, ragged) gloo jobs.  Each rank renders its block of voices,
-the partial mixes are summed with torch.distributed.reduce, rank 0 applies the master stage; the
-result must match the single-process render of the whole bank within the float-mix tolerance."""
+"""N>1 path on CPU: world_size-2 (and 3, ragged) gloo jobs driving the C sharding code (skred_shard_*: partition,
+cut check, render -> reduce -> master sequencing) with the oracle as renderer and gloo as the collective; the result
+must match the single-process render of the whole bank within the float-mix tolerance."""
 import os
 import socket
 import subprocess
@@ -34,10 +34,23 @@ def test_partition_covers_bank():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.parametrize("world,n,mode", [(2, 2048, "sync"), (3, 1000, "sync"), (2, 2048, "overlapped"),
-                                          (3, 1000, "overlapped")])
-def test_sharded_matches_single_process(tmp_path, world, n, mode):
-    frames, steps = 256, 4 if mode == "overlapped" else 3
+def test_cut_check_refuses_modulation_across_ranks():
+    from skred_amd.sharded import modulation_components_ok
+    bank, _, _ = banks.bank_c2(512)
+    assert modulation_components_ok(bank, 0, 256) and modulation_components_ok(bank, 256, 512)
+    bank["voice_freq_mod_osc"][10] = 300                       # carrier on rank 0, modulator on rank 1
+    assert not modulation_components_ok(bank, 0, 256)
+    assert modulation_components_ok(bank, 256, 512)            # rank 1's block itself is self-contained
+    bank["voice_freq_mod_osc"][10] = -1
+    bank["voice_cz_mod_osc"][300] = 5                           # a CZ source only counts with CZ on (synth.c:262)
+    assert modulation_components_ok(bank, 256, 512)
+    bank["voice_cz_mode"][300] = 2
+    assert not modulation_components_ok(bank, 256, 512)
+
+
+@pytest.mark.parametrize("world,n", [(2, 2048), (3, 1000)])
+def test_sharded_matches_single_process(tmp_path, world, n):
+    frames, steps = 256, 3
     out = str(tmp_path / "mix.npy")
     port = free_port()
     procs = []
@@ -45,7 +58,7 @@ def test_sharded_matches_single_process(tmp_path, world, n, mode):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), out,
-                                       str(n), str(frames), str(steps), mode], env=env))
+                                       str(n), str(frames), str(steps)], env=env))
     for p in procs:
         assert p.wait(timeout=240) == 0
     got = np.load(out)

@@ -24,7 +24,20 @@
  *   output   v = (s * gain) >> 15 (product in 64 bits) ; L = (v * pan_left_q15) >> 15 ; R = (v * pan_right_q15) >> 15
  *            every other product is an int32 one (keep it inside 32 bits: Q15 gains, velocity <= 65535)
  *   mix      int64 sum of L and of R over all voices, per frame
- *   skipped  amp_q15 == 0: v = 0, state frozen (as synth.c:537-542 does for the float path)
+ *   skipped  amp_q15 == 0 or finished: v = 0, state frozen (as synth.c:531-542 does for the float path)
+ *   one-shot a voice with one_shot != 0 plays ONE cycle of its table: in the frame where phase + phase_inc carries out of
+ *            32 bits the phase is left at 0xFFFFFFFF, that frame is still rendered from the table's last entry (linear:
+ *            the neighbour does not fold back to entry 0, b = a), `finished` is set and from the next frame on the voice
+ *            is skipped -- the image of osc_next()'s finish rule for forward playback (synth.c:241-256)
+ *   biquad   filter_mode != 0: direct form I on the (interpolated) table sample s, |s| <= 32767, in the order of the
+ *            float path (synth.c:349-364: after the oscillator, before the gain).  Coefficients Q2.30 in int32 (the RBJ
+ *            b/a0, a/a0 of mmf_set_params, synth.c:929-1008: all inside (-2, 2)); delay line in Q12 sample units, int32,
+ *            |x|, |y| < 2^29; accumulation in int64 (five products < 2^60 each):
+ *              x0  = s << 12
+ *              acc = b0*x0 + b1*x1 + b2*x2 - a1*y1 - a2*y2
+ *              y0  = clamp((acc + 2^29) >> 30, -2^29, 2^29 - 1)       round to nearest, saturating
+ *              x2 = x1, x1 = x0, y2 = y1, y1 = y0
+ *              s   = clamp(y0 >> 12, -32768, 32767)                   back to sample units: a resonant overshoot saturates
  */
 #ifndef SKRED_AMD_FXPT_H
 #define SKRED_AMD_FXPT_H
@@ -54,6 +67,11 @@ typedef struct skred_fxpt_bank {
   int32_t  *smoother_k_q15;
   int32_t  *smoother_gain_q15;  /* rw */
   int32_t  *voice_sample;       /* rw: v of the last rendered frame */
+  int32_t  *one_shot;           /* plays one cycle, then finishes */
+  int32_t  *finished;           /* rw */
+  int32_t  *filter_mode;        /* 0 = no filter (the kind of filter is in the coefficients) */
+  int32_t  *b0_q30, *b1_q30, *b2_q30, *a1_q30, *a2_q30;
+  int32_t  *x1, *x2, *y1, *y2;  /* rw: delay line, Q12 sample units */
 } skred_fxpt_bank_t;
 
 typedef struct skred_fxbank skred_fxbank_t;   /* opaque device-side bank */

@@ -37,6 +37,26 @@ static int32_t fx_envelope(skred_fxpt_bank_t *b, int v, uint64_t now) {
   return 0;
 }
 
+/* direct form I biquad in Q2.30 x Q12 with int64 accumulation (include/skred_amd_fxpt.h: "biquad"); s in, s out */
+static int32_t fx_biquad(skred_fxpt_bank_t *b, int v, int32_t s) {
+  const int64_t x0 = (int64_t)s * 4096;                       /* s << 12, also for negative s */
+  int64_t acc = (int64_t)b->b0_q30[v] * x0;
+  acc += (int64_t)b->b1_q30[v] * b->x1[v];
+  acc += (int64_t)b->b2_q30[v] * b->x2[v];
+  acc -= (int64_t)b->a1_q30[v] * b->y1[v];
+  acc -= (int64_t)b->a2_q30[v] * b->y2[v];
+  int64_t y0 = (acc + ((int64_t)1 << 29)) >> 30;
+  const int64_t lim = (int64_t)1 << 29;
+  if (y0 < -lim) y0 = -lim;
+  if (y0 > lim - 1) y0 = lim - 1;
+  b->x2[v] = b->x1[v]; b->x1[v] = (int32_t)x0;
+  b->y2[v] = b->y1[v]; b->y1[v] = (int32_t)y0;
+  int32_t o = (int32_t)(y0 >> 12);
+  if (o < -32768) o = -32768;
+  if (o > 32767) o = 32767;
+  return o;
+}
+
 /* mix: int64 [F][2]; stems: int32 [F][n][2] or NULL.  *count is synth_sample_count (advanced). */
 int skred_cpuref_fx_render(skred_fxpt_bank_t *b, const int16_t *pool, uint64_t *count, int num_frames,
                            int interp, int64_t *mix, int32_t *stems) {
@@ -48,20 +68,27 @@ int skred_cpuref_fx_render(skred_fxpt_bank_t *b, const int16_t *pool, uint64_t *
     int64_t sum_l = 0, sum_r = 0;
     for (int v = 0; v < n; v++) {
       int32_t l = 0, r = 0;
-      if (b->amp_q15[v] == 0) {
+      if (b->amp_q15[v] == 0 || b->finished[v]) {
         b->voice_sample[v] = 0;
       } else {
         const int L = b->log2_size[v];
         const int16_t *lut = pool + b->table_offset[v];
-        const uint32_t ph = b->phase[v] + b->phase_inc[v];
+        uint32_t ph = b->phase[v] + b->phase_inc[v];
+        int ends = 0;
+        if (b->one_shot[v] && ph < b->phase[v]) {        /* the add carried: the one cycle is over */
+          ph = 0xFFFFFFFFu;
+          b->finished[v] = 1;
+          ends = 1;
+        }
         b->phase[v] = ph;
         const uint32_t idx = ph >> (32 - L);
         int32_t s = lut[idx];
         if (interp) {
-          const int32_t nxt = lut[(idx + 1) & ((1u << L) - 1)];
+          const int32_t nxt = ends ? s : lut[(idx + 1) & ((1u << L) - 1)];
           const int32_t frac = (int32_t)((uint32_t)(ph << L) >> 17);
           s = s + (((nxt - s) * frac) >> 15);
         }
+        if (b->filter_mode[v]) s = fx_biquad(b, v, s);
         int32_t e = 32768;
         if (b->use_envelope[v]) e = (fx_envelope(b, v, now) * b->velocity_q15[v]) >> 15;
         int32_t gain = (int32_t)(((int64_t)b->amp_q15[v] * e) >> 15);

@@ -48,6 +48,25 @@ __device__ __forceinline__ int fxmul_s15(int a, int b) { return NARROW ? (__mul2
 
 __device__ __forceinline__ bool fits24(int x) { return x >= -(1 << 23) && x < (1 << 23); }
 
+// The definition's biquad (include/skred_amd_fxpt.h: "biquad"): Q2.30 coefficients x Q12 delay line, int64 accumulation
+// (v_mad_i64_i32), round to nearest, saturate to +-2^29, back to sample units with saturation to int16.  Returns the
+// filtered sample and the new newest entries x0 / y0.
+struct FxFilt { int b0, b1, b2, a1, a2; };
+__device__ __forceinline__ int fx_biquad(const FxFilt &f, int s, int x1, int x2, int y1, int y2, int &x0, int &y0) {
+  x0 = s * 4096;                                           // |s| <= 32767: exact, also for negative s
+  long long acc = (long long)f.b0 * x0;
+  acc += (long long)f.b1 * x1;
+  acc += (long long)f.b2 * x2;
+  acc -= (long long)f.a1 * y1;
+  acc -= (long long)f.a2 * y2;
+  long long y = (acc + (1ll << 29)) >> 30;
+  y = y < -(1ll << 29) ? -(1ll << 29) : y;
+  y = y > (1ll << 29) - 1 ? (1ll << 29) - 1 : y;
+  y0 = (int)y;
+  const int o = y0 >> 12;
+  return o < -32768 ? -32768 : (o > 32767 ? 32767 : o);
+}
+
 #define SKX_WAVE_SYNC()                                     \
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
@@ -61,15 +80,16 @@ struct FxVoice {
   uint32_t mask;
   int pan_l, pan_r, k;     // k = 0 for a skipped voice: its smoother stays frozen
   bool smooth, silent;     // silent: skipped or muted -> (0, 0) out
+  bool filt;               // runs the biquad
 };
 
 // Eight frames of a wave whose envelope levels are constant over the chunk (`target` = (amp * e) >> 15 per lane):
 // oscillator, smoother, output, per-voice (L, R) parked in the wave-private tile xp[8][65]; then the same
 // transposition sum as the float kernels (skred_render_fast2.hip), in integers -- any order is exact.
-template <bool STEMS, bool NARROW, bool INTERP, bool STALL>
-__device__ __forceinline__ void fx_block(const skx_args_t &a, const FxVoice &vc, const int16_t *lut, uint32_t &phase,
-                                         int &sg, int &sample, const int target, int2 *xp, int2 *xq, int2 *wsum_row,
-                                         const int lane, const int v, const int frame0) {
+template <bool STEMS, bool NARROW, bool INTERP, bool STALL, bool FILTER>
+__device__ __forceinline__ void fx_block(const skx_args_t &a, const FxVoice &vc, const FxFilt &ff, const int16_t *lut, uint32_t &phase,
+                                         int &sg, int &sample, int &x1, int &x2, int &y1, int &y2, const int target, int2 *xp,
+                                         int2 *xq, int2 *wsum_row, const int lane, const int v, const int frame0) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     phase += vc.inc;
@@ -79,6 +99,11 @@ __device__ __forceinline__ void fx_block(const skx_args_t &a, const FxVoice &vc,
       const int nxt = lut[(idx + 1) & vc.mask];
       const int frac = (int)((uint32_t)(phase << vc.L) >> 17);
       s = s + (__mul24(nxt - s, frac) >> 15);            // |nxt - s| < 2^17, frac < 2^15: always within 24 bits
+    }
+    if (FILTER) {                                        // (bank-wide: some voice is filtered; per lane: vc.filt)
+      int x0, y0;
+      const int fs = fx_biquad(ff, s, x1, x2, y1, y2, x0, y0);
+      if (vc.filt) { x2 = x1; x1 = x0; y2 = y1; y1 = y0; s = fs; }
     }
     int gain = target;
     if (vc.smooth) {
@@ -140,7 +165,7 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
     const uint4 p2 = *reinterpret_cast<const uint4 *>(&a.ro[SKX_ENV][v]);
     const uint4 p3 = *reinterpret_cast<const uint4 *>(&a.ro[SKX_RECIP][v]);
     const uint4 p4 = *reinterpret_cast<const uint4 *>(&a.ro[SKX_TIME][v]);
-    const uint4 st = *reinterpret_cast<const uint4 *>(&a.rw[v]);
+    const uint4 st = *reinterpret_cast<const uint4 *>(&a.rw[0][v]);
     const uint32_t inc = p0.x;
     const int toff = (int)p0.y, L = (int)(p0.z & 31u);
     const uint32_t flags = p0.z >> 8;
@@ -154,7 +179,19 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
     uint32_t phase = st.x;
     int sg = (int)st.y, sample = (int)st.z;
     uint32_t active = st.w & 1u;
-    const bool dead = amp == 0 || (flags & SKXF_INERT);
+    bool finished = (st.w & 2u) != 0;
+    const bool one_shot = (flags & SKXF_ONE_SHOT) != 0;
+    FxFilt ff = {0, 0, 0, 0, 0};
+    int x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+    const bool filt = (flags & SKXF_FILTER) != 0;
+    if (a.any_filter) {
+      const uint4 f0 = *reinterpret_cast<const uint4 *>(&a.ro[SKX_FILT][v]);
+      const uint4 f1 = *reinterpret_cast<const uint4 *>(&a.ro[SKX_FILT2][v]);
+      const uint4 fs = *reinterpret_cast<const uint4 *>(&a.rw[1][v]);
+      ff.b0 = (int)f0.x; ff.b1 = (int)f0.y; ff.b2 = (int)f0.z; ff.a1 = (int)f0.w; ff.a2 = (int)f1.x;
+      x1 = (int)fs.x; x2 = (int)fs.y; y1 = (int)fs.z; y2 = (int)fs.w;
+    }
+    const bool dead = amp == 0 || (flags & SKXF_INERT) || finished;
     // (a skipped lane runs the block code on inert numbers: entries 0..1 of the pool, whatever its own table fields say)
     const int16_t *lut = (lut_in_lds ? lut_lds : a.tables) + (dead ? 0 : toff);
     const uint32_t mask = (1u << L) - 1u;
@@ -165,6 +202,7 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
     vc.pan_l = pan_l; vc.pan_r = pan_r; vc.k = dead ? 0 : k;
     vc.smooth = (flags & SKXF_SMOOTH) != 0;
     vc.silent = dead || (flags & SKXF_MUTED);
+    vc.filt = filt && !dead;
     // NARROW blocks (24-bit multiplies): pan gains within 24 bits, 0 <= k <= 32768 (the smoother state then stays between
     // itself and its target), and |smoother state|, |target| <= 65535, so that s * gain fits 32 bits like the int16
     // sample times a Q16 gain it is meant to be; anything else takes the blocks with the definition's full-width products
@@ -175,9 +213,14 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
       // steady: the envelope level of every live lane is one constant over this chunk -- no envelope, an inactive one
       // (it stays inactive), or a held note past its decay (t only grows; note-off arrives between launches)
       const uint32_t t_first = sat32(a.count0 + (uint64_t)c0 + 1 - t_start);
-      const bool steady = __all(dead || !uses_env || !active || (t_release == 0 && (uint64_t)t_first >= AD));
+      // (a wave with a live one-shot voice checks for its end frame by frame: no blocks)
+      const bool steady = __all(dead || !uses_env || !active || (t_release == 0 && (uint64_t)t_first >= AD)) &&
+                          !__any(one_shot && !dead && !finished);
       int j = 0;
       if (steady && cn >= 8) {
+        if (finished && !dead) {       // a one-shot that ended earlier in this launch: from here on a skipped lane (state frozen)
+          vc.inc = 0u; vc.k = 0; vc.silent = true; vc.filt = false;
+        }
         const int lvl = active ? S : 0;
         const int e = uses_env ? (lvl * vel) >> 15 : 32768;
         const int target = fxmul64_s15(amp, e);
@@ -185,7 +228,8 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
         const bool narrow_c = narrow && __all(dead || (target >= -65535 && target <= 65535));
         int2 *row = wsum + wave * SKX_CHUNK;
 #define SKX_BLOCKS(NARROW_, INTERP_, STALL_)                                                                       \
-  for (; j + 8 <= cn; j += 8) fx_block<STEMS, NARROW_, INTERP_, STALL_>(a, vc, lut, phase, sg, sample, target, xp, xq, row + j, lane, v, c0 + j);
+  if (a.any_filter) { for (; j + 8 <= cn; j += 8) fx_block<STEMS, NARROW_, INTERP_, STALL_, true>(a, vc, ff, lut, phase, sg, sample, x1, x2, y1, y2, target, xp, xq, row + j, lane, v, c0 + j); } \
+  else { for (; j + 8 <= cn; j += 8) fx_block<STEMS, NARROW_, INTERP_, STALL_, false>(a, vc, ff, lut, phase, sg, sample, x1, x2, y1, y2, target, xp, xq, row + j, lane, v, c0 + j); }
         if (narrow_c) {
           if (a.interp) { if (stalled) SKX_BLOCKS(true, true, true) else SKX_BLOCKS(true, true, false) }
           else          { if (stalled) SKX_BLOCKS(true, false, true) else SKX_BLOCKS(true, false, false) }
@@ -193,18 +237,29 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
           if (a.interp) SKX_BLOCKS(false, true, false) else SKX_BLOCKS(false, false, false)
         }
 #undef SKX_BLOCKS
+        if (finished && j > 0) sample = 0;   // (the blocks leave smp in `sample`; a skipped voice's is 0)
       }
       for (; j < cn; ++j) {
         const uint64_t now = a.count0 + (uint64_t)(c0 + j) + 1;
         int l = 0, r = 0;
-        if (!dead) {
-          phase += inc;
+        if (dead || finished) {
+          if (finished) sample = 0;                      // skipped from the frame after its last one on
+        } else {
+          uint32_t ph = phase + inc;
+          bool ends = false;
+          if (one_shot && ph < phase) { ph = 0xFFFFFFFFu; finished = true; ends = true; }   // the add carried: the cycle is over
+          phase = ph;
           const uint32_t idx = phase >> (32 - L);
           int s = lut[idx];
           if (a.interp) {
-            const int nxt = lut[(idx + 1) & mask];
+            const int nxt = ends ? s : lut[(idx + 1) & mask];
             const int frac = (int)((uint32_t)(phase << L) >> 17);
             s = s + (((nxt - s) * frac) >> 15);
+          }
+          if (filt) {
+            int x0, y0;
+            s = fx_biquad(ff, s, x1, x2, y1, y2, x0, y0);
+            x2 = x1; x1 = x0; y2 = y1; y1 = y0;
           }
           int e = 32768;
           if (flags & SKXF_USE_ENV) {
@@ -260,8 +315,9 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
     }
     if (dead) sample = 0;
     uint4 o;
-    o.x = phase; o.y = (uint32_t)sg; o.z = (uint32_t)sample; o.w = active;
-    *reinterpret_cast<uint4 *>(&a.rw[v]) = o;
+    o.x = phase; o.y = (uint32_t)sg; o.z = (uint32_t)sample; o.w = active | (finished ? 2u : 0u);
+    *reinterpret_cast<uint4 *>(&a.rw[0][v]) = o;
+    if (a.any_filter && filt) *reinterpret_cast<uint4 *>(&a.rw[1][v]) = make_uint4((uint32_t)x1, (uint32_t)x2, (uint32_t)y1, (uint32_t)y2);
     first_pass = false;
   }
 }

@@ -10,14 +10,20 @@ enum {
   SKX_ENV,      /* u32 attack_frames | u32 decay_frames | u32 release_frames | i32 sustain_q15    */
   SKX_RECIP,    /* u32 floor(2^32/attack) | floor(2^32/decay) | floor(2^32/release) | 0           */
   SKX_TIME,     /* u32 sample_start lo,hi | u32 sample_release lo,hi                               */
+  SKX_FILT,     /* i32 b0 | b1 | b2 | a1   (Q2.30)                                                 */
+  SKX_FILT2,    /* i32 a2 (Q2.30) | 0 | 0 | 0                                                       */
   SKX_COUNT
 };
-/* read-write plane: u32 phase | i32 smoother_gain_q15 | i32 voice_sample | u32 is_active */
+/* read-write planes: [0] u32 phase | i32 smoother_gain_q15 | i32 voice_sample | u32 bit 0 is_active, bit 1 finished
+ *                    [1] i32 x1 | x2 | y1 | y2   (biquad delay line, Q12 sample units) */
+#define SKX_RW_COUNT 2
 
 #define SKXF_USE_ENV (1u << 0)
 #define SKXF_SMOOTH  (1u << 1)
 #define SKXF_MUTED   (1u << 2)
 #define SKXF_INERT   (1u << 3)
+#define SKXF_FILTER  (1u << 4)
+#define SKXF_ONE_SHOT (1u << 5)
 
 #define SKX_GROUP 256
 #define SKX_CHUNK 64
@@ -28,12 +34,13 @@ typedef struct { uint32_t w[4]; } skx_plane_t;
 
 typedef struct {
   const skx_plane_t *ro[SKX_COUNT];
-  skx_plane_t *rw;
+  skx_plane_t *rw[SKX_RW_COUNT];
   const int16_t *tables;
   long long *partial;     /* [n_workgroups][num_frames][2] */
   int32_t *stems;         /* [num_frames][n_voices][2] or NULL */
   uint64_t count0;
   int32_t n_voices, n_groups, num_frames, interp;
   int32_t lds_bytes_tables;   /* bytes of the pool staged in LDS (multiple of 16), 0 = gather from L2/HBM */
+  int32_t any_filter;         /* some voice of the bank runs the biquad (selects the block instantiation) */
 } skx_args_t;
 #endif

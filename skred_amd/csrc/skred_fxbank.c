@@ -22,7 +22,8 @@ int skred_amd_set_error(int code, const char *fmt, ...);   /* skred_bank.c */
 struct skred_fxbank {
   int device, n_voices, n_padded, n_groups;
   skx_plane_t *d_ro[SKX_COUNT];
-  skx_plane_t *d_rw;
+  skx_plane_t *d_rw[SKX_RW_COUNT];
+  int n_filter;                 /* voices with filter_mode != 0 (recounted on whole-bank uploads, grown otherwise) */
   int16_t *d_tables;
   size_t table_entries, table_bytes_padded;
   long long *d_partial; size_t partial_cap;
@@ -63,7 +64,7 @@ int skred_fxbank_create(int device, int n_voices, skred_fxbank_t **out) {
   fx->n_padded = fx->n_groups * SKX_GROUP;
   const size_t bytes = (size_t)fx->n_padded * sizeof(skx_plane_t);
   for (int p = 0; p < SKX_COUNT; p++) { HIP_TRY(hipMalloc((void **)&fx->d_ro[p], bytes)); HIP_TRY(hipMemset(fx->d_ro[p], 0, bytes)); }
-  HIP_TRY(hipMalloc((void **)&fx->d_rw, bytes)); HIP_TRY(hipMemset(fx->d_rw, 0, bytes));
+  for (int p = 0; p < SKX_RW_COUNT; p++) { HIP_TRY(hipMalloc((void **)&fx->d_rw[p], bytes)); HIP_TRY(hipMemset(fx->d_rw[p], 0, bytes)); }
   skx_plane_t *inert = (skx_plane_t *)calloc((size_t)fx->n_padded, sizeof(skx_plane_t));
   if (!inert) return skred_amd_set_error(SKRED_E_NO_MEM, "calloc");
   for (int v = 0; v < fx->n_padded; v++) inert[v].w[2] = 3u | (SKXF_INERT << 8);   /* log2_size 3, amp 0 */
@@ -79,7 +80,7 @@ void skred_fxbank_destroy(skred_fxbank_t *fx) {
   if (!fx) return;
   hipSetDevice(fx->device);
   for (int p = 0; p < SKX_COUNT; p++) if (fx->d_ro[p]) hipFree(fx->d_ro[p]);
-  if (fx->d_rw) hipFree(fx->d_rw);
+  for (int p = 0; p < SKX_RW_COUNT; p++) if (fx->d_rw[p]) hipFree(fx->d_rw[p]);
   if (fx->d_tables) hipFree(fx->d_tables);
   if (fx->d_partial) hipFree(fx->d_partial);
   if (fx->d_redtmp) hipFree(fx->d_redtmp);
@@ -110,8 +111,9 @@ int skred_fxbank_upload(skred_fxbank_t *fx, const skred_fxpt_bank_t *h, int src_
     return skred_amd_set_error(SKRED_E_RANGE, "fx upload window outside bank");
   if (count == 0) return SKRED_OK;
   HIP_TRY(hipSetDevice(fx->device));
-  skx_plane_t *st = (skx_plane_t *)calloc((size_t)(SKX_COUNT + 1) * (size_t)count, sizeof(skx_plane_t));
+  skx_plane_t *st = (skx_plane_t *)calloc((size_t)(SKX_COUNT + SKX_RW_COUNT) * (size_t)count, sizeof(skx_plane_t));
   if (!st) return skred_amd_set_error(SKRED_E_NO_MEM, "fx upload staging");
+  if (dst_first == 0 && count == fx->n_voices) fx->n_filter = 0;          /* whole bank replaced */
   for (int i = 0; i < count; i++) {
     const int v = src_first + i;
     const int L = h->log2_size[v];
@@ -125,6 +127,14 @@ int skred_fxbank_upload(skred_fxbank_t *fx, const skred_fxpt_bank_t *h, int src_
     if (h->use_envelope[v]) flags |= SKXF_USE_ENV;
     if (h->smoother_enable[v]) flags |= SKXF_SMOOTH;
     if (h->disconnect[v]) flags |= SKXF_MUTED;
+    if (h->filter_mode[v]) { flags |= SKXF_FILTER; fx->n_filter++; }
+    if (h->one_shot[v]) flags |= SKXF_ONE_SHOT;
+    {
+      const int64_t lim = (int64_t)1 << 29;      /* the delay line the definition can produce: |x|, |y| < 2^29 */
+      const int32_t d[4] = { h->x1[v], h->x2[v], h->y1[v], h->y2[v] };
+      for (int k = 0; k < 4; k++)
+        if (d[k] < -lim || d[k] >= lim) { free(st); return skred_amd_set_error(SKRED_E_RANGE, "fx voice %d: filter state %d outside +-2^29", v, d[k]); }
+    }
 #define P(p) st[(size_t)(p) * count + i]
     P(SKX_OSC).w[0] = h->phase_inc[v]; P(SKX_OSC).w[1] = (uint32_t)h->table_offset[v];
     P(SKX_OSC).w[2] = (uint32_t)L | (flags << 8); P(SKX_OSC).w[3] = (uint32_t)h->amp_q15[v];
@@ -136,15 +146,21 @@ int skred_fxbank_upload(skred_fxbank_t *fx, const skred_fxpt_bank_t *h, int src_
     P(SKX_RECIP).w[2] = recip32(h->release_frames[v]);
     P(SKX_TIME).w[0] = (uint32_t)h->sample_start[v]; P(SKX_TIME).w[1] = (uint32_t)(h->sample_start[v] >> 32);
     P(SKX_TIME).w[2] = (uint32_t)h->sample_release[v]; P(SKX_TIME).w[3] = (uint32_t)(h->sample_release[v] >> 32);
+    P(SKX_FILT).w[0] = (uint32_t)h->b0_q30[v]; P(SKX_FILT).w[1] = (uint32_t)h->b1_q30[v];
+    P(SKX_FILT).w[2] = (uint32_t)h->b2_q30[v]; P(SKX_FILT).w[3] = (uint32_t)h->a1_q30[v];
+    P(SKX_FILT2).w[0] = (uint32_t)h->a2_q30[v];
     P(SKX_COUNT).w[0] = h->phase[v]; P(SKX_COUNT).w[1] = (uint32_t)h->smoother_gain_q15[v];
-    P(SKX_COUNT).w[2] = (uint32_t)h->voice_sample[v]; P(SKX_COUNT).w[3] = h->is_active[v] ? 1u : 0u;
+    P(SKX_COUNT).w[2] = (uint32_t)h->voice_sample[v]; P(SKX_COUNT).w[3] = (h->is_active[v] ? 1u : 0u) | (h->finished[v] ? 2u : 0u);
+    P(SKX_COUNT + 1).w[0] = (uint32_t)h->x1[v]; P(SKX_COUNT + 1).w[1] = (uint32_t)h->x2[v];
+    P(SKX_COUNT + 1).w[2] = (uint32_t)h->y1[v]; P(SKX_COUNT + 1).w[3] = (uint32_t)h->y2[v];
 #undef P
   }
   const size_t bytes = (size_t)count * sizeof(skx_plane_t);
   hipError_t e = hipSuccess;
   for (int p = 0; p < SKX_COUNT && e == hipSuccess; p++)
     e = hipMemcpy(fx->d_ro[p] + dst_first, st + (size_t)p * count, bytes, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(fx->d_rw + dst_first, st + (size_t)SKX_COUNT * count, bytes, hipMemcpyHostToDevice);
+  for (int p = 0; p < SKX_RW_COUNT && e == hipSuccess; p++)
+    e = hipMemcpy(fx->d_rw[p] + dst_first, st + (size_t)(SKX_COUNT + p) * count, bytes, hipMemcpyHostToDevice);
   free(st);
   HIP_TRY(e);
   return SKRED_OK;
@@ -156,17 +172,22 @@ int skred_fxbank_download(skred_fxbank_t *fx, skred_fxpt_bank_t *h, int src_firs
     return skred_amd_set_error(SKRED_E_RANGE, "fx download window outside bank");
   if (count == 0) return SKRED_OK;
   HIP_TRY(hipSetDevice(fx->device));
-  skx_plane_t *st = (skx_plane_t *)malloc((size_t)count * sizeof(skx_plane_t));
+  skx_plane_t *st = (skx_plane_t *)malloc((size_t)SKX_RW_COUNT * (size_t)count * sizeof(skx_plane_t));
   if (!st) return skred_amd_set_error(SKRED_E_NO_MEM, "fx download staging");
   HIP_TRY(hipDeviceSynchronize());
-  hipError_t e = hipMemcpy(st, fx->d_rw + src_first, (size_t)count * sizeof(skx_plane_t), hipMemcpyDeviceToHost);
+  hipError_t e = hipSuccess;
+  for (int p = 0; p < SKX_RW_COUNT && e == hipSuccess; p++)
+    e = hipMemcpy(st + (size_t)p * count, fx->d_rw[p] + src_first, (size_t)count * sizeof(skx_plane_t), hipMemcpyDeviceToHost);
   if (e != hipSuccess) { free(st); HIP_TRY(e); }
   for (int i = 0; i < count; i++) {
     const int v = dst_first + i;
+    const skx_plane_t *f = &st[(size_t)count + i];
     h->phase[v] = st[i].w[0];
     h->smoother_gain_q15[v] = (int32_t)st[i].w[1];
     h->voice_sample[v] = (int32_t)st[i].w[2];
     h->is_active[v] = (int32_t)(st[i].w[3] & 1u);
+    h->finished[v] = (int32_t)((st[i].w[3] >> 1) & 1u);
+    h->x1[v] = (int32_t)f->w[0]; h->x2[v] = (int32_t)f->w[1]; h->y1[v] = (int32_t)f->w[2]; h->y2[v] = (int32_t)f->w[3];
   }
   free(st);
   return SKRED_OK;
@@ -187,7 +208,9 @@ int skred_fxbank_render(skred_fxbank_t *fx, int num_frames, int interp, int64_t 
   skx_args_t a;
   memset(&a, 0, sizeof(a));
   for (int p = 0; p < SKX_COUNT; p++) a.ro[p] = fx->d_ro[p];
-  a.rw = fx->d_rw; a.tables = fx->d_tables; a.partial = fx->d_partial; a.stems = d_stems;
+  for (int p = 0; p < SKX_RW_COUNT; p++) a.rw[p] = fx->d_rw[p];
+  a.any_filter = fx->n_filter > 0;
+  a.tables = fx->d_tables; a.partial = fx->d_partial; a.stems = d_stems;
   a.count0 = fx->count; a.n_voices = fx->n_voices; a.n_groups = fx->n_groups;
   a.num_frames = num_frames; a.interp = interp ? 1 : 0;
   a.lds_bytes_tables = fx->table_bytes_padded <= SKX_LDS_TABLE_MAX_BYTES ? (int32_t)fx->table_bytes_padded : 0;

@@ -23,6 +23,9 @@ FX_FIELDS = [
     ("sample_start", U64, False), ("sample_release", U64, False),
     ("is_active", I32, True), ("smoother_enable", I32, False), ("smoother_k_q15", I32, False),
     ("smoother_gain_q15", I32, True), ("voice_sample", I32, True),
+    ("one_shot", I32, False), ("finished", I32, True), ("filter_mode", I32, False),
+    ("b0_q30", I32, False), ("b1_q30", I32, False), ("b2_q30", I32, False), ("a1_q30", I32, False), ("a2_q30", I32, False),
+    ("x1", I32, True), ("x2", I32, True), ("y1", I32, True), ("y2", I32, True),
 ]
 FX_RW = [f[0] for f in FX_FIELDS if f[2]]
 FX_ABI_SYMBOLS = ["skred_fxbank_create", "skred_fxbank_destroy", "skred_fxbank_set_tables_i16",
@@ -159,15 +162,25 @@ def fx_lut_pool() -> Tuple[np.ndarray, dict]:
 
 
 # what bench.py's `fixed_point` leg says about itself
-DTYPE_NOTE = "q15/u32/i64"
-WORKLOAD_NOTE = "fixed-point analogue of the C2 recipe without the biquad (fxbank.bank_fx), linear interpolation"
+DTYPE_NOTE = "q15 gains / u32 phase / q2.30 x q12 biquad / i64 mix"
+WORKLOAD_NOTE = ("fixed-point analogue of the C2 recipe (fxbank.bank_fx): int16 LUT pyramids, linear interpolation, "
+                 "per-voice biquad (modes 1-4), ADSR, amp smoother")
 
 
-def bank_fx(n: int = 65536, sample_rate: int = 48000, seed: int = banks.SEED):
-    """Fixed-point analogue of the C2 recipe without the filter: v mod 3 -> sine / triangle / impulse
-    int16 pyramids (level by frequency), ADSR 0.01/0.1/0.7/0.2 s, staggered note-ons, smoother k=0.02."""
+def q30_coeffs(mode, freq, q, sample_rate) -> Dict[str, np.ndarray]:
+    """RBJ coefficients (banks.biquad_coeffs == mmf_set_params, synth.c:929-1008) rounded to Q2.30."""
+    co = banks.biquad_coeffs(mode, freq, q, sample_rate)
+    return {k + "_q30": np.clip(np.round(co[k].astype(np.float64) * (1 << 30)), -(1 << 31), (1 << 31) - 1).astype(np.int32)
+            for k in ("b0", "b1", "b2", "a1", "a2")}
+
+
+def bank_fx(n: int = 65536, sample_rate: int = 48000, seed: int = banks.SEED, with_filter: bool = True):
+    """Fixed-point analogue of the C2 recipe: v mod 3 -> sine / triangle / impulse int16 pyramids (level by frequency),
+    biquad mode 1 + v mod 4 with K ~ logU[100, 8000] Hz and Q ~ U[0.5, 4] (the float recipe's draws), ADSR
+    0.01/0.1/0.7/0.2 s, staggered note-ons, smoother k=0.02."""
     pool, info = fx_lut_pool()
-    u = banks.lcg_uniform(3 * n, seed).reshape(3, n)
+    u5 = banks.lcg_uniform(5 * n, seed).reshape(5, n)
+    u = u5[:3]
     freq = (np.float32(27.5) * np.exp2(np.float32(7.0) * u[0])).astype(np.float64)
     b = FxVoiceBank(n)
     fam = np.arange(n) % 3
@@ -199,4 +212,11 @@ def bank_fx(n: int = 65536, sample_rate: int = 48000, seed: int = banks.SEED):
     b["is_active"] = 1
     b["smoother_enable"] = 1
     b["smoother_k_q15"] = int(round(0.02 * 32768))
+    if with_filter:
+        mode = (1 + np.arange(n) % 4).astype(np.int32)
+        cutoff = (np.float32(100.0) * np.power(np.float32(80.0), u5[3])).astype(np.float32)
+        q = (np.float32(0.5) + np.float32(3.5) * u5[4]).astype(np.float32)
+        for k, v in q30_coeffs(mode, cutoff, q, sample_rate).items():
+            b[k] = v
+        b["filter_mode"] = mode
     return b, pool, count0

@@ -32,6 +32,46 @@ def _release_odd(bank, now):
     bank["sample_release"][1::2] = now
 
 
+def test_fx_definition_biquad_and_one_shots():
+    """CPU definition: the Q2.30 biquad tracks the float biquad of the same coefficients; a one-shot plays one cycle,
+    sounds on its last frame from the table's last entry and is skipped afterwards with its state frozen."""
+    from skred_amd import banks
+    n = 64
+    b, pool, c0 = fxbank.bank_fx(n)
+    b["use_envelope"][:] = 0
+    b["smoother_enable"][:] = 0
+    b["amp_q15"][:] = 32768
+    b["pan_left_q15"][:] = 32768
+    b["disconnect"][:] = 0
+    mix, stems, _ = cpuref.fx_render(b.copy(), pool, c0, 2000, 1, want_stems=True)
+    nb = b.copy()
+    nb["filter_mode"][:] = 0
+    _, dry, _ = cpuref.fx_render(nb, pool, c0, 2000, 1, want_stems=True)
+    co = {k: b[k + "_q30"].astype(np.float64) / (1 << 30) for k in ("b0", "b1", "b2", "a1", "a2")}
+    x = dry[:, :, 0].astype(np.float64)
+    y = np.zeros_like(x)
+    for i in range(2000):
+        y[i] = co["b0"] * x[i] + (co["b1"] * x[i - 1] if i > 0 else 0) + (co["b2"] * x[i - 2] if i > 1 else 0) \
+            - (co["a1"] * y[i - 1] if i > 0 else 0) - (co["a2"] * y[i - 2] if i > 1 else 0)
+    unclipped = np.abs(y).max(0) < 32000
+    err = np.abs(stems[:, :, 0] - y)[:, unclipped].max()
+    assert unclipped.sum() > n // 2 and err < 4.0, (int(unclipped.sum()), float(err))   # a few LSBs of a 16-bit sample
+    # one-shots
+    o = b.copy()
+    o["filter_mode"][:] = 0
+    o["one_shot"][::2] = 1
+    o["phase"][:] = 0
+    o["phase_inc"][:] = np.uint32((1 << 32) // 100 + 12345)          # ~100 frames per cycle
+    ob = o.copy()
+    _, st, _ = cpuref.fx_render(ob, pool, c0, 300, 1, want_stems=True)
+    assert (ob["finished"][::2] == 1).all() and (ob["finished"][1::2] == 0).all()
+    assert (ob["phase"][::2] == 0xFFFFFFFF).all() and (ob["voice_sample"][::2] == 0).all()
+    last = int(np.ceil((1 << 32) / float(o["phase_inc"][0]))) - 1   # 0-based frame whose add carries
+    assert (st[last + 1:, ::2, :] == 0).all() and (np.abs(st[:last + 1, ::2, :]).sum(0) > 0).all()
+    lut_last = np.array([pool[o["table_offset"][v] + (1 << o["log2_size"][v]) - 1] for v in range(0, n, 2)], np.int64)
+    assert (st[last, ::2, 0] == lut_last).all()                    # amp 1.0, pan_left 1.0, no interpolation across the end
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,interp", [(4096, 0), (4096, 1), (65536, 1), (1000, 1)])
 def test_fx_gpu_bit_exact(n, interp):
@@ -39,6 +79,11 @@ def test_fx_gpu_bit_exact(n, interp):
     b["disconnect"][::7] = 1
     b["amp_q15"][::11] = 0
     b["smoother_enable"][::13] = 0
+    b["filter_mode"][::5] = 0                              # some voices unfiltered: per-lane select in the blocks
+    one = np.arange(3, n, 17)                              # stopping one-shots, periods of 50 .. 1500 frames
+    b["one_shot"][one] = 1
+    b["phase_inc"][one] = ((1 << 32) // (50 + (one * 37) % 1450)).astype(np.uint32)
+    b["phase"][one] = (one.astype(np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
     want_stems = n <= 4096
     segs = [(301, None), (333, _release_odd), (10001, None), (64, None)]
     # definition
@@ -111,6 +156,73 @@ def test_fx_wide_parameters_bit_exact(interp):
     db.download(host)
     db.close()
     assert not host.rw_mismatch(rb), host.rw_mismatch(rb)
+
+
+@pytest.mark.gpu
+def test_fx_gpu_bit_exact_at_bench_size():
+    """2^20 voices -- the size bench.py's `fixed_point` leg times: integer mix and read-write state, no stems."""
+    n = 1 << 20
+    b, pool, c0 = fxbank.bank_fx(n)
+    b["amp_q15"][::11] = 0
+    one = np.arange(5, n, 29)
+    b["one_shot"][one] = 1
+    b["phase_inc"][one] = ((1 << 32) // (40 + (one * 13) % 900)).astype(np.uint32)
+    segs = [(300, None), (212, _release_odd)]
+    rb, count = b.copy(), c0
+    db = fxbank.DeviceFxBank(n)
+    db.set_tables(pool)
+    host = b.copy()
+    db.upload(host)
+    db.set_sample_count(c0)
+    for frames, ev in segs:
+        if ev:
+            ev(rb, count)
+            db.download(host)
+            ev(host, db.sample_count())
+            db.upload(host)
+        ref, _, count = cpuref.fx_render(rb, pool, count, frames, 1, fast=True)
+        got, _ = db.render_host(frames, 1)
+        assert (got == ref).all()
+    db.download(host)
+    db.close()
+    assert not host.rw_mismatch(rb), host.rw_mismatch(rb)
+    assert int(rb["finished"].sum()) > 10000
+
+
+@pytest.mark.gpu
+def test_fx_filter_state_saturates_like_the_definition():
+    """Resonant filters driven hard: the Q12 delay line hits +-2^29 and the sample clamp to int16 acts -- the kernel must
+    saturate exactly where the definition does (block and frame-by-frame paths)."""
+    n = 2048
+    b, pool, c0 = fxbank.bank_fx(n)
+    co = fxbank.q30_coeffs(np.full(n, 1), 40.0 + 3.0 * np.arange(n, dtype=np.float32), np.full(n, 60.0, np.float32), 48000)
+    for k, v in co.items():
+        b[k] = v
+    b["filter_mode"][:] = 1
+    b["x1"][:] = (1 << 29) - 1                               # start at the rail
+    b["y1"][::2] = -(1 << 29)
+    b["use_envelope"][n // 2:] = 0                           # half the bank on the steady blocks from the first frame
+    rb, count = b.copy(), c0
+    db = fxbank.DeviceFxBank(n)
+    db.set_tables(pool)
+    db.upload(b)
+    db.set_sample_count(c0)
+    for frames in (700, 64, 9):
+        ref, rst, count = cpuref.fx_render(rb, pool, count, frames, 1, want_stems=True)
+        got, gst = db.render_host(frames, 1, want_stems=True)
+        assert (got == ref).all() and (gst == rst).all()
+    host = b.copy()
+    db.download(host)
+    db.close()
+    assert not host.rw_mismatch(rb), host.rw_mismatch(rb)
+    assert (np.abs(rb["y1"]) >= (1 << 29) - 1).any() or (np.abs(rst).max() > 20000)
+    bad = fxbank.FxVoiceBank(4)
+    bad["y2"][1] = 1 << 30                                   # outside what the definition can produce: refused
+    d2 = fxbank.DeviceFxBank(4)
+    d2.set_tables(np.zeros(16, np.int16))
+    with pytest.raises(device.SkredAmdError):
+        d2.upload(bad)
+    d2.close()
 
 
 @pytest.mark.gpu

@@ -265,6 +265,40 @@ int  skred_bank_defer(skred_bank_t *bank, uint64_t when, const skred_voice_bank_
 int  skred_bank_run_queue(skred_bank_t *bank, int frame_count, void *stream);
 int  skred_bank_queue_pending(const skred_bank_t *bank);
 
+/* ---- the pattern step clock: the other half of seq() (seq.c:179-213) ---------------------------------------------
+ *
+ * skred_seq_t is the reference's sequencer state on the host, with the same arithmetic: a double clock that gains
+ * (float)frame_count / (float)rate per call and fires when it reaches tempo_time_per_step (tempo_set: 1 / (bpm / 60) / 4
+ * seconds, four steps per beat; 60 s until a tempo is set), one step per call at most; per RUNNING pattern the modulo
+ * (default 4) divides the step rate, a muted step advances silently, the pointer wraps at the first empty step.  No
+ * device is involved: tests hold it against the compiled reference call by call.
+ * A bank owns one (skred_bank_seq); a step of a bank's pattern is a batch of voice updates captured when it is written,
+ * and skred_bank_run_queue() -- called once per block after the render, like seq() at skred.c:119 -- applies the
+ * deferred items that are due and then the steps the clock fires, in pattern order, on `stream`. */
+#define SKRED_PATTERNS_MAX 16          /* skred.h:75 */
+#define SKRED_SEQ_STEPS_MAX 256        /* skred.h:76 */
+enum { SKRED_SEQ_STOPPED = 0, SKRED_SEQ_RUNNING = 1, SKRED_SEQ_PAUSED = 2 };   /* skred.h:80-82 */
+typedef struct skred_seq skred_seq_t;
+int   skred_seq_create(skred_seq_t **out);
+void  skred_seq_destroy(skred_seq_t *seq);
+int   skred_seq_tempo_set(skred_seq_t *seq, float bpm);                       /* tempo_set, seq.c:21-28 */
+float skred_seq_time_per_step(const skred_seq_t *seq);
+int   skred_seq_step_set(skred_seq_t *seq, int pattern, int step, int occupied);   /* seq_step_set: empty text = not occupied */
+int   skred_seq_mute_set(skred_seq_t *seq, int pattern, int step, int mute);  /* seq_mute_set */
+int   skred_seq_modulo_set(skred_seq_t *seq, int pattern, int modulo);        /* seq_modulo_set */
+int   skred_seq_state_set(skred_seq_t *seq, int pattern, int state);          /* seq_state_set: 0 stop, 1 start, 2 pause, 3 resume */
+int   skred_seq_pattern_reset(skred_seq_t *seq, int pattern);                 /* pattern_reset */
+int   skred_seq_pointer(const skred_seq_t *seq, int pattern);
+int   skred_seq_counter(const skred_seq_t *seq, int pattern);
+/* one call per block: fired[] receives (pattern << 16) | step of every step whose text the reference would run */
+int   skred_seq_tick(skred_seq_t *seq, int frame_count, float sample_rate, int32_t *fired, int max_fired);
+
+skred_seq_t *skred_bank_seq(skred_bank_t *bank);                    /* the bank's own clock (tempo, mute, modulo, state through skred_seq_*) */
+int  skred_bank_set_sample_rate(skred_bank_t *bank, float rate);   /* the rate the clock counts blocks in; default 44100 (MAIN_SAMPLE_RATE, skred.h:6) */
+int  skred_bank_pattern_step_set(skred_bank_t *bank, int pattern, int step, const skred_voice_bank_t *host,
+                                 const int32_t *voices, int n_voices, uint32_t dirty);   /* n_voices == 0: a rest */
+int  skred_bank_pattern_step_clear(skred_bank_t *bank, int pattern, int step);           /* empty step: the pattern wraps here */
+
 /* Options.  The render loop has full-featured kernels (generic; modulated for banks with cross-voice modulation) and
  * specialised ones chosen per launch from what the bank holds (one voice per lane, two per lane);
  * their per-voice results, stems included, are bit-identical.  FORCE_GENERIC pins the full-featured kernels (the parity

@@ -133,6 +133,7 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_stems) hipFree(b->d_stems);
   free(b->h_class); free(b->h_mod); free(b->h_level);
   sk_queue_free(b);
+  sk_patterns_free(b);
   for (int i = 0; i < SK_UPD_RING; i++) {
     if (b->upd[i].d) hipFree(b->upd[i].d);
     if (b->upd[i].h) hipHostFree(b->upd[i].h);

@@ -73,6 +73,9 @@ struct skred_bank {
   uint8_t quiet_skipped[SK_QUIET_RING];   /* that launch ran with skip_env2 (a deferral it reports was NOT rendered) */
   int quiet_head, quiet_tail, quiet_pending;
   uint32_t quiet_misses;      /* launches that ran without sk_render_env2_kernel although a slice needed it (self-check; must stay 0) */
+  skred_seq_t *seq;             /* the pattern step clock (skred_seq.c), created on first use */
+  struct sk_pat_step *pat;      /* [SKRED_PATTERNS_MAX][SKRED_SEQ_STEPS_MAX] batches the steps apply (skred_bank_update.c) */
+  float seq_rate;               /* sample rate the step clock counts blocks in (0: the reference's 44100) */
   struct sk_queue_item *queue;  /* deferred updates (skred_bank_update.c), singly linked in arrival order */
   struct sk_queue_item *queue_tail;
   int queue_len;
@@ -120,6 +123,7 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
  * follows the host's values; otherwise the bit the voice had is kept.  params_travel: everything else of `meta` applies. */
 void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *meta, int params_travel, int clock_travels);
 void sk_queue_free(skred_bank_t *b);
+void sk_patterns_free(skred_bank_t *b);
 /* a control action reached the bank: what earlier launches reported about envelope activity no longer holds */
 static inline void sk_control_changed(skred_bank_t *b) { b->control_epoch++; b->env_quiet = 0; }
 

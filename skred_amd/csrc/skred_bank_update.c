@@ -318,6 +318,72 @@ int skred_bank_defer(skred_bank_t *b, uint64_t when, const skred_voice_bank_t *h
 
 int skred_bank_queue_pending(const skred_bank_t *b) { return b ? b->queue_len : 0; }
 
+/* ------------------------------------------------------------------ pattern steps (seq.c:179-213 through skred_seq.c) */
+
+typedef struct sk_pat_step { int n; sk_update_t *rec; sk_voice_meta_t *meta; } sk_pat_step_t;
+
+skred_seq_t *skred_bank_seq(skred_bank_t *b) {
+  if (!b) return NULL;
+  if (!b->seq && skred_seq_create(&b->seq) != SKRED_OK) return NULL;
+  return b->seq;
+}
+
+int skred_bank_set_sample_rate(skred_bank_t *b, float rate) {
+  if (!b || !(rate > 0.0f)) return fail(SKRED_E_BAD_ARG, "set_sample_rate");
+  b->seq_rate = rate;
+  return SKRED_OK;
+}
+
+static void pat_step_free(sk_pat_step_t *st) { free(st->rec); free(st->meta); st->rec = NULL; st->meta = NULL; st->n = 0; }
+
+static int pat_slot(skred_bank_t *b, int pattern, int step, sk_pat_step_t **out) {
+  if (pattern < 0 || pattern >= SKRED_PATTERNS_MAX || step < 0 || step >= SKRED_SEQ_STEPS_MAX)
+    return fail(SKRED_E_BAD_ARG, "pattern %d step %d", pattern, step);
+  if (!skred_bank_seq(b)) return fail(SKRED_E_NO_MEM, "pattern clock");
+  if (!b->pat) {
+    b->pat = (sk_pat_step_t *)calloc((size_t)SKRED_PATTERNS_MAX * SKRED_SEQ_STEPS_MAX, sizeof(sk_pat_step_t));
+    if (!b->pat) return fail(SKRED_E_NO_MEM, "pattern steps");
+  }
+  *out = &b->pat[(size_t)pattern * SKRED_SEQ_STEPS_MAX + step];
+  return SKRED_OK;
+}
+
+/* What the reference stores as a line of wire text (seq_step_set, seq.c:267-270) is stored here as what that line would
+ * DO: the `dirty` parts of the listed voices as the host view has them now.  n_voices == 0: a rest -- the step is
+ * occupied (the pattern does not wrap here) but stores nothing. */
+int skred_bank_pattern_step_set(skred_bank_t *b, int pattern, int step, const skred_voice_bank_t *h, const int32_t *voices,
+                                int n_voices, uint32_t dirty) {
+  if (!b || n_voices < 0 || (n_voices > 0 && (!h || !voices))) return fail(SKRED_E_BAD_ARG, "pattern_step_set: bad arguments");
+  sk_pat_step_t *st;
+  int rc = pat_slot(b, pattern, step, &st);
+  if (rc) return rc;
+  sk_update_t *rec = NULL;
+  sk_voice_meta_t *meta = NULL;
+  if (n_voices > 0 && (rc = build_batch(b, h, voices, n_voices, dirty, &rec, &meta))) return rc;
+  pat_step_free(st);
+  st->n = n_voices; st->rec = rec; st->meta = meta;
+  return skred_seq_step_set(b->seq, pattern, step, 1);
+}
+
+int skred_bank_pattern_step_clear(skred_bank_t *b, int pattern, int step) {
+  if (!b) return fail(SKRED_E_BAD_ARG, "pattern_step_clear");
+  sk_pat_step_t *st;
+  const int rc = pat_slot(b, pattern, step, &st);
+  if (rc) return rc;
+  pat_step_free(st);
+  return skred_seq_step_set(b->seq, pattern, step, 0);
+}
+
+void sk_patterns_free(skred_bank_t *b) {
+  if (b->pat) {
+    for (size_t i = 0; i < (size_t)SKRED_PATTERNS_MAX * SKRED_SEQ_STEPS_MAX; i++) pat_step_free(&b->pat[i]);
+    free(b->pat);
+    b->pat = NULL;
+  }
+  skred_seq_destroy(b->seq);
+  b->seq = NULL;
+}
+
 int skred_bank_run_queue(skred_bank_t *b, int frame_count, void *stream) {
   if (!b || frame_count < 0) return fail(SKRED_E_BAD_ARG, "run_queue: bad arguments");
   const uint64_t horizon = b->g.synth_sample_count + (uint64_t)frame_count;      /* seq.c:173 */
@@ -336,6 +402,20 @@ int skred_bank_run_queue(skred_bank_t *b, int frame_count, void *stream) {
     } else {
       prev = it;
       link = &it->next;
+    }
+  }
+  /* the second half of seq(): the tempo clock and the steps it fires (seq.c:179-213) */
+  if (b->seq) {
+    int32_t fired[SKRED_PATTERNS_MAX];
+    const int n = skred_seq_tick(b->seq, frame_count, b->seq_rate > 0.0f ? b->seq_rate : 44100.0f, fired, SKRED_PATTERNS_MAX);
+    if (n < 0) return n;
+    for (int i = 0; i < n; i++) {
+      const sk_pat_step_t *st = &b->pat[(size_t)(fired[i] >> 16) * SKRED_SEQ_STEPS_MAX + (fired[i] & 0xFFFF)];
+      if (st->n > 0) {
+        const int rc = apply_batch(b, st->rec, st->meta, st->n, (hipStream_t)stream);
+        if (rc) return rc;
+      }
+      applied++;
     }
   }
   return applied;

@@ -29,6 +29,10 @@ ABI_SYMBOLS = [
     "skred_shard_partition", "skred_shard_cut_ok", "skred_shard_create", "skred_shard_create_custom", "skred_shard_destroy",
     "skred_shard_bank", "skred_shard_range", "skred_shard_upload", "skred_shard_set_ops", "skred_shard_rccl_unique_id",
     "skred_shard_init_rccl", "skred_shard_render_mix",
+    "skred_seq_create", "skred_seq_destroy", "skred_seq_tempo_set", "skred_seq_time_per_step", "skred_seq_step_set",
+    "skred_seq_mute_set", "skred_seq_modulo_set", "skred_seq_state_set", "skred_seq_pattern_reset", "skred_seq_pointer",
+    "skred_seq_counter", "skred_seq_tick",
+    "skred_bank_seq", "skred_bank_set_sample_rate", "skred_bank_pattern_step_set", "skred_bank_pattern_step_clear",
 ]
 
 # SKRED_DIRTY_* / SKRED_STAMP_* of include/skred_amd.h
@@ -91,6 +95,24 @@ def load() -> C.CDLL:
     L.skred_bank_defer.argtypes = [vp, C.c_uint64, C.POINTER(VoiceBankC), vp, i32, C.c_uint32]
     L.skred_bank_run_queue.argtypes = [vp, i32, vp]
     L.skred_bank_queue_pending.argtypes = [vp]
+    L.skred_seq_create.argtypes = [C.POINTER(vp)]
+    L.skred_seq_destroy.argtypes = [vp]
+    L.skred_seq_destroy.restype = None
+    L.skred_seq_tempo_set.argtypes = [vp, C.c_float]
+    L.skred_seq_time_per_step.argtypes = [vp]
+    L.skred_seq_time_per_step.restype = C.c_float
+    for name in ("skred_seq_step_set", "skred_seq_mute_set"):
+        getattr(L, name).argtypes = [vp, i32, i32, i32]
+    for name in ("skred_seq_modulo_set", "skred_seq_state_set"):
+        getattr(L, name).argtypes = [vp, i32, i32]
+    for name in ("skred_seq_pattern_reset", "skred_seq_pointer", "skred_seq_counter"):
+        getattr(L, name).argtypes = [vp, i32]
+    L.skred_seq_tick.argtypes = [vp, i32, C.c_float, vp, i32]
+    L.skred_bank_seq.argtypes = [vp]
+    L.skred_bank_seq.restype = vp
+    L.skred_bank_set_sample_rate.argtypes = [vp, C.c_float]
+    L.skred_bank_pattern_step_set.argtypes = [vp, i32, i32, C.POINTER(VoiceBankC), vp, i32, C.c_uint32]
+    L.skred_bank_pattern_step_clear.argtypes = [vp, i32, i32]
     _lib = L
     return L
 
@@ -210,6 +232,22 @@ class DeviceBank:
     def queue_pending(self) -> int:
         return self.L.skred_bank_queue_pending(self.h)
 
+    # ---- pattern steps on the bank's own step clock (include/skred_amd.h: skred_bank_pattern_* / skred_seq_*) ----
+    def seq(self) -> "SeqClock":
+        return SeqClock(self.L.skred_bank_seq(self.h), owner=False)
+
+    def set_sample_rate(self, rate: float):
+        _check(self.L.skred_bank_set_sample_rate(self.h, rate), "skred_bank_set_sample_rate")
+
+    def pattern_step_set(self, pattern: int, step: int, bank: Optional[VoiceBank] = None, voices=(), dirty: int = 0):
+        v = np.ascontiguousarray(voices, np.int32)
+        cb = bank.as_c() if bank is not None else None
+        _check(self.L.skred_bank_pattern_step_set(self.h, pattern, step, C.byref(cb) if cb is not None else None,
+                                                  v.ctypes.data if len(v) else None, len(v), dirty), "skred_bank_pattern_step_set")
+
+    def pattern_step_clear(self, pattern: int, step: int):
+        _check(self.L.skred_bank_pattern_step_clear(self.h, pattern, step), "skred_bank_pattern_step_clear")
+
     def force_generic(self, on: bool = True):
         _check(self.L.skred_bank_set_option(self.h, 1, int(on)), "skred_bank_set_option")
 
@@ -237,3 +275,56 @@ class DeviceBank:
         _check(self.L.skred_bank_timing_summary(self.h, C.byref(mean), C.byref(mn), C.byref(cnt)),
                "skred_bank_timing_summary")
         return float(mean.value), float(mn.value), int(cnt.value)
+
+
+class SeqClock:
+    """skred_seq_t: the reference's pattern step clock (seq.c:179-213) on the host."""
+
+    def __init__(self, handle=None, owner: bool = True):
+        self.L = load()
+        self.owner = owner
+        if handle is None:
+            h = C.c_void_p()
+            _check(self.L.skred_seq_create(C.byref(h)), "skred_seq_create")
+            handle = h
+        self.h = C.c_void_p(handle) if isinstance(handle, int) else handle
+
+    def close(self):
+        if self.owner and self.h:
+            self.L.skred_seq_destroy(self.h)
+        self.h = None
+
+    def tempo(self, bpm: float):
+        _check(self.L.skred_seq_tempo_set(self.h, bpm), "skred_seq_tempo_set")
+
+    def time_per_step(self) -> float:
+        return float(self.L.skred_seq_time_per_step(self.h))
+
+    def step(self, pattern: int, step: int, occupied: bool = True):
+        _check(self.L.skred_seq_step_set(self.h, pattern, step, int(occupied)), "skred_seq_step_set")
+
+    def mute(self, pattern: int, step: int, on: bool = True):
+        _check(self.L.skred_seq_mute_set(self.h, pattern, step, int(on)), "skred_seq_mute_set")
+
+    def modulo(self, pattern: int, m: int):
+        _check(self.L.skred_seq_modulo_set(self.h, pattern, m), "skred_seq_modulo_set")
+
+    def state(self, pattern: int, state: int):
+        _check(self.L.skred_seq_state_set(self.h, pattern, state), "skred_seq_state_set")
+
+    def reset(self, pattern: int):
+        _check(self.L.skred_seq_pattern_reset(self.h, pattern), "skred_seq_pattern_reset")
+
+    def pointer(self, pattern: int) -> int:
+        return int(self.L.skred_seq_pointer(self.h, pattern))
+
+    def counter(self, pattern: int) -> int:
+        return int(self.L.skred_seq_counter(self.h, pattern))
+
+    def tick(self, frame_count: int, sample_rate: float = 44100.0):
+        """[(pattern, step)] of the steps that fire in this block."""
+        out = (C.c_int32 * 16)()
+        n = self.L.skred_seq_tick(self.h, frame_count, sample_rate, out, 16)
+        if n < 0:
+            _check(n, "skred_seq_tick")
+        return [(out[i] >> 16, out[i] & 0xFFFF) for i in range(n)]

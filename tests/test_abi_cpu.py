@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "skred_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(skred_(?:amd|bank|shard)_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(skred_(?:amd|bank|shard|seq)_\w+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():

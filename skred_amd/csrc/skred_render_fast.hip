@@ -212,8 +212,21 @@ struct FastPk {
   v2f pan;                      // (pan_left, pan_right)
 };
 
+// sample & hold and bit-crush of a lane (synth.c:560-574), for the block paths of extended banks
+__device__ __forceinline__ float fast_holdq(FastRegs &r, float s) {
+  if (r.hold_max) {
+    if (r.hold_count == 0) r.hold = s;
+    s = r.hold;
+    if (++r.hold_count >= r.hold_max) r.hold_count = 0;
+  }
+  if (r.quant) s = crush(s, r.quant);
+  return s;
+}
+
 template <bool FILTER, bool ENV, bool STALL, bool EXT, bool NEWEST_X>
-__device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float s, v2f &xx, v2f &yy, float &out_l, float &out_r) {
+__device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float s, v2f &xx, v2f &yy, float &out_l, float &out_r,
+                                            const int xf = 0) {
+  if (EXT && (xf & XF_HOLDQ)) s = fast_holdq(r, s);           // (wave-uniform: some lane of the wave holds or crushes)
   if (FILTER) {
     const v2f t = (NEWEST_X ? k.b12 : k.b21) * xx;
     const v2f u = (NEWEST_X ? k.a12 : k.a21) * yy;
@@ -227,11 +240,14 @@ __device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float 
       s = y;
     }
   }
-  if (!STALL) {
-    const float gain = ENV ? r.gain_sustain : r.amp;   // (an un-enveloped voice of a mixed bank carries amp in gain_sustain)
-    r.sgain += r.k * (gain - r.sgain);
+  const float gain = ENV ? r.gain_sustain : r.amp;     // (an un-enveloped voice of a mixed bank carries amp in gain_sustain)
+  if (EXT && (xf & XF_NOSMOOTH)) {                     // some lane runs without the smoother: its gain applies directly,
+    if (!STALL) { const float nx = r.sgain + r.k * (gain - r.sgain); r.sgain = r.nosmooth ? r.sgain : nx; }   // voice_smoother_gain rests
+    s *= r.nosmooth ? gain : r.sgain;
+  } else {
+    if (!STALL) r.sgain += r.k * (gain - r.sgain);
+    s *= r.sgain;
   }
-  s *= r.sgain;
   r.sample = s;
   const v2f lr = k.pan * (v2f){s, s};
   out_l = lr.x;
@@ -244,7 +260,7 @@ template <bool ENV>
 __device__ __forceinline__ bool fast_smoother_stalled(const FastRegs &r) {
   const float gain = ENV ? r.gain_sustain : r.amp;
   const float nxt = r.sgain + r.k * (gain - r.sgain);
-  return __all(__float_as_uint(nxt) == __float_as_uint(r.sgain));
+  return __all(r.nosmooth || __float_as_uint(nxt) == __float_as_uint(r.sgain));   // (a lane without the smoother never moves it)
 }
 
 // One voice, one frame.  STEADY: every lane of the wave sits in its sustain stage.  When !STEADY the
@@ -397,8 +413,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     float l0, r0, l1, r1;                                                                                \
     const float sa_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
     const float sb_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
-    fast_post_v<FILTER, ENV, false, STOPS, true>(r, pk, sa_, xx, yy, l0, r0);                            \
-    fast_post_v<FILTER, ENV, false, STOPS, false>(r, pk, sb_, xx, yy, l1, r1);                           \
+    fast_post_v<FILTER, ENV, false, STOPS, true>(r, pk, sa_, xx, yy, l0, r0, xf);                           \
+    fast_post_v<FILTER, ENV, false, STOPS, false>(r, pk, sb_, xx, yy, l1, r1, xf);                           \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
@@ -432,21 +448,6 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     if ((lane & 24) == 0) reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (JP) + (lane & 7)])[lane >> 5] = t_; \
     SK_FAST_WAVE_SYNC()                                                                                  \
   }
-#define SK_FAST_LDS_BLOCK(J, STALL_)                                                                     \
-  {                                                                                                      \
-    float smp_[8];                                                                                       \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                     \
-      smp_[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));          \
-    if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
-      float l0, r0, l1, r1;                                                                              \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, smp_[q_], xx, yy, l0, r0);                    \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, smp_[q_ + 1], xx, yy, l1, r1);               \
-      xt[q_ * SK_XT + lane] = fold_lr(l0, r0);                                                           \
-      xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                     \
-    }                                                                                                    \
-    pend_j = (J);                                                                                        \
-  }
 #define SK_FAST_LDS_FLUSH() if (pend_j >= 0) { SK_FAST_TILE_REDUCE(pend_j) pend_j = -1; }
 // All 8-frame blocks of a chunk, software-pipelined one block deep: while the biquad / gain chains of block b run
 // (a serial recurrence over its 8 frames), the oscillator of block b+1 advances and gathers (another serial recurrence,
@@ -454,17 +455,14 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // added up.  The three strands sit in ONE scheduling region (the wave-level fences only bracket the tile reads), so the
 // instruction scheduler can weave them: with one or two waves per SIMD there is nothing else to fill the dependent-issue
 // gaps of a single recurrence with.
-#ifndef SK_FAST_PIPE
-#define SK_FAST_PIPE 1
-#endif
 #define SK_FAST_OSC8(DST)                                                                                \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                       \
     DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));
 #define SK_FAST_POST8(SRC, STALL_)                                                                       \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
     float l0, r0, l1, r1;                                                                                \
-    fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0, r0);                       \
-    fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1, r1);                  \
+    fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0, r0, xf);                       \
+    fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1, r1, xf);                  \
     xt[q_ * SK_XT + lane] = fold_lr(l0, r0);                                                             \
     xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                       \
   }
@@ -473,9 +471,9 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
     float l0, r0, l1, r1;                                                                                \
     DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));             \
-    fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0, r0);                       \
+    fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0, r0, xf);                       \
     DST[q_ + 1] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));         \
-    fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1, r1);                  \
+    fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1, r1, xf);                  \
     xt[q_ * SK_XT + lane] = fold_lr(l0, r0);                                                             \
     xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                       \
   }
@@ -555,6 +553,37 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     }                                                                                                    \
     pend_j = (J);                                                                                        \
   }
+// Eight steady frames of a wave whose only extended feature is frequency modulation the way the reference's patches write
+// it (`v0 ... F1,depth` with the modulator above the carrier: last frame's voice_sample[m], synth.c:548-555).  The exchange
+// makes the frames strictly sequential, but most of them are tame: when the modulated increment of every lane still lies in
+// [0, span/2] (one wave-wide vote per frame) the frame runs the straight-line oscillator, the unclamped fetch and the
+// pair-register chain of the plain blocks; a frame in which deep modulation drives some increment negative or beyond half a
+// loop takes the general frame.  (Muted lanes -- the modulators of such patches are `m1` -- are selected away per frame.)
+#define SK_FAST_FM_FRAME(Q, NEWEST_X_, XN, XO, YN, YO)                                                   \
+  {                                                                                                      \
+    float l, rr;                                                                                         \
+    const float ms_ = __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, __float_as_int(r.sample))); \
+    const float inc_ = r.fm_addr >= 0 ? r.inc + r.fm_k * (ms_ * r.fm_depth) : r.inc;      /* synth.c:551-554 */ \
+    if (__all(inc_ >= 0.0f && inc_ <= half_span)) {                                                      \
+      const float s_ = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false>(r, inc_)); \
+      fast_post_v<FILTER, ENV, false, STOPS, NEWEST_X_>(r, pk, s_, xx, yy, l, rr, xf);                   \
+    } else {                                                                                             \
+      SK_FAST_PACK_OUT()                                                                                 \
+      fast_frame<TAB_LDS, FILTER, ENV, true, false, INTERP, STOPS>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, 0.0f); \
+      SK_FAST_REPACK()                                                                                   \
+    }                                                                                                    \
+    l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
+    xt[((Q) & 7) * SK_XT + lane] = fold_lr(l, rr);                                                       \
+  }
+#define SK_FAST_FM_BLOCK(J)                                                                              \
+  {                                                                                                      \
+    if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      SK_FAST_FM_FRAME((J) + q_, true, r.x1, r.x2, r.y1, r.y2)                                           \
+      SK_FAST_FM_FRAME((J) + q_ + 1, false, r.x2, r.x1, r.y2, r.y1)                                      \
+    }                                                                                                    \
+    pend_j = (J);                                                                                        \
+  }
 // eight steady frames of a tame wave of a global-table bank through the table window
 #define SK_FAST_WIN_BLOCK(J, STALL_)                                                                     \
   {                                                                                                      \
@@ -563,10 +592,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, s0_, xx, yy, l0, r0);                         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, s0_, xx, yy, l0, r0, xf);                         \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); SK_FAST_REPACK() } \
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, s1_, xx, yy, l1, r1);                        \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, s1_, xx, yy, l1, r1, xf);                        \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); SK_FAST_REPACK() } \
       { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
     }                                                                                                    \
@@ -579,6 +608,9 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 
 #ifndef SK_FAST_WIN_MIN_WAVES
 #define SK_FAST_WIN_MIN_WAVES 4  /* global-table banks: the window refill wants ~20 more registers (6: 12 B of scratch) */
+#endif
+#ifndef SK_FAST_WIN_EXT_MIN_WAVES
+#define SK_FAST_WIN_EXT_MIN_WAVES 4  /* the extended instantiation on global-table banks */
 #endif
 #ifndef SK_FAST_EXT_MIN_WAVES
 #define SK_FAST_EXT_MIN_WAVES 3  /* the extended instantiation (LDS-table banks) carries ~30 more per-lane fields: at 4 waves (128
@@ -594,7 +626,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // (checked frame by frame) and / or carriers frequency-modulated by a higher-indexed voice of their 64-voice group.
 // Such banks run the plain frame loop (no frame pairs); table windows only in waves without carriers.
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS>
-__global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES : SK_FAST_MIN_WAVES) : SK_FAST_WIN_MIN_WAVES) void sk_render_fast_kernel(const sk_render_args_t a) {
+__global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES : SK_FAST_MIN_WAVES) : (STOPS ? SK_FAST_WIN_EXT_MIN_WAVES : SK_FAST_WIN_MIN_WAVES)) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
   const char *lds_tab = reinterpret_cast<const char *>(lds);
@@ -735,14 +767,21 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       if (__any(r.noise)) xf |= XF_NOISE;
       if (__any(r.stop)) xf |= XF_STOP;                    // (a lane that finishes turns its flag off: the bit stays, harmless)
     }
-    const bool any_fm = (xf & ~XF_STOP) != 0;              // any extended feature but stopping
+    // features the block paths do not serve (modulation exchange, reverse, the noise source): such a wave walks frame by
+    // frame; sample & hold, bit-crush and smoother-off ride the block paths (fast_post_v), stopping voices while far from their end
+    const bool any_fm = (xf & ~(XF_STOP | XF_HOLDQ | XF_NOSMOOTH)) != 0;
     const bool any_stop = (xf & XF_STOP) != 0;
     uint64_t rng = a.rng0;                                // noise LCG state before the first frame of the launch
     (void)any_stop; (void)any_fm; (void)rng;
     // TAME (decided once per pass): the only wrap that can occur is the simple one and the table index
     // needs no clamp -- see fast_frame<TAME> / fast_fetch<NOCLAMP>
-    const bool tame = __all(dead || (r.inc >= 0.0f && r.inc <= 0.5f * r.span && r.phase >= r.lo && r.phase <= r.hi &&
-                                     r.lo >= 0.0f && r.hi <= (float)(r.tsize_m1 + 1))) && !__any(silent && !dead);
+    const bool tame_geom = __all(dead || (r.inc >= 0.0f && r.inc <= 0.5f * r.span && r.phase >= r.lo && r.phase <= r.hi &&
+                                          r.lo >= 0.0f && r.hi <= (float)(r.tsize_m1 + 1)));
+    const bool tame = tame_geom && !__any(silent && !dead);
+    // a wave whose only reason for the frame loop is frequency modulation from above (SK_FAST_FM_BLOCK)
+    const bool fm_only = STOPS && TAB_LDS && tame_geom && (xf & XF_FM) && (xf & ~(XF_FM | XF_HOLDQ | XF_NOSMOOTH)) == 0;
+    const float half_span = 0.5f * r.span;
+    (void)fm_only; (void)half_span;
 
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
@@ -767,16 +806,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       if (STOPS && (!ENV || steady) && tame && !any_fm && !stop_near && TAB_LDS && !stems_on) {
         // an extended bank, but nothing in THIS wave needs the frame loop now (e.g. only some voices filtered, or one-shots
         // still far from their end): frame pairs
-        int j = 0, pend_j = -1;
+        int j = 0;
         SK_FAST_PACK_IN()
-#if SK_FAST_PIPE
         if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
-        (void)pend_j;
-#else
-        if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, true)
-        else for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, false)
-        SK_FAST_LDS_FLUSH()
-#endif
         for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
         SK_FAST_PACK_OUT()
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
@@ -786,6 +818,12 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
           SK_FAST_PACK_IN()
           if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
           else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
+          SK_FAST_PACK_OUT()
+        } else if (fm_only && !stems_on) {
+          int pend_j = -1;
+          SK_FAST_PACK_IN()
+          for (; j + 8 <= cn; j += 8) SK_FAST_FM_BLOCK(j)
+          SK_FAST_LDS_FLUSH()
           SK_FAST_PACK_OUT()
         } else {
           int pend_j = -1;
@@ -803,16 +841,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
           for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
           SK_FAST_PACK_OUT()
         } else {
-          int pend_j = -1;
           SK_FAST_PACK_IN()
-#if SK_FAST_PIPE
           if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
-          (void)pend_j;
-#else
-          if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, true)
-          else for (; j + 8 <= cn; j += 8) SK_FAST_LDS_BLOCK(j, false)
-          SK_FAST_LDS_FLUSH()
-#endif
           for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
           SK_FAST_PACK_OUT()
         }

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""tools/fold_profiles.py TAG [OUT_PREFIX] -- fold the rocprofv3 passes of tools/profile_round.sh (gpurun_out/prof_<TAG>_<workload>/)
+into profiles/<OUT_PREFIX>_<workload>_{kernel_stats.csv,pmc_summary.json} and refresh profiles/pmc_traffic.json (what bench.py
+reports as roofline.traffic / c4.l2_requests).  Runs here, after gpurun merged gpurun_out/ back."""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W = {"c1": ("sk_render_fast_kernel", 4096, 64, 0.0), "c2": ("sk_render_fast_kernel", 65536, 64, 0.0),
+     "c3": ("sk_render_fast2_kernel", 1048576, 128, 0.0), "c4": ("sk_render_fast_kernel", 262144, 64, 8.0)}
+
+
+def main():
+    tag = sys.argv[1]
+    prefix = sys.argv[2] if len(sys.argv) > 2 else tag
+    traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    traffic = json.load(open(traffic_path))
+    ta = {}
+    ta_file = os.path.join(ROOT, "gpurun_out", "ta_rate_r02.txt")
+    if os.path.exists(ta_file):
+        import re
+        for line in open(ta_file):
+            m = re.match(r"^(.*?)\s+([\d.]+) ms\s+([\d.e+]+) lane-gathers/s", line)
+            if m:
+                ta[m.group(1).strip()] = float(m.group(3))
+    for w, (kernel, voices, vpw, gbytes) in W.items():
+        d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{w}")
+        if not os.path.isdir(d):
+            continue
+        stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
+        if stats:
+            shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{prefix}_{w}_kernel_stats.csv"))
+        B = gbytes + 292.0 / 512
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "--kernel", kernel, "--voices", str(voices),
+                              "--frames", "512", "--voices-per-wave", str(vpw), "--algorithmic-bytes-per-voice-sample", str(B),
+                              "--command", f"tools/profile_round.sh {w} {tag} (rocprofv3 --pmc ... -- python3 bench.py --workload {w} --steps 5 "
+                                           "--warmup 5 --no-cpu --no-extra --time-every 1; separate passes for FETCH_SIZE, WRITE_SIZE, SQ and memory counters)",
+                              "--note", f"round 2: {w} on {kernel}; one dispatch = one block (render + in-kernel mix-down + master volume)",
+                              os.path.join(d, "fetch"), os.path.join(d, "write"), os.path.join(d, "sq"), os.path.join(d, "mem")],
+                             capture_output=True, text=True, check=True)
+        summ = json.loads(out.stdout)
+        json.dump(summ, open(os.path.join(ROOT, "profiles", f"{prefix}_{w}_pmc_summary.json"), "w"), indent=1)
+        e = {"frames_per_launch": 512, "voices": voices, "hbm_bytes_per_launch": summ["hbm_bytes_per_launch"]["total"],
+             "algorithmic_bytes_per_launch": summ["hbm_bytes_per_launch"]["algorithmic_bytes_per_launch"],
+             "source": f"profiles/{prefix}_{w}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)"}
+        if w == "c4":
+            req = summ["counters_mean_per_dispatch"].get("TCP_TCC_READ_REQ_sum")
+            if req:
+                e["l2_read_requests_per_launch"] = req
+            key = "5 x dwordx4 every 8th iter"            # the table-window refill pattern of the kernel
+            if key in ta:
+                # the tool counts lane-iterations; that mode issues 5 dwordx4 lane-requests per 8 of them
+                e["l2_request_peak_per_s"] = ta[key] * 5.0 / 8.0
+                e["l2_request_peak_source"] = ("tools/ta_rate.hip on the same box, mode '5 x dwordx4 every 8th iter' (the window refill pattern: "
+                                               f"{ta[key]:.3e} lane-iterations/s x 5/8 lane-requests each), gpurun_out/ta_rate_r02.txt")
+        traffic[w] = e
+        print(w, json.dumps({k: summ.get(k) for k in ("per_wave_frame", "valu_busy_fraction", "ta_busy_fraction", "kernel_cycles_per_xcd")}),
+              "hbm MB", summ["hbm_bytes_per_launch"]["total"] / 1e6)
+    json.dump(traffic, open(traffic_path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -4,7 +4,7 @@
 set -e
 W=${1:-c3}; TAG=${2:-r01}; R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/prof_$TAG
 mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --workload $W --no-cpu --no-low-latency --time-every 1 --no-tail-overlap"   # in-order stream, every launch bracketed: one dispatch = one block
+B="python3 $R/bench.py --workload $W --no-cpu --no-extra --time-every 1"   # every launch bracketed; one dispatch = one block (render + mix-down + master volume)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B --steps 100 --warmup 20 > $O/trace.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 5 --warmup 5 > $O/fetch.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 5 --warmup 5 > $O/write.log 2>&1 &&

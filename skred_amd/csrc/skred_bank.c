@@ -311,6 +311,7 @@ int skred_bank_set_globals(skred_bank_t *b, const skred_globals_t *g) {
    * non-blocking stream, or on the bank's tail stream under SKRED_OPT_OVERLAP_TAIL): wait for the device first */
   HIP_TRY(hipDeviceSynchronize());
   b->g = *g;
+  b->gains_frames = 0;                /* gains prepared for a pending skred_bank_master no longer hold */
   HIP_TRY(hipMemcpy(b->d_gain_state, &g->volume_smoother_gain, sizeof(float), hipMemcpyHostToDevice));
   sk_control_changed(b);              /* the clock may have moved: envelope stages are a function of it */
   return SKRED_OK;
@@ -405,17 +406,23 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   a.partial = b->d_partial;
   a.slab_rows = b->d_partial + (size_t)n_wg * row;
   a.gains = a.slab_rows + (size_t)SK_FINISH_SLABS * row;
+  b->gains_offset = (size_t)(a.gains - b->d_partial);
   a.n_rows = n_wg;
   a.finish = 1;
-  a.wg_shift = d_out ? 1 : 0;               /* the gain workgroup only exists where the master stage is applied */
+  /* The gain workgroup walks the master gain of every frame beside the renderers.  Single-GPU form: the last arriver applies
+   * it.  Sum-only form (the multi-GPU render): the gains are left for skred_bank_master(), which runs after the RCCL sum
+   * and then has nothing serial left to do; the carried gain is committed there (slot 1 holds it meanwhile). */
+  a.wg_shift = 1;
   a.sum_out = d_sum;
   a.mix_out = d_out;
   a.num_channels = num_channels;
   a.gain_state = b->d_gain_state;
+  a.gain_commit = d_out ? b->d_gain_state : b->d_gain_state + 1;
+  b->gains_frames = d_out ? 0 : num_frames;  /* gains for a block of this many frames are waiting for skred_bank_master */
   a.tickets = b->d_tickets;
   a.vol_target = b->g.volume_final;
   a.vol_k = b->g.volume_smoother_smoothing;
-  if (getenv("SKRED_DEBUG_NO_FINISH")) { a.finish = 0; a.wg_shift = 0; }   /* timing experiments only: the block's output is then garbage */
+  if (getenv("SKRED_DEBUG_NO_FINISH")) { a.finish = 0; a.wg_shift = 0; b->gains_frames = 0; }   /* timing experiments only: the block's output is then garbage */
 
   const int tslot = b->n_timed % SK_TIMING_RING;
   /* two-per-lane banks with envelopes: sk_render_fast2_kernel hands groups with envelopes in motion to
@@ -485,8 +492,16 @@ int skred_bank_wait_mix(skred_bank_t *b, void *stream) {
 int skred_bank_master(skred_bank_t *b, const float *d_sum, int num_frames, int num_channels, float *d_out, void *stream) {
   if (!b || !d_sum || !d_out || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "master: bad arguments");
   HIP_TRY(hipSetDevice(b->device));
-  hipError_t e = (hipError_t)sk_launch_master(d_sum, d_out, num_frames, num_channels, b->g.volume_final,
-                                              b->g.volume_smoother_smoothing, b->d_gain_state, (hipStream_t)stream);
+  hipError_t e;
+  if (b->gains_frames == num_frames && b->d_partial) {
+    /* the render of this block (skred_bank_render, same stream) already walked the gains: scale and commit */
+    const float *gains = b->d_partial + b->gains_offset;
+    e = (hipError_t)sk_launch_master_apply(d_sum, gains, d_out, num_frames, num_channels, b->d_gain_state + 1, b->d_gain_state, (hipStream_t)stream);
+    b->gains_frames = 0;
+  } else {
+    e = (hipError_t)sk_launch_master(d_sum, d_out, num_frames, num_channels, b->g.volume_final,
+                                     b->g.volume_smoother_smoothing, b->d_gain_state, (hipStream_t)stream);
+  }
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "master launch -> %s", hipGetErrorString(e));
   return SKRED_OK;
 }

@@ -38,7 +38,9 @@ struct skred_bank {
   size_t partial_cap;         /* floats */
   uint32_t *d_tickets;        /* [SK_FINISH_SLABS + 1] arrival counters of the in-kernel mix-down */
   int timing_every;           /* SKRED_OPT_KERNEL_TIMING: bracket every n-th launch's render kernels with an event pair (0: none) */
-  float *d_gain_state;        /* master smoother gain carried between blocks */
+  float *d_gain_state;        /* [0] master smoother gain carried between blocks; [1] the gain a sum-only render prepared for skred_bank_master */
+  int gains_frames;           /* > 0: the latest skred_bank_render() left the master gains of a block of this many frames in d_partial */
+  size_t gains_offset;        /* ... at this float offset */
   float *d_out, *d_stems;     /* scratch of skred_bank_render_host */
   size_t out_cap, stems_cap;
   uint8_t *h_class;           /* per-voice SKC_* bits, shadow used to pick the kernel */

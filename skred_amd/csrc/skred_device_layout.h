@@ -152,7 +152,10 @@ typedef struct {
   float *sum_out;          /* [num_frames][2] pre-master sum of all rows (the operand of the multi-GPU reduce), or NULL */
   float *mix_out;          /* [num_frames][num_channels] post-master output (channels 0, 1 written), or NULL */
   float *gains;            /* [num_frames] master gain per frame (synth.c:616-620), written by the gain workgroup */
-  float *gain_state;       /* the smoother's carried gain: read before frame 0, written after the last frame */
+  float *gain_state;       /* the smoother's carried gain as of frame 0 (read) */
+  float *gain_commit;      /* where the gain after the last frame goes: gain_state itself when this launch applies the master
+                              stage; a pending slot when it only prepares `gains` for skred_bank_master (multi-GPU form), which
+                              commits it */
   uint32_t *tickets;       /* [SK_FINISH_SLABS + 1] arrival counters; the last arriver re-arms its counter to 0 */
   float vol_target, vol_k; /* volume_final, volume_smoother_smoothing */
 } sk_render_args_t;

@@ -177,7 +177,7 @@ __device__ __forceinline__ void sk_finish_cols(const sk_render_args_t &a, int bi
         vg += a.vol_k * (a.vol_target - vg);
         sk_store_through(&a.gains[i], vg);
       }
-      a.gain_state[0] = vg;                                   // (read by the next launch only)
+      a.gain_commit[0] = vg;                                  // (read by a later launch only: the next block's, or the master kernel's)
     }
   } else {
     if (!published) {

@@ -5,7 +5,7 @@
  *   skred_render_generic.hip  sk_launch_render (dispatcher), sk_launch_render_mod
  *   skred_render_fast.hip     sk_launch_render_fast
  *   skred_render_fast2.hip    sk_launch_render_fast2
- *   skred_mix_kernels.hip     sk_launch_master
+ *   skred_mix_kernels.hip     sk_launch_master, sk_launch_master_apply
  *   skred_update_kernels.hip  sk_launch_update
  *   skred_rec_kernels.hip     sk_launch_rec_minmax, sk_rec_partial_floats, sk_launch_rec_convert
  *
@@ -38,6 +38,9 @@ int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_
 
 int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels, float target, float k,
                      float *gain_state, hipStream_t stream);
+/* the same with the block's gains already walked by the render kernel (gains[num_frames], the gain to carry on in gain_pending) */
+int sk_launch_master_apply(const float *sum, const float *gains, float *out, int num_frames, int num_channels,
+                           const float *gain_pending, float *gain_state, hipStream_t stream);
 
 /* scatter n voice updates into the planes; `now` = synth_sample_count for the STAMP bits */
 int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[SKP_COUNT], sk_plane_t *const rw[SKS_COUNT],

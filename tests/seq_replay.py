@@ -47,5 +47,23 @@ def main():
     print("RESULT " + json.dumps(out))
 
 
+def write_golden(path):
+    """tests/golden/seq_clock.npz: the four scripted sessions' results from the compiled reference (one fresh process per
+    session), so that the comparison also runs where the reference tree is absent."""
+    import subprocess
+    arrays = {}
+    for seed in range(4):
+        o = subprocess.run([sys.executable, os.path.abspath(__file__), str(seed)], capture_output=True, text=True, check=True)
+        res = json.loads([l for l in o.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+        arrays[f"s{seed}_fired"] = np.array([(k, p, s) for k, r in enumerate(res) for p, s in r["fired"]], np.int32).reshape(-1, 3)
+        arrays[f"s{seed}_pointer"] = np.array([r["pointer"] for r in res], np.int32)
+        arrays[f"s{seed}_counter"] = np.array([r["counter"] for r in res], np.int32)
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, {k: v.shape for k, v in arrays.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1] == "--write-golden":
+        write_golden(os.path.join(HERE, "golden", "seq_clock.npz"))
+    else:
+        main()

@@ -20,11 +20,17 @@ ROOT = os.path.dirname(HERE)
 def test_step_times_equal_the_reference_seq(seed):
     """Same edits, same blocks (512-frame callbacks and ragged ones, tempo changes, pause / resume / stop, mutes, modulo
     0..7, holes, a pattern reset mid-run): the steps that fire and every pointer / counter, call by call."""
-    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libskred_ref.so")):
-        pytest.skip("oracle/_ref/libskred_ref.so not built (needs the reference tree)")
-    out = subprocess.run([sys.executable, os.path.join(HERE, "seq_replay.py"), str(seed)], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr[-1500:]
-    ref = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    z = np.load(os.path.join(HERE, "golden", "seq_clock.npz"))      # written by `seq_replay.py --write-golden`
+    nblk = len(z[f"s{seed}_pointer"])
+    fired_at = [[] for _ in range(nblk)]
+    for k, p, s in z[f"s{seed}_fired"].tolist():
+        fired_at[k].append([p, s])
+    ref = [{"fired": fired_at[k], "pointer": z[f"s{seed}_pointer"][k].tolist(), "counter": z[f"s{seed}_counter"][k].tolist()}
+           for k in range(nblk)]
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libskred_ref.so")):   # and the live reference, when built
+        out = subprocess.run([sys.executable, os.path.join(HERE, "seq_replay.py"), str(seed)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-1500:]
+        assert json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]) == ref, "fixture is stale"
     sq = device.SeqClock()
     k = 0
     for op in script(seed):

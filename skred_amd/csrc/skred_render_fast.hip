@@ -223,7 +223,7 @@ __device__ __forceinline__ float fast_holdq(FastRegs &r, float s) {
   return s;
 }
 
-template <bool FILTER, bool ENV, bool STALL, bool EXT, bool NEWEST_X>
+template <bool FILTER, bool ENV, bool STALL, bool EXT, bool NEWEST_X, bool PAN = true>
 __device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float s, v2f &xx, v2f &yy, float &out_l, float &out_r,
                                             const int xf = 0) {
   if (EXT && (xf & XF_HOLDQ)) s = fast_holdq(r, s);           // (wave-uniform: some lane of the wave holds or crushes)
@@ -249,9 +249,32 @@ __device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float 
     s *= r.sgain;
   }
   r.sample = s;
+  if (!PAN) { out_l = s; return; }                     // the caller pans and folds two frames at once (fast_pan_fold2)
   const v2f lr = k.pan * (v2f){s, s};
   out_l = lr.x;
   out_r = lr.y;
+}
+
+// Pan and L/R fold of two frames in one go: four plain products (a v_pk_mul_f32 of a splat makes hipcc treat the
+// unused upper register of the pair as a source -- if an LDS gather is in flight into it the wave stalls on it -- and
+// costs a v_mov + s_nop 1 per frame to get its halves into the swap), the two swaps spaced by hand (>= 2 wait states
+// behind the product they read; hipcc pads nothing inside an asm statement), the two adds.  Same products as
+// `s * pan_left`, `s * pan_right`, same sum as fold_lr.
+__device__ __forceinline__ void fast_pan_fold2(float s0, float s1, float pan_l, float pan_r, float &f0, float &f1) {
+  float a0, b0, a1, b1;
+  asm("v_mul_f32_e32 %0, %4, %6\n\t"
+      "v_mul_f32_e32 %1, %4, %7\n\t"
+      "v_mul_f32_e32 %2, %5, %6\n\t"
+      "v_mul_f32_e32 %3, %5, %7\n\t"
+      "v_permlane32_swap_b32_e32 %0, %1\n\t"
+      "s_nop 0\n\t"
+      "v_permlane32_swap_b32_e32 %2, %3\n\t"
+      "v_add_f32_e32 %0, %0, %1\n\t"
+      "v_add_f32_e32 %2, %2, %3"
+      : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1)
+      : "v"(s0), "v"(s1), "v"(pan_l), "v"(pan_r));
+  f0 = a0;
+  f1 = a1;
 }
 
 // A one-pole smoother towards a constant gain stops moving once k*(gain - g) rounds away (see
@@ -460,22 +483,40 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));
 #define SK_FAST_POST8(SRC, STALL_)                                                                       \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
-    float l0, r0, l1, r1;                                                                                \
-    fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0, r0, xf);                       \
-    fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1, r1, xf);                  \
-    xt[q_ * SK_XT + lane] = fold_lr(l0, r0);                                                             \
-    xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                       \
+    float f0_, f1_;                                                                                      \
+    if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
+      float s0_, s1_, u_;                                                                                \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SRC[q_], xx, yy, s0_, u_, xf);         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf);    \
+      fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
+    } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
+      float l0_, r0_, l1_, r1_;                                                                          \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf);               \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1_, r1_, xf);          \
+      f0_ = fold_lr(l0_, r0_); f1_ = fold_lr(l1_, r1_);                                                  \
+    }                                                                                                    \
+    xt[q_ * SK_XT + lane] = f0_;                                                                         \
+    xt[(q_ + 1) * SK_XT + lane] = f1_;                                                                   \
   }
 /* the two strands written frame pair by frame pair, the way they should issue: oscillator of the NEXT block, chains of this one */
 #define SK_FAST_OSC_POST8(DST, SRC, STALL_)                                                              \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
-    float l0, r0, l1, r1;                                                                                \
+    float f0_, f1_;                                                                                      \
     DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));             \
-    fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0, r0, xf);                       \
     DST[q_ + 1] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));         \
-    fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1, r1, xf);                  \
-    xt[q_ * SK_XT + lane] = fold_lr(l0, r0);                                                             \
-    xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                       \
+    if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
+      float s0_, s1_, u_;                                                                                \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SRC[q_], xx, yy, s0_, u_, xf);         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf);    \
+      fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
+    } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
+      float l0_, r0_, l1_, r1_;                                                                          \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf);               \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1_, r1_, xf);          \
+      f0_ = fold_lr(l0_, r0_); f1_ = fold_lr(l1_, r1_);                                                  \
+    }                                                                                                    \
+    xt[q_ * SK_XT + lane] = f0_;                                                                         \
+    xt[(q_ + 1) * SK_XT + lane] = f1_;                                                                   \
   }
 #define SK_FAST_TILE_LOAD(TA, TB)                                                                        \
   {                                                                                                      \
@@ -499,14 +540,20 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       SK_FAST_OSC8(sa_)                                                                                  \
       if (nblk_ > 1) {                                                                                   \
         SK_FAST_OSC_POST8(sb_, sa_, STALL_)                                             /* block 0 */    \
-        _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) sa_[q_] = sb_[q_];                              \
-        for (int b_ = 1; b_ + 1 < nblk_; ++b_) {                                                         \
+        int b_ = 1;                                                                                      \
+        for (; b_ + 2 < nblk_; b_ += 2) {          /* two blocks per trip: the gathers ping-pong, no moves */ \
           SK_FAST_TILE_LOAD(ta_, tb_)                                                                    \
-          SK_FAST_OSC_POST8(sb_, sa_, STALL_) SK_FAST_TILE_FINISH(ta_, tb_, (b_ - 1) * 8)                \
-          _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) sa_[q_] = sb_[q_];                            \
+          SK_FAST_OSC_POST8(sa_, sb_, STALL_) SK_FAST_TILE_FINISH(ta_, tb_, (b_ - 1) * 8)                \
+          SK_FAST_TILE_LOAD(ta_, tb_)                                                                    \
+          SK_FAST_OSC_POST8(sb_, sa_, STALL_) SK_FAST_TILE_FINISH(ta_, tb_, b_ * 8)                      \
+        }                                                                                                \
+        if (b_ + 1 < nblk_) {                      /* an odd middle block */                             \
+          SK_FAST_TILE_LOAD(ta_, tb_)                                                                    \
+          SK_FAST_OSC_POST8(sa_, sb_, STALL_) SK_FAST_TILE_FINISH(ta_, tb_, (b_ - 1) * 8)                \
+          _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) sb_[q_] = sa_[q_];                            \
         }                                                                                                \
         SK_FAST_TILE_LOAD(ta_, tb_)                                                                      \
-        SK_FAST_POST8(sa_, STALL_) SK_FAST_TILE_FINISH(ta_, tb_, (nblk_ - 2) * 8)       /* last block */ \
+        SK_FAST_POST8(sb_, STALL_) SK_FAST_TILE_FINISH(ta_, tb_, (nblk_ - 2) * 8)       /* last block */ \
       } else {                                                                                           \
         SK_FAST_POST8(sa_, STALL_)                                                                       \
       }                                                                                                  \

@@ -21,3 +21,5 @@ def run(name, rec, n, interp=0, F=512, steps=100, min2=None):
 run("c1 4096", "c1", 4096)
 run("c2 65536", "c2", 65536)
 run("c2 131072 one", "c2", 131072, min2=1<<30)
+run("c3 131072 one (shard)", "c3", 131072, min2=1<<30)
+run("c2 262144 one", "c2", 262144, min2=1<<30)

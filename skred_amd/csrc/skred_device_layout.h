@@ -140,6 +140,9 @@ typedef struct {
   uint32_t fast_mode;      /* SKM_* : which specialised kernel the host picked */
   uint32_t launch_ticket;  /* this launch's number (see group_flag) */
   uint32_t skip_env2;      /* host knows no group can be deferred: sk_render_env2_kernel is not launched */
+  int32_t env_workers;     /* sk_render_env2_kernel: workgroups that take passes = what the device holds at once (the grid
+                              still has n_rows of them: the others only hand their row to the mix-down).  A grid of more
+                              rendering workgroups than fit runs in rounds, the last one mostly empty. */
   /* ---- the block's mix-down, inside the last render kernel of the block (skred_kernel_common.hpp: sk_finish_block) ----
    * Every workgroup leaves its partial-mix row in `partial`; with `finish` set the workgroup that arrives LAST at a
    * ticket adds the rows up in a fixed order (slab by slab when there are many), writes the pre-master sum and, in

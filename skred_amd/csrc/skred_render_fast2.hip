@@ -548,7 +548,7 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
 }
 
 // NW (a constexpr in scope): wavefronts per workgroup = 128-voice slices per workgroup pass
-#define SK_FAST2_PROLOGUE()                                                                          \
+#define SK_FAST2_PROLOGUE_(WORKS)                                                                      \
   extern __shared__ float lds[];                                                                     \
   float2 *const wsum0 = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));        \
   float2 *wsum = wsum0;                      /* [2][NW][SK_CHUNK]: see SK_FAST2_FLUSH */              \
@@ -562,7 +562,8 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
   (void)xp; (void)xq; (void)win;                                                                     \
   const int bid = (int)blockIdx.x - a.wg_shift;   /* row of the partial mix; -1: the gain workgroup */ \
   if (bid < 0) { sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds)); return; }      \
-  if (TAB_LDS) {                                                                                     \
+  const int n_flags = a.n_groups * 2;      /* one hand-over flag per 128-voice wave slice; [n_flags] = the ticket slot */ \
+  if (TAB_LDS && (WORKS)) {                 /* (a workgroup without a pass needs no tables) */           \
     const int n4 = a.lds_table_floats >> 2;                                                          \
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);                                 \
     float4 *dst4 = reinterpret_cast<float4 *>(lds);                                                  \
@@ -571,8 +572,8 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
   }                                                                                                  \
   const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;                                   \
   const int n_groups2 = a.n_groups >> 1;   /* 512-voice groups: one pass of sk_render_env2_kernel */ \
-  const int n_pass = (a.n_groups * SK_GROUP) / (NW * 128);   /* workgroup passes over the (padded) bank */ \
-  const int n_flags = a.n_groups * 2;      /* one hand-over flag per 128-voice wave slice; [n_flags] = the ticket slot */
+  const int n_pass = (a.n_groups * SK_GROUP) / (NW * 128);   /* workgroup passes over the (padded) bank */
+#define SK_FAST2_PROLOGUE() SK_FAST2_PROLOGUE_(true)
 
 #ifndef SK_FAST2_MIN_WAVES
 #define SK_FAST2_MIN_WAVES 4     /* <= 128 VGPRs */
@@ -655,13 +656,15 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
 template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
   constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
-  SK_FAST2_PROLOGUE()
+  SK_FAST2_PROLOGUE_((int)blockIdx.x - a.wg_shift < (a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows) &&
+                     ((int)blockIdx.x - a.wg_shift) * 4 < a.env_list[a.n_groups * 2])
   (void)n_pass; (void)n_groups2;
   // the slices sk_render_fast2_kernel left to this kernel, compacted in ascending order (sk_compact_flags_kernel): every
   // workgroup pass takes four of them, so the launch costs what the flagged share of the bank costs
   const int n_mine = a.env_list[n_flags];
   constexpr bool publish = false;   // (a workgroup of this kernel may have no pass at all: sk_finish_block copies every row out)
-  for (int g = bid; g * 4 < n_mine; g += a.n_rows) {
+  const int n_workers = a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows;
+  for (int g = bid < n_workers ? bid : n_mine; g * 4 < n_mine; g += n_workers) {
     const bool mine = g * 4 + wave < n_mine;
     const int slice = mine ? a.env_list[g * 4 + wave] : 0;
     Fast2Regs r;
@@ -790,6 +793,14 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
   // the block's mix-down (sk_finish_block) belongs to the LAST kernel that writes rows: sk_render_env2_kernel when it
   // runs (it adds into the rows sk_render_fast2_kernel left), else sk_render_fast2_kernel itself
   sk_render_args_t first = *args, second = *args;
+  {   /* workgroups of sk_render_env2_kernel the device holds at once: 3 per CU by registers (SK_ENV2_MIN_WAVES), fewer by LDS */
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    int per_cu = (int)((size_t)160 * 1024 / (lds_env2 ? lds_env2 : 1));
+    if (per_cu > SK_ENV2_MIN_WAVES) per_cu = SK_ENV2_MIN_WAVES;
+    if (per_cu < 1) per_cu = 1;
+    second.env_workers = cus > 0 ? cus * per_cu - 1 : 0;   /* (the gain workgroup holds a slot too) */
+  }
   const bool env_follows = (args->fast_mode & SKM_ENV_ALL) && !args->skip_env2;
   if (env_follows) { first.finish = 0; first.wg_shift = 0; }
   dim3 grid_first((unsigned)(n_workgroups + first.wg_shift));

@@ -77,8 +77,12 @@ static int bank_build(skred_bank_t *b) {
   /* one hand-over flag per 128-voice wave slice of the two-per-lane kernels, plus the ticket slot */
   HIP_TRY(hipMalloc((void **)&b->d_group_flag, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
   HIP_TRY(hipMemset(b->d_group_flag, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
-  HIP_TRY(hipMalloc((void **)&b->d_env_list, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
-  HIP_TRY(hipMemset(b->d_env_list, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void **)&b->d_env_list, (size_t)b->n_groups * SK_GROUP * sizeof(int32_t)));
+  HIP_TRY(hipMemset(b->d_env_list, 0, (size_t)b->n_groups * SK_GROUP * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void **)&b->d_env_off, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
+  HIP_TRY(hipMemset(b->d_env_off, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void **)&b->d_move_mask, (size_t)b->n_groups * 4 * sizeof(uint64_t)));
+  HIP_TRY(hipMemset(b->d_move_mask, 0, (size_t)b->n_groups * 4 * sizeof(uint64_t)));
   HIP_TRY(hipMalloc((void **)&b->d_gain_state, 4 * sizeof(float)));
   HIP_TRY(hipMemset(b->d_gain_state, 0, 4 * sizeof(float)));
   /* arrival tickets of the in-kernel mix-down: zero once, every last arriver re-arms its own */
@@ -145,6 +149,8 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_level) hipFree(b->d_level);
   if (b->d_group_flag) hipFree(b->d_group_flag);
   if (b->d_env_list) hipFree(b->d_env_list);
+  if (b->d_env_off) hipFree(b->d_env_off);
+  if (b->d_move_mask) hipFree(b->d_move_mask);
   for (int i = 0; i < SK_TIMING_RING; i++) {
     if (b->ev0[i]) hipEventDestroy(b->ev0[i]);
     if (b->ev1[i]) hipEventDestroy(b->ev1[i]);
@@ -377,6 +383,8 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   a.stems = d_stems;
   a.group_flag = b->d_group_flag;
   a.env_list = b->d_env_list;
+  a.env_off = b->d_env_off;
+  a.move_mask = b->d_move_mask;
   a.count0 = b->g.synth_sample_count;
   a.rng0 = b->g.noise_rng;
   a.n_voices = b->n_voices;

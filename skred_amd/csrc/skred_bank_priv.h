@@ -47,8 +47,10 @@ struct skred_bank {
   int8_t *h_mod;              /* [4][n_padded] modulator lane inside the 64-voice group (fm, am, pm, cz) or -1 */
   int *h_level;               /* [n_padded] dependency level of each voice (modulated banks) */
   int *d_level;
-  int32_t *d_env_list;        /* the flagged slices, compacted (sk_compact_flags_kernel) */
-  int32_t *d_group_flag;      /* per 128-voice wave slice: left to sk_render_env2_kernel; one more slot: the ticket */
+  int32_t *d_env_list;        /* the voices handed to sk_render_env2_kernel, in ascending order (sk_expand_moving_kernel) */
+  int32_t *d_env_off;         /* per 128-voice wave slice: where its voices start in d_env_list; one more slot: their number */
+  uint64_t *d_move_mask;      /* per slice, two lane masks: which of its voices were handed over */
+  int32_t *d_group_flag;      /* per 128-voice wave slice: voices handed over; one more slot: the ticket */
   int max_level;
   int class_dirty;
   int cnt_real, cnt_filter, cnt_env, cnt_exotic, cnt_stops, cnt_fm;   /* voices per SKC_* bit (kept incrementally) */

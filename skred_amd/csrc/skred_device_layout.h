@@ -124,10 +124,13 @@ typedef struct {
   const float *tables;     /* HBM pool */
   float *partial;          /* [n_workgroups][num_frames][2] pre-master partial sums */
   float *stems;            /* [num_frames][n_voices][2] or NULL */
-  int32_t *group_flag;     /* [n_groups*2]: 1 = this 128-voice wave slice has an envelope in motion (fast2 -> env2 hand-over);
-                              [n_groups*2] (one more): ticket of the last launch that deferred any slice */
-  int32_t *env_list;       /* [n_groups*2 + 1]: the flagged slices in ascending order, [n_groups*2] = how many
-                              (sk_compact_flags_kernel, between the two kernels) */
+  int32_t *group_flag;     /* [n_groups*2]: how many voices of this 128-voice wave slice have an envelope in motion and are
+                              left to sk_render_env2_kernel (fast2 -> env2 hand-over, voice by voice);
+                              [n_groups*2] (one more): ticket of the last launch that handed any voice over */
+  uint64_t *move_mask;     /* [n_groups*2][2]: which lanes (voices slice*128 + c*64 + lane, c = 0 / 1) those are */
+  int32_t *env_off;        /* [n_groups*2 + 1]: exclusive prefix sums of the counts, [n_groups*2] = their total
+                              (sk_scan_moving_kernel, between the two render kernels) */
+  int32_t *env_list;       /* [n_groups*SK_GROUP]: the handed-over voices in ascending order (sk_expand_moving_kernel) */
   uint64_t count0;         /* synth_sample_count before the first frame */
   uint64_t rng0;           /* noise LCG state before the first frame */
   int32_t n_voices;        /* real voices (stems indexing) */

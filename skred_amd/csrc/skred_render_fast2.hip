@@ -443,14 +443,26 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
   wsum = (wsum == wsum0) ? wsum0 + NW * SK_CHUNK : wsum0;
 
 // load the two voices of this lane (vbase + lane, vbase + 64 + lane); returns whether the wave is tame
+// a voice that contributes nothing to this launch: inert numbers -> exact zeros, table index 0 (see sk_render_fast_kernel)
+__device__ __forceinline__ void fast2_make_inert(Fast2Regs &r, Env2Regs &e, int c) {
+  r.inc[c] = 0.0f; r.lo[c] = 0.0f; r.hi[c] = 1.0f; r.phase[c] = 0.0f;
+  r.toff4[c] = 0; r.tsize_m1[c] = 0;
+  r.k[c] = 0.0f; r.sgain[c] = 0.0f; e.ampv[c] = 0.0f; r.gain_const[c] = 0.0f;
+  r.b0[c] = r.b1[c] = r.b2[c] = r.a1[c] = r.a2[c] = 0.0f;
+  r.x1[c] = r.x2[c] = r.y1[c] = r.y2[c] = 0.0f;
+  r.pan_lr[c] = (v2f){0.0f, 0.0f}; r.rw[c] &= ~SKR_ENV_ACTIVE;
+}
+
+// vidx[c]: the lane's two voices (sk_render_fast2_kernel: vbase + c*64 + lane of its 128-voice slice; sk_render_env2_kernel:
+// two entries of the hand-over list); absent[c]: no voice in that slot (the list's ragged end) -- treated as dead and
+// never stored.
 template <bool FILTER, bool ENV, bool MIXED>
-__device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase, int lane, Fast2Regs &r,
+__device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, const int vidx[2], const bool absent[2], int lane, Fast2Regs &r,
                                            Env2Regs &e, bool dead[2], bool silent[2], bool released[2],
-                                           uint64_t t_start[2], uint64_t t_release[2], int vidx[2], bool &tame_m) {
+                                           uint64_t t_start[2], uint64_t t_release[2], bool &tame_m) {
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    const int v = vbase + c * 64 + lane;            // vbase: first voice of this wave's 128-voice slice
-    vidx[c] = v;
+    const int v = vidx[c];
     const uint4 osc = *reinterpret_cast<const uint4 *>(&a.ro[SKP_OSC][v]);
     const uint4 tab = *reinterpret_cast<const uint4 *>(&a.ro[SKP_TAB][v]);
     const uint4 gn = *reinterpret_cast<const uint4 *>(&a.ro[SKP_GAIN][v]);
@@ -500,16 +512,9 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase,
       r.fake_active[c] = !(r.rw[c] & SKR_ENV_ACTIVE);
       r.rw[c] |= SKR_ENV_ACTIVE;
     }
-    dead[c] = (r.rw[c] & SKR_FINISHED) || e.ampv[c] == 0.0f || (flags & SKF_INERT);
+    dead[c] = absent[c] || (r.rw[c] & SKR_FINISHED) || e.ampv[c] == 0.0f || (flags & SKF_INERT);
     silent[c] = dead[c] || (flags & SKF_MUTED);
-    if (dead[c]) {   // never stored back: inert numbers -> exact zeros, table index 0 (see sk_render_fast_kernel)
-      r.inc[c] = 0.0f; r.lo[c] = 0.0f; r.hi[c] = 1.0f; r.phase[c] = 0.0f;
-      r.toff4[c] = 0; r.tsize_m1[c] = 0;
-      r.k[c] = 0.0f; r.sgain[c] = 0.0f; e.ampv[c] = 0.0f; r.gain_const[c] = 0.0f;
-      r.b0[c] = r.b1[c] = r.b2[c] = r.a1[c] = r.a2[c] = 0.0f;
-      r.x1[c] = r.x2[c] = r.y1[c] = r.y2[c] = 0.0f;
-      r.pan_lr[c] = (v2f){0.0f, 0.0f}; r.rw[c] &= ~SKR_ENV_ACTIVE;
-    }
+    if (dead[c]) fast2_make_inert(r, e, c);   // never stored back
   }
   r.span = r.hi - r.lo;
   r.span2 = r.span + r.span;
@@ -526,12 +531,14 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, int vbase,
   return tame_m && !__any(muted_lane);
 }
 
+// skip[c]: the slot is not this kernel's to store (a voice handed to sk_render_env2_kernel, or no voice at all)
 template <bool MIXED>
 __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fast2Regs &r, const bool dead[2],
-                                            const int vidx[2]) {
+                                            const int vidx[2], const bool skip[2]) {
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int v = vidx[c];
+    if (skip[c]) continue;
     if (!dead[c]) {
       uint4 s0, s1;
       const bool keep = MIXED && !r.filt[c];           // an unfiltered voice's delay line goes back as it came
@@ -584,13 +591,19 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
 // 16 waves, 4 per SIMD -- share a CU's LDS with ONE copy of the tables each (four per SIMD needs <= 40 KB per
 // 256-thread workgroup otherwise, and tables + tiles take ~46 KB); global-table banks keep 4 (their table windows
 // scale with the wave count).
+/* store what this kernel rendered: not the voices handed over (lane masks m0 / m1) */
+#define SK_FAST2_STORE_MINE()                                                                        \
+  {                                                                                                  \
+    const bool skip_[2] = {(bool)((m0 >> lane) & 1), (bool)((m1 >> lane) & 1)};                      \
+    fast2_store<MIXED>(a, r, dead, vidx, skip_);                                                     \
+  }
 template <bool TAB_LDS> struct Fast2Shape { static constexpr int NW = TAB_LDS ? SK_FAST2_NW_LDS : 4; };
 
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED>
 __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
   constexpr int NW = Fast2Shape<TAB_LDS>::NW;
   SK_FAST2_PROLOGUE()
-  (void)n_groups2; (void)n_flags;
+  (void)n_groups2;
   bool first_pass = true;
   bool row_published = false;
   for (int g = bid; g < n_pass; g += a.n_rows) {
@@ -599,34 +612,55 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     Env2Regs e;
     bool dead[2], silent[2], released[2];
     uint64_t t_start[2], t_release[2];
-    int vidx[2];
     bool tame_m;
-    const bool tame = fast2_load<FILTER, ENV, MIXED>(a, g * (NW * 128) + wave * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx, tame_m);
+    const int slice = g * NW + wave;
+    const int vidx[2] = {slice * 128 + lane, slice * 128 + 64 + lane};
+    const bool absent[2] = {false, false};
+    uint64_t m0 = 0, m1 = 0;                          // the lanes whose voice 0 / 1 is handed over (wave-uniform masks)
+    const bool tame = fast2_load<FILTER, ENV, MIXED>(a, vidx, absent, lane, r, e, dead, silent, released, t_start, t_release, tame_m);
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
     bool wave_ok = true;
     if (ENV) {
       // constant envelope level on the first frame of the launch <=> for the whole launch (absorbing codes)
-      bool ok = true;
+      bool moving[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const uint64_t d_on = a.count0 + 1 - t_start[c], d_off = a.count0 + 1 - t_release[c];
         const int code = env_stage_code((r.rw[c] & SKR_ENV_ACTIVE) != 0, released[c], (float)d_on, (float)d_off,
                                         e.att[c], e.attdec[c], e.rel[c]);
-        ok = ok && (dead[c] || code == 0 || code == 3 || code == 5);
+        moving[c] = !(dead[c] || code == 0 || code == 3 || code == 5);
         const float level = code == 3 ? e.susv[c] : 0.0f;
         r.gain_const[c] = e.ampv[c] * (level * e.velv[c]);                       // synth.c:582,588
         if (!dead[c] && code == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;                   // synth.c:429
       }
-      // hand-over per WAVE (128 voices): a wave with an envelope in motion leaves its slice to sk_render_env2_kernel,
-      // the others render theirs here.  (Notes start and end all the time in a live bank: per 512-voice group almost
-      // every group would be deferred, per wave a good share still is not.)
-      wave_ok = __all(ok);
+      // hand-over per VOICE: a voice with its envelope in motion is left to sk_render_env2_kernel (which collects such
+      // voices from the whole bank into full waves) and sits out this launch here with its pan gains at zero -- exact
+      // zeros into the mix, nothing stored.  (Notes start and end all the time in a live bank: almost every 128-voice slice holds a few such voices,
+      // and a slice handed over whole makes the envelope kernel render the ~90 % of its lanes that are merely held.)
+      m0 = __ballot(moving[0]); m1 = __ballot(moving[1]);
+      const int n_moving = __popcll(m0) + __popcll(m1);
       if (lane == 0) {
-        a.group_flag[g * NW + wave] = wave_ok ? 0 : 1;
-        if (!wave_ok) a.group_flag[n_flags] = (int32_t)a.launch_ticket;     // "this launch deferred something"
+        a.group_flag[slice] = n_moving;
+        a.move_mask[2 * slice] = m0;
+        a.move_mask[2 * slice + 1] = m1;
+        if (n_moving) a.group_flag[n_flags] = (int32_t)a.launch_ticket;         // "this launch handed something over"
       }
-      if (!__syncthreads_or(wave_ok ? 1 : 0)) continue;   // nothing of this pass is rendered here
+      if (n_moving) {                                 // (wave-uniform: the steady state pays for none of this)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          if (moving[c]) {     // (two numbers, not fast2_make_inert's twenty-five: the kernel sits at its register budget)
+            r.pan_lr[c] = (v2f){0.0f, 0.0f};           // it walks its oscillator for nothing and adds exact zeros
+            r.k[c] = 0.0f;                             // its smoother counts as stalled (fast2_smoother_stalled is a wave vote)
+          }
+        wave_ok = __any((!dead[0] && !moving[0]) || (!dead[1] && !moving[1]));   // (nothing left to render: zeros to the chunk sums)
+      }
+      if (!__syncthreads_or(wave_ok ? 1 : 0)) {       // nothing of this pass is rendered here
+#pragma unroll
+        for (int c = 0; c < 2; ++c)                   // (really dead voices still get voice_sample = 0, synth.c:532,538)
+          if (dead[c]) reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][vidx[c]])[2] = 0u;
+        continue;
+      }
     }
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
@@ -637,7 +671,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
       }
       SK_FAST2_FLUSH(!first_pass)
     }
-    if (wave_ok) fast2_store<MIXED>(a, r, dead, vidx);
+    SK_FAST2_STORE_MINE()
     first_pass = false;
     row_published = publish;
   }
@@ -649,7 +683,8 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
   if (a.finish) sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds), row_published);
 }
 
-// Groups with envelopes in motion (flagged by sk_render_fast2_kernel, which ran just before on the stream).
+// The voices with envelopes in motion (handed over by sk_render_fast2_kernel, which ran just before on the stream), 128
+// list entries per wave.
 #ifndef SK_ENV2_MIN_WAVES
 #define SK_ENV2_MIN_WAVES 3      /* the envelope machinery wants ~170 VGPRs: 3 waves per SIMD measured best (2: no spills, 4: 220 B of scratch) */
 #endif
@@ -657,24 +692,31 @@ template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
   constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
   SK_FAST2_PROLOGUE_((int)blockIdx.x - a.wg_shift < (a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows) &&
-                     ((int)blockIdx.x - a.wg_shift) * 4 < a.env_list[a.n_groups * 2])
+                     ((int)blockIdx.x - a.wg_shift) * (NW * 128) < a.env_off[a.n_groups * 2])
   (void)n_pass; (void)n_groups2;
-  // the slices sk_render_fast2_kernel left to this kernel, compacted in ascending order (sk_compact_flags_kernel): every
-  // workgroup pass takes four of them, so the launch costs what the flagged share of the bank costs
-  const int n_mine = a.env_list[n_flags];
+  // the voices sk_render_fast2_kernel left to this kernel, in ascending order (sk_scan_moving_kernel +
+  // sk_expand_moving_kernel): every workgroup pass takes 512 of them, so the launch costs what those voices cost
+  const int n_mine = a.env_off[n_flags];
   constexpr bool publish = false;   // (a workgroup of this kernel may have no pass at all: sk_finish_block copies every row out)
   const int n_workers = a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows;
-  for (int g = bid < n_workers ? bid : n_mine; g * 4 < n_mine; g += n_workers) {
-    const bool mine = g * 4 + wave < n_mine;
-    const int slice = mine ? a.env_list[g * 4 + wave] : 0;
+  for (int g = bid < n_workers ? bid : n_mine; g * (NW * 128) < n_mine; g += n_workers) {
+    const int p0 = g * (NW * 128) + wave * 128;          // this wave's first list entry
+    const bool mine = p0 < n_mine;
     Fast2Regs r;
     Env2Regs e;
     bool dead[2], silent[2], released[2];
     uint64_t t_start[2], t_release[2];
-    int vidx[2];
+    int vidx[2] = {0, 0};
+    bool absent[2] = {true, true};
     bool tame_m = false, tame = false, loz = false;
     if (mine) {
-      tame = fast2_load<FILTER, true, MIXED>(a, slice * 128, lane, r, e, dead, silent, released, t_start, t_release, vidx, tame_m);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int p = p0 + c * 64 + lane;
+        absent[c] = p >= n_mine;
+        vidx[c] = absent[c] ? 0 : a.env_list[p];
+      }
+      tame = fast2_load<FILTER, true, MIXED>(a, vidx, absent, lane, r, e, dead, silent, released, t_start, t_release, tame_m);
       loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     }
     (void)loz; (void)tame; (void)tame_m;
@@ -750,29 +792,41 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
       }   // mine
       SK_FAST2_FLUSH(true)
     }
-    if (mine) fast2_store<MIXED>(a, r, dead, vidx);
+    if (mine) fast2_store<MIXED>(a, r, dead, vidx, absent);
   }
   if (a.finish) sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds));
 }
 
 // ---------------------------------------------------------------- launcher (C linkage)
 
-// flags[n] (0/1 per 128-voice slice) -> list of the flagged slice indices in ascending order, list[n] = their number.
-// One workgroup: every thread counts its contiguous share, an LDS scan places the shares, every thread writes its own.
-__global__ __launch_bounds__(256) void sk_compact_flags_kernel(const int32_t *__restrict__ flags, int n, int32_t *__restrict__ list) {
+// counts[n] (voices handed over per 128-voice slice) -> off[n] exclusive prefix sums, off[n] = their total.  One
+// workgroup: every thread sums its contiguous share, an LDS scan places the shares, every thread writes its own.
+__global__ __launch_bounds__(256) void sk_scan_moving_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restrict__ off) {
   __shared__ int base[257];
   const int t = threadIdx.x;
   const int per = (n + 255) / 256, lo = min(t * per, n), hi = min(lo + per, n);
   int c = 0;
-  for (int i = lo; i < hi; ++i) c += flags[i] != 0;
+  for (int i = lo; i < hi; ++i) c += counts[i];
   base[t + 1] = c;
   if (t == 0) base[0] = 0;
   __syncthreads();
   if (t == 0) for (int i = 1; i <= 256; ++i) base[i] += base[i - 1];
   __syncthreads();
   int w = base[t];
-  for (int i = lo; i < hi; ++i) if (flags[i] != 0) list[w++] = i;
-  if (t == 255) list[n] = base[256];
+  for (int i = lo; i < hi; ++i) { off[i] = w; w += counts[i]; }
+  if (t == 255) off[n] = base[256];
+}
+
+// One wavefront per slice: its handed-over voices (two lane masks) go to list[off[slice] ...] in ascending voice order.
+__global__ __launch_bounds__(256) void sk_expand_moving_kernel(const int32_t *__restrict__ counts, const uint64_t *__restrict__ mask,
+                                                                const int32_t *__restrict__ off, int n, int32_t *__restrict__ list) {
+  const int lane = threadIdx.x & 63, slice = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  if (slice >= n || counts[slice] == 0) return;
+  const uint64_t m0 = mask[2 * slice], m1 = mask[2 * slice + 1];
+  const uint64_t below = ((uint64_t)1 << lane) - 1;
+  const int o = off[slice];
+  if ((m0 >> lane) & 1) list[o + __popcll(m0 & below)] = slice * 128 + lane;
+  if ((m1 >> lane) & 1) list[o + __popcll(m0) + __popcll(m1 & below)] = slice * 128 + 64 + lane;
 }
 
 // sk_render_fast2_kernel renders the constant-envelope slices and flags the others; when the bank has
@@ -807,18 +861,22 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
   const bool mixed = (args->fast_mode & SKM_MIXED) != 0;     // filter / envelope on some voices only: per-lane flags
   const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
+#define SK_FAST2_COLLECT()                                                                              \
+  hipLaunchKernelGGL(sk_scan_moving_kernel, dim3(1), dim3(256), 0, stream, args->group_flag, args->n_groups * 2, args->env_off); \
+  hipLaunchKernelGGL(sk_expand_moving_kernel, dim3((unsigned)((args->n_groups * 2 + 3) / 4)), dim3(256), 0, stream,          \
+                     args->group_flag, args->move_mask, args->env_off, args->n_groups * 2, args->env_list);
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
     if (mixed) {                                                                                        \
       hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, true>), grid_first, block, lds_fast2, stream, first);  \
       if (E && !args->skip_env2) {                                                                      \
-        hipLaunchKernelGGL(sk_compact_flags_kernel, dim3(1), dim3(256), 0, stream, args->group_flag, args->n_groups * 2, args->env_list); \
+        SK_FAST2_COLLECT()                                                                              \
         hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, true>), grid, block_env, lds_env2, stream, second); \
       }                                                                                                 \
     } else {                                                                                            \
       hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, false>), grid_first, block, lds_fast2, stream, first); \
       if (E && !args->skip_env2) {                                                                      \
-        hipLaunchKernelGGL(sk_compact_flags_kernel, dim3(1), dim3(256), 0, stream, args->group_flag, args->n_groups * 2, args->env_list); \
+        SK_FAST2_COLLECT()                                                                              \
         hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, false>), grid, block_env, lds_env2, stream, second); \
       }                                                                                                 \
     }                                                                                                   \
@@ -834,5 +892,6 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
     SK_FAST2_CASE(14, true, true, true, 0)   SK_FAST2_CASE(15, true, true, true, 1)
   }
 #undef SK_FAST2_CASE
+#undef SK_FAST2_COLLECT
   return (int)hipGetLastError();
 }

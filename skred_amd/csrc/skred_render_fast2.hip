@@ -44,6 +44,8 @@ struct Env2Regs {                 // sk_render_env2_kernel only
   float att[2], attdec[2], dec[2], rel[2];
   v2f ampv, velv, susv, omsv;     // amp, velocity, sustain_level, 1 - sustain_level
   v2f clk, ebase, eden, erinv, eA, eB, eC;   // "ramp" spans: see fast2_env_span
+  v2f clk2, ebase2, eden2, erinv2, eA2, eB2, eC2, bnd;   // blocks with ONE stage change per lane: the stage after it, and
+                                                         // the clock value (of `clk`) from which it applies (fast2_env_span2)
   float tf[2], trf[2];            // general frames: this frame's clocks
 };
 
@@ -111,6 +113,43 @@ __device__ __forceinline__ void fast2_env_span(Fast2Regs &r, Env2Regs &e, int c,
   same = same && (dead || (code0 == code1 && d >= 0x1p-40f && d <= 0x1p40f));
   // a release that has run out: the reference clears is_active on the first frame it notices (synth.c:429)
   if (!dead && code0 == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;
+}
+
+// The same for a span in which a lane may change stage ONCE, to the stage that follows its own (attack -> decay, decay ->
+// sustain or release, release -> finished): the ramp constants of the stage after the change go to the second set and
+// `bnd` is the value of the first set's clock from which they apply -- the comparison the reference makes on that frame
+// (synth.c:403,408,420: `t < attack_time`, `t < decay_start + decay_time`, `t_release < release_time`).  A lane that keeps
+// its stage gets bnd = +inf.  `ok` stays true while no lane does anything else (two changes inside the span: attack or
+// decay shorter than the span, or a release that has already run out when the decay ends).
+__device__ __forceinline__ void fast2_env_span2(Fast2Regs &r, Env2Regs &e, int c, bool dead, bool released,
+                                                float t1, float tr1, float tN, float trN, float t0, float tr0, bool &ok) {
+  const bool act = (r.rw[c] & SKR_ENV_ACTIVE) != 0;
+  const int code0 = env_stage_code(act, released, t1, tr1, e.att[c], e.attdec[c], e.rel[c]);
+  const int code1 = env_stage_code(act, released, tN, trN, e.att[c], e.attdec[c], e.rel[c]);
+  const bool step = code0 != code1;
+  const bool next_stage = (code0 == 1 && code1 == 2) || (code0 == 2 && (code1 == 3 || code1 == 4)) || (code0 == 4 && code1 == 5);
+  float den[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int code = h ? code1 : code0;
+    const float level = code == 3 ? e.susv[c] : 0.0f;
+    const float A = code == 1 ? 0.0f : 1.0f;
+    const float B = code == 1 ? 1.0f : (code == 2 ? -e.omsv[c] : (code == 4 ? -1.0f : 0.0f));
+    const float C = code == 4 ? e.susv[c] : ((code == 1 || code == 2) ? 1.0f : level);
+    const float clk = code == 4 ? tr0 : t0;
+    const float base = code == 2 ? e.att[c] : 0.0f;
+    const float d = code == 1 ? e.att[c] : (code == 2 ? e.dec[c] : (code == 4 ? e.rel[c] : 1.0f));
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float ri = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    den[h] = d;
+    if (h == 0) { e.eA[c] = A; e.eB[c] = B; e.eC[c] = C; e.clk[c] = clk; e.ebase[c] = base; e.eden[c] = d; e.erinv[c] = ri; }
+    else        { e.eA2[c] = A; e.eB2[c] = B; e.eC2[c] = C; e.clk2[c] = clk; e.ebase2[c] = base; e.eden2[c] = d; e.erinv2[c] = ri; }
+  }
+  e.bnd[c] = !step ? __builtin_huge_valf() : (code0 == 1 ? e.att[c] : (code0 == 2 ? e.attdec[c] : e.rel[c]));
+  ok = ok && (dead || ((!step || next_stage) && den[0] >= 0x1p-40f && den[0] <= 0x1p40f && den[1] >= 0x1p-40f && den[1] <= 0x1p40f));
+  // a release that runs out: the reference clears is_active on the first frame it notices (synth.c:429); nothing in this
+  // span reads the flag again
+  if (!dead && (code0 == 5 || code1 == 5)) r.rw[c] &= ~SKR_ENV_ACTIVE;
 }
 
 // General frames (a lane changes stage inside the block): amp_envelope_step as the reference writes it.
@@ -207,6 +246,27 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
     rem = __builtin_elementwise_fma(-e.eden, q, num);
     q = __builtin_elementwise_fma(rem, e.erinv, q);
     const v2f lvl = e.eC * (e.eA + e.eB * q);
+    gain = e.ampv * (lvl * e.velv);
+  } else if (EM == 4) {                                // one stage change per lane at most: fast2_env_span2
+    e.clk = e.clk + 1.0f;
+    e.clk2 = e.clk2 + 1.0f;
+    v2f num, den, rinv, A, B, C;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bool after = e.clk[c] >= e.bnd[c];           // the reference's `t < limit` failed on this frame
+      num[c] = after ? e.clk2[c] - e.ebase2[c] : e.clk[c] - e.ebase[c];
+      den[c] = after ? e.eden2[c] : e.eden[c];
+      rinv[c] = after ? e.erinv2[c] : e.erinv[c];
+      A[c] = after ? e.eA2[c] : e.eA[c];
+      B[c] = after ? e.eB2[c] : e.eB[c];
+      C[c] = after ? e.eC2[c] : e.eC[c];
+    }
+    v2f q = num * rinv;
+    v2f rem = __builtin_elementwise_fma(-den, q, num);
+    q = __builtin_elementwise_fma(rem, rinv, q);
+    rem = __builtin_elementwise_fma(-den, q, num);
+    q = __builtin_elementwise_fma(rem, rinv, q);
+    const v2f lvl = C * (A + B * q);
     gain = e.ampv * (lvl * e.velv);
   } else {
     gain.x = fast2_env_general(r, e, 0, rel0);
@@ -760,11 +820,22 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
             fast2_env_span(r, e, c, dead[c], released[c], cb_tf[c] + fb + 1.0f, cb_trf[c] + fb + 1.0f,
                            cb_tf[c] + fb + 8.0f, cb_trf[c] + fb + 8.0f, cb_tf[c] + fb, cb_trf[c] + fb, st, same);
           const bool b_const = __all(st), b_ramp = __all(same);
+          bool b_step = false;
+          if (!b_const && !b_ramp) {                  // some lane changes stage in this block: once, to the next stage?
+            bool ok2 = true;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+              fast2_env_span2(r, e, c, dead[c], released[c], cb_tf[c] + fb + 1.0f, cb_trf[c] + fb + 1.0f,
+                              cb_tf[c] + fb + 8.0f, cb_trf[c] + fb + 8.0f, cb_tf[c] + fb, cb_trf[c] + fb, ok2);
+            b_step = __all(ok2);
+          }
 #if SK_LDS_REDUCE
           if (TAB_LDS && b_const) SK_FAST2_LDS_BLOCK(jb, 0)
           else if (TAB_LDS && b_ramp) SK_FAST2_LDS_BLOCK(jb, 1)
+          else if (TAB_LDS && b_step) SK_FAST2_LDS_BLOCK(jb, 4)
           else if (!TAB_LDS && b_const) SK_FAST2_WIN_BLOCK(jb, 0)
           else if (!TAB_LDS && b_ramp) SK_FAST2_WIN_BLOCK(jb, 1)
+          else if (!TAB_LDS && b_step) SK_FAST2_WIN_BLOCK(jb, 4)
           else
 #endif
           {

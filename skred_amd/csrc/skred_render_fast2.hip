@@ -413,8 +413,10 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#define SK_XT2 68   /* floats per tile row (see SK_XT in skred_render_fast.hip) */
 #define SK_FAST2_LDS_BLOCK_Z(J, EM_, LOZ_, MUTE_)                                                                       \
   {                                                                                                      \
+    float *const xt_ = reinterpret_cast<float *>(xp);   /* the wave's tile: [8 frames][SK_XT2] folded (L | R) pair sums */ \
     /* software pipeline: the table gather of the NEXT frame is issued before the biquad/gain chain of the   \
        current one (the source order matters: the compiler may not move an LDS read above the tile write) */  \
     v2f s0_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                                      \
@@ -424,21 +426,16 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
       fast2_post<FILTER, EM_, true, MIXED, MUTE_>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
       if (q_ < 6) s0_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                            \
       fast2_post<FILTER, EM_, true, MIXED, MUTE_>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
-      xp[q_ * 65 + lane] = make_float2(l0, r0);                                                          \
-      xp[(q_ + 1) * 65 + lane] = make_float2(l1, r1);                                                    \
+      xt_[q_ * SK_XT2 + lane] = fold_lr(l0, r0);                                                         \
+      xt_[(q_ + 1) * SK_XT2 + lane] = fold_lr(l1, r1);                                                   \
     }                                                                                                    \
     SK_WAVE_SYNC()                                                                                       \
-    {                                                                                                    \
-      const float2 *src_ = xp + (lane & 7) * 65 + (lane >> 3) * 8;                                       \
-      float2 a0_ = src_[0];                                                                              \
-      _Pragma("unroll") for (int i_ = 1; i_ < 8; ++i_) { const float2 t_ = src_[i_]; a0_.x += t_.x; a0_.y += t_.y; } \
-      xq[lane] = a0_; /* == xq[seg * 8 + f] */                                                           \
-    }                                                                                                    \
-    SK_WAVE_SYNC()                                                                                       \
-    if (lane < 8) {                                                                                      \
-      float2 t0_ = xq[lane];                                                                             \
-      _Pragma("unroll") for (int g_ = 1; g_ < 8; ++g_) { const float2 t_ = xq[g_ * 8 + lane]; t0_.x += t_.x; t0_.y += t_.y; } \
-      wsum[wave * SK_CHUNK + (J) + lane] = t0_;                                                          \
+    {   /* lane (f, seg) adds 8 floats of tile row f: segments 0..3 hold L pair sums, 4..7 R pair sums */ \
+      const float4 *src_ = reinterpret_cast<const float4 *>(xt_ + (lane & 7) * SK_XT2 + (lane >> 3) * 8); \
+      const float4 a_ = src_[0], b_ = src_[1];                                                           \
+      float t_ = ((((((a_.x + a_.y) + a_.z) + a_.w) + b_.x) + b_.y) + b_.z) + b_.w;                      \
+      t_ = row_pair_add(row_ror8_add(t_));       /* -> lanes 0..7 (L of frames 0..7), 32..39 (R) */      \
+      if ((lane & 24) == 0) reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (J) + (lane & 7)])[lane >> 5] = t_; \
     }                                                                                                    \
     SK_WAVE_SYNC()                                                                                       \
   }

@@ -23,7 +23,7 @@ typedef struct {
   size_t cap;                 /* bytes */
   hipEvent_t ev;              /* fired once the copy and the scatter that read them have run */
 } sk_upd_slot_t;
-#define SK_FAST2_MIN_VOICES 245760   /* banks at least this large use two voices per lane (measured crossover, 512-frame blocks, C2 recipe: 196608 voices 86 vs 95 us, 262144 voices 108 vs 101 us; profiles/r02_v1_measure_banks.txt) */
+#define SK_FAST2_MIN_VOICES 212992   /* banks at least this large use two voices per lane (measured crossover, 512-frame blocks, C2 recipe: 196608 voices 86 vs 95 us, 262144 voices 108 vs 101 us; profiles/r02_v1_measure_banks.txt) */
 
 struct skred_bank {
   int device;

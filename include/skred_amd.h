@@ -308,7 +308,10 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
                                       launch; 0: none).  skred_bank_last_render_ms / _timing_summary report the bracketed
                                       launches; an event pair costs ~6 us of stream time on an MI355X, hence the knob */,
        SKRED_OPT_OVERLAP_TAIL = 3 /* accepted and ignored (the block's mix-down and master stage run inside the render
-                                     kernel: there is no tail left to overlap) */ };
+                                     kernel: there is no tail left to overlap) */,
+       SKRED_OPT_FM2_MIN_VOICES = 5 /* bank size from which a two-operator FM bank (every carrier an even voice, frequency-
+                                       modulated by the voice after it and by nothing else) keeps carrier and modulator in
+                                       one lane of the two-voices-per-lane kernel */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */

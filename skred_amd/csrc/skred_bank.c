@@ -67,7 +67,7 @@ static int bank_build(skred_bank_t *b) {
   }
   free(inert);
   HIP_TRY(e);
-  b->h_class = (uint8_t *)calloc((size_t)b->n_padded, 1);
+  b->h_class = (uint16_t *)calloc((size_t)b->n_padded, sizeof(uint16_t));
   b->h_mod = (int8_t *)malloc((size_t)b->n_padded * 4);
   b->h_level = (int *)calloc((size_t)b->n_padded, sizeof(int));
   if (!b->h_class || !b->h_mod || !b->h_level) return fail(SKRED_E_NO_MEM, "calloc");
@@ -109,6 +109,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   b->n_voices = n_voices;
   b->n_groups = ((n_voices + 4 * SK_GROUP - 1) / (4 * SK_GROUP)) * 4;   /* multiple of 4: the two-per-lane kernel takes up to 1024 voices per pass */
   b->fast2_min_voices = SK_FAST2_MIN_VOICES;
+  b->fm2_min_voices = SK_FM2_MIN_VOICES;
   b->timing_every = 1;
   b->n_padded = b->n_groups * SK_GROUP;
   b->class_dirty = 1;
@@ -219,7 +220,7 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
 static int classify(skred_bank_t *b) {
   if (b->cnt_future > 0 && b->g.synth_sample_count >= b->future_horizon) {
     /* the clock has passed every note-on / note-off that was written ahead of it: those voices are ordinary again */
-    for (int v = 0; v < b->n_padded; v++) b->h_class[v] &= (uint8_t)~SKC_FUTURE;
+    for (int v = 0; v < b->n_padded; v++) b->h_class[v] &= (uint16_t)~SKC_FUTURE;
     b->cnt_future = 0;
     b->class_dirty = 1;
   }
@@ -235,6 +236,7 @@ static int classify(skred_bank_t *b) {
     if ((filt && filt != real) || (env && env != real)) m |= SKM_MIXED;   /* some voices only: per-lane flags */
     if (b->cnt_stops) m |= SKM_STOPS;
     if (b->cnt_fm) m |= SKM_FM;
+    if (b->cnt_fm && !b->cnt_fm_odd && !b->cnt_stops) m |= SKM_FM_PAIR;   /* every carrier: an even voice modulated by the next one */
   }
   b->fast_mode = m;
   b->class_dirty = 0;
@@ -265,6 +267,7 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
   switch (option) {
     case SKRED_OPT_FORCE_GENERIC: b->force_generic = value != 0; return SKRED_OK;
     case SKRED_OPT_FAST2_MIN_VOICES: b->fast2_min_voices = value; b->fast2_min_user = 1; return SKRED_OK;
+    case SKRED_OPT_FM2_MIN_VOICES: b->fm2_min_voices = value; return SKRED_OK;
     case SKRED_OPT_KERNEL_TIMING: b->timing_every = value < 0 ? 0 : value; return SKRED_OK;
     case SKRED_OPT_OVERLAP_TAIL: return SKRED_OK;   /* accepted and ignored: a block is one launch, there is no tail to overlap */
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
@@ -401,6 +404,12 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   if ((a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_STOPS | SKM_FM)) && b->n_voices >= b->fast2_min_voices &&
       (a.lds_table_floats > 0 || b->fast2_min_user) && !d_stems)      /* (per-voice stems: the one-voice kernel writes them) */
     a.fast_mode |= SKM_TWO_PER_LANE;        /* (voices that finish mid-launch are handled by the one-per-lane kernel only) */
+  /* two-operator FM (every carrier an even voice, modulated by the voice after it): carrier and modulator share a lane of
+   * the two-per-lane kernel, so the per-frame exchange of the one-per-lane kernel disappears.  LDS-table banks. */
+  if (fast_ok && (a.fast_mode & SKM_FM_PAIR) && a.lds_table_floats > 0 && !d_stems && b->n_voices >= b->fm2_min_voices)
+    a.fast_mode |= SKM_TWO_PER_LANE;
+  else
+    a.fast_mode &= ~SKM_FM_PAIR;
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
   if (!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) {

@@ -23,6 +23,7 @@ typedef struct {
   size_t cap;                 /* bytes */
   hipEvent_t ev;              /* fired once the copy and the scatter that read them have run */
 } sk_upd_slot_t;
+#define SK_FM2_MIN_VOICES 16384     /* two-operator FM banks at least this large keep each (carrier, modulator) pair in one lane */
 #define SK_FAST2_MIN_VOICES 212992   /* banks at least this large use two voices per lane (measured crossover, 512-frame blocks, C2 recipe: 196608 voices 86 vs 95 us, 262144 voices 108 vs 101 us; profiles/r02_v1_measure_banks.txt) */
 
 struct skred_bank {
@@ -43,7 +44,7 @@ struct skred_bank {
   size_t gains_offset;        /* ... at this float offset */
   float *d_out, *d_stems;     /* scratch of skred_bank_render_host */
   size_t out_cap, stems_cap;
-  uint8_t *h_class;           /* per-voice SKC_* bits, shadow used to pick the kernel */
+  uint16_t *h_class;          /* per-voice SKC_* bits, shadow used to pick the kernel */
   int8_t *h_mod;              /* [4][n_padded] modulator lane inside the 64-voice group (fm, am, pm, cz) or -1 */
   int *h_level;               /* [n_padded] dependency level of each voice (modulated banks) */
   int *d_level;
@@ -54,6 +55,7 @@ struct skred_bank {
   int max_level;
   int class_dirty;
   int cnt_real, cnt_filter, cnt_env, cnt_exotic, cnt_stops, cnt_fm;   /* voices per SKC_* bit (kept incrementally) */
+  int cnt_fm_odd;             /* SKC_FM voices that are not the even half of a (carrier, next voice) pair (SKC_FM_ODD) */
   int cnt_escapes;            /* voices naming a modulator outside their aligned 64-voice group (SKC_ESCAPES) */
   uint64_t future_horizon;    /* the latest such clock value: once the bank's clock reaches it, no voice is "future" any more */
   int cnt_future;             /* enveloped voices whose note-on / note-off clock lay ahead of the bank's when they were written (SKC_FUTURE) */
@@ -61,6 +63,7 @@ struct skred_bank {
   uint32_t fast_mode;         /* SKM_* from classify() */
   int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
   int fast2_min_voices;       /* SKRED_OPT_FAST2_MIN_VOICES */
+  int fm2_min_voices;         /* SKRED_OPT_FM2_MIN_VOICES */
   int fast2_min_user;         /* ... was set by the caller (then it also applies to global-table banks) */
   int last_kernel;            /* SKRED_KERNEL_* used by the most recent render */
   skred_globals_t g;
@@ -98,6 +101,8 @@ struct skred_bank {
 #define SKC_FUTURE 64u  /* uses the envelope and its sample_start / sample_release lay AHEAD of the bank's clock when written: its stage
                            is not monotone (the unsigned clock difference wraps to "sustain" until the clock catches up, synth.c:401),
                            so "no envelope in motion" may not be latched while such a voice exists */
+#define SKC_FM_ODD 256u /* an SKC_FM voice that is anything but: even index, frequency-modulated by the voice after it and by nothing else
+                          -- the shape sk_render_fast2_kernel<FMP> renders with carrier and modulator in one lane */
 #define SKC_ESCAPES 128u /* names a modulator outside its aligned 64-voice group: the bank cannot be rendered until that is fixed */
 
 
@@ -115,7 +120,7 @@ int skred_amd_set_error(int code, const char *fmt, ...);
  * written.  phase_known: the host's voice_phase is the voice's current phase (an upload); 0 when only
  * parameters are being pushed and the phase lives on the device. */
 typedef struct {
-  uint8_t cls;          /* SKC_* (SKC_FUTURE as the HOST's envelope clocks say: only applied when those clocks travel) */
+  uint16_t cls;         /* SKC_* (SKC_FUTURE as the HOST's envelope clocks say: only applied when those clocks travel) */
   int8_t mod_lane[4];   /* modulator lane inside the 64-voice group (fm, am, pan, cz) or -1 */
   uint32_t features;    /* SKB_* this voice needs */
   uint64_t future_until;/* SKC_FUTURE: the later of the voice's two envelope clocks */

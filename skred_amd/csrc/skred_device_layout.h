@@ -76,6 +76,8 @@ enum {
                                       nothing else is modulated (sk_render_fast_kernel<STOPS>: previous-frame exchange by ds_bpermute) */
 #define SKM_MIXED       (1u << 6)  /* the biquad and / or the envelope is used by some voices only: per-lane flags
                                       (sk_render_fast_kernel's extended instantiation) */
+#define SKM_FM_PAIR     (1u << 7)  /* SKM_FM and every carrier is an even voice modulated by the next voice only, no SKM_STOPS features:
+                                      sk_render_fast2_kernel<FMP> keeps carrier and modulator in one lane (no exchange, no votes) */
 #define SKM_STOPS       (1u << 4)  /* some voice is a forward one-shot that finishes at its table end (sk_render_fast_kernel<STOPS>) */
 
 #define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */

@@ -38,6 +38,10 @@ struct Fast2Regs {
   v2f ox1, ox2, oy1, oy2;                  // delay lines as loaded: an unfiltered voice gets its own back untouched
   v2f phase, sgain, x1, x2, y1, y2, sample;
   uint32_t rw[2];
+  // FMP kernels (two-operator FM banks: the lane's voice 0 is an even voice, voice 1 the voice after it): voice 0 is
+  // frequency-modulated by voice 1's sample of the previous frame (synth.c:548-555: the carrier comes first in index order)
+  bool fm_on;
+  float fm_k, fm_depth;                    // voice_phase_inc[m] * voice_freq_scale[n];  voice_freq_mod_depth[n]
 };
 
 struct Env2Regs {                 // sk_render_env2_kernel only
@@ -178,9 +182,11 @@ __device__ __forceinline__ float fast2_env_general(Fast2Regs &r, Env2Regs &e, in
 // Oscillator half of a frame: advance both phases, wrap, fetch the two table samples.
 // LOZ: every lane of the wave has lo == 0 (no loop window: the plain LUT case).  Then ph0 - lo == ph0 and
 // lo + y == y exactly, so the wrapped phase lo + ((ph0 - lo) - span) is ph0 - span: one packed add instead of three.
-template <bool TAB_LDS, bool TAME, int INTERP, bool LOZ = false>
+template <bool TAB_LDS, bool TAME, int INTERP, bool LOZ = false, bool FMP = false>
 __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, const char *__restrict__ glb_tab) {
-  const v2f ph0 = r.phase + r.inc;
+  v2f inc = r.inc;
+  if (FMP && !TAME) inc.x = r.fm_on ? r.inc.x + r.fm_k * (r.sample.y * r.fm_depth) : r.inc.x;   // synth.c:551-554
+  const v2f ph0 = r.phase + inc;
   const v2f x = LOZ ? ph0 : ph0 - r.lo;
   const v2f phw = LOZ ? x - r.span : r.lo + (x - r.span);
   v2f ph;
@@ -299,12 +305,12 @@ __device__ __forceinline__ bool fast2_smoother_stalled(const Fast2Regs &r) {
   return __all(__float_as_uint(nxt.x) == __float_as_uint(r.sgain.x) && __float_as_uint(nxt.y) == __float_as_uint(r.sgain.y));
 }
 
-template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP, bool MIXED = false>
+template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP, bool MIXED = false, bool FMP = false>
 __device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
                                             const bool rel0, const bool rel1, const bool silent0,
                                             const bool silent1, const char *lds_tab,
                                             const char *__restrict__ glb_tab, float &out_l, float &out_r) {
-  const v2f s = fast2_osc<TAB_LDS, TAME, INTERP>(r, lds_tab, glb_tab);
+  const v2f s = fast2_osc<TAB_LDS, TAME, INTERP, false, FMP>(r, lds_tab, glb_tab);
   fast2_post<FILTER, EM, TAME, MIXED>(r, e, s, xn, xo, yn, yo, rel0, rel1, silent0, silent1, out_l, out_r);
 }
 
@@ -392,15 +398,15 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
 #define SK_FAST2_ONE(J, EM_, TAME_)                                                                      \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP, MIXED>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l, rr);   \
+    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP, MIXED, FMP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l, rr);   \
     SK_REDUCE_AND_STORE(J)                                                                               \
     { v2f t_ = r.x1; r.x1 = r.x2; r.x2 = t_; t_ = r.y1; r.y1 = r.y2; r.y2 = t_; }                        \
   }
 #define SK_FAST2_PAIR(J, EM_, TAME_)                                                                     \
   {                                                                                                      \
     float l0, r0, l1, r1;                                                                                \
-    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP, MIXED>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);  \
-    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP, MIXED>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);  \
+    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP, MIXED, FMP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);  \
+    fast2_frame<TAB_LDS, FILTER, EM_, TAME_, INTERP, MIXED, FMP>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);  \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
 // Eight frames (J..J+7) with the cross-lane sum through LDS instead of the VALU: every lane parks its (L,R) of
@@ -513,10 +519,11 @@ __device__ __forceinline__ void fast2_make_inert(Fast2Regs &r, Env2Regs &e, int 
 // vidx[c]: the lane's two voices (sk_render_fast2_kernel: vbase + c*64 + lane of its 128-voice slice; sk_render_env2_kernel:
 // two entries of the hand-over list); absent[c]: no voice in that slot (the list's ragged end) -- treated as dead and
 // never stored.
-template <bool FILTER, bool ENV, bool MIXED>
+template <bool FILTER, bool ENV, bool MIXED, bool FMP = false>
 __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, const int vidx[2], const bool absent[2], int lane, Fast2Regs &r,
                                            Env2Regs &e, bool dead[2], bool silent[2], bool released[2],
                                            uint64_t t_start[2], uint64_t t_release[2], bool &tame_m) {
+  float inc_raw1 = 0.0f;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int v = vidx[c];
@@ -528,6 +535,7 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, const int 
     const uint4 s2 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_MISC][v]);
     r.inc[c] = __uint_as_float(osc.x); r.lo[c] = __uint_as_float(osc.y);
     r.hi[c] = __uint_as_float(osc.z);
+    if (c == 1) inc_raw1 = r.inc[1];                   // voice_phase_inc[m], whatever m's own state is
     e.ampv[c] = __uint_as_float(osc.w);
     r.toff4[c] = (int)tab.x << 2; r.tsize_m1[c] = (int)tab.y - 1;
     const uint32_t flags = tab.z;
@@ -576,7 +584,15 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, const int 
   r.span = r.hi - r.lo;
   r.span2 = r.span + r.span;
   if (MIXED) { r.ox1 = r.x1; r.ox2 = r.x2; r.oy1 = r.y1; r.oy2 = r.y2; }
-  bool tame_lane = true, muted_lane = false;
+  r.fm_on = false; r.fm_k = 0.0f; r.fm_depth = 0.0f;
+  if (FMP) {
+    const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][vidx[0]]);
+    const uint4 mf = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODF][vidx[0]]);
+    r.fm_on = !dead[0] && (int)mi.x >= 0;            // (the host vouches that the modulator is the voice after it)
+    r.fm_k = inc_raw1 * __uint_as_float(mf.y);
+    r.fm_depth = __uint_as_float(mf.x);
+  }
+  bool tame_lane = !(FMP && r.fm_on), muted_lane = false;   // a modulated increment may be negative or long: general wrap
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     muted_lane = muted_lane || (silent[c] && !dead[c]);
@@ -656,7 +672,8 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
   }
 template <bool TAB_LDS> struct Fast2Shape { static constexpr int NW = TAB_LDS ? SK_FAST2_NW_LDS : 4; };
 
-template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED>
+// FMP: a two-operator FM bank (SKM_FM_PAIR) -- a lane holds voices 2i and 2i+1 of its slice, carrier and modulator.
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED, bool FMP = false>
 __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
   constexpr int NW = Fast2Shape<TAB_LDS>::NW;
   SK_FAST2_PROLOGUE()
@@ -671,10 +688,10 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     uint64_t t_start[2], t_release[2];
     bool tame_m;
     const int slice = g * NW + wave;
-    const int vidx[2] = {slice * 128 + lane, slice * 128 + 64 + lane};
+    const int vidx[2] = {FMP ? slice * 128 + 2 * lane : slice * 128 + lane, FMP ? slice * 128 + 2 * lane + 1 : slice * 128 + 64 + lane};
     const bool absent[2] = {false, false};
     uint64_t m0 = 0, m1 = 0;                          // the lanes whose voice 0 / 1 is handed over (wave-uniform masks)
-    const bool tame = fast2_load<FILTER, ENV, MIXED>(a, vidx, absent, lane, r, e, dead, silent, released, t_start, t_release, tame_m);
+    const bool tame = fast2_load<FILTER, ENV, MIXED, FMP>(a, vidx, absent, lane, r, e, dead, silent, released, t_start, t_release, tame_m);
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
     bool wave_ok = true;
@@ -695,6 +712,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
       // voices from the whole bank into full waves) and sits out this launch here with its pan gains at zero -- exact
       // zeros into the mix, nothing stored.  (Notes start and end all the time in a live bank: almost every 128-voice slice holds a few such voices,
       // and a slice handed over whole makes the envelope kernel render the ~90 % of its lanes that are merely held.)
+      if (FMP) moving[0] = moving[1] = moving[0] || moving[1];   // carrier and modulator stay together
       m0 = __ballot(moving[0]); m1 = __ballot(moving[1]);
       const int n_moving = __popcll(m0) + __popcll(m1);
       if (lane == 0) {
@@ -745,7 +763,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
 #ifndef SK_ENV2_MIN_WAVES
 #define SK_ENV2_MIN_WAVES 3      /* the envelope machinery wants ~170 VGPRs: 3 waves per SIMD measured best (2: no spills, 4: 220 B of scratch) */
 #endif
-template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED>
+template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED, bool FMP = false>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
   constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
   SK_FAST2_PROLOGUE_((int)blockIdx.x - a.wg_shift < (a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows) &&
@@ -769,11 +787,11 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
     if (mine) {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const int p = p0 + c * 64 + lane;
+        const int p = FMP ? p0 + 2 * lane + c : p0 + c * 64 + lane;   // (FMP: the list holds whole pairs, even voice first)
         absent[c] = p >= n_mine;
         vidx[c] = absent[c] ? 0 : a.env_list[p];
       }
-      tame = fast2_load<FILTER, true, MIXED>(a, vidx, absent, lane, r, e, dead, silent, released, t_start, t_release, tame_m);
+      tame = fast2_load<FILTER, true, MIXED, FMP>(a, vidx, absent, lane, r, e, dead, silent, released, t_start, t_release, tame_m);
       loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     }
     (void)loz; (void)tame; (void)tame_m;
@@ -841,9 +859,9 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
             for (int q = 0; q < 8; q += 2) {
               float l0, r0, l1, r1;
               e.tf[0] += 1.0f; e.trf[0] += 1.0f; e.tf[1] += 1.0f; e.trf[1] += 1.0f;
-              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP, MIXED>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);
+              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP, MIXED, FMP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);
               e.tf[0] += 1.0f; e.trf[0] += 1.0f; e.tf[1] += 1.0f; e.trf[1] += 1.0f;
-              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP, MIXED>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);
+              fast2_frame<TAB_LDS, FILTER, 2, true, INTERP, MIXED, FMP>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);
               { const int J_ = jb + q; SK_REDUCE4_AND_STORE(J_) }
             }
           }
@@ -886,13 +904,22 @@ __global__ __launch_bounds__(256) void sk_scan_moving_kernel(const int32_t *__re
 }
 
 // One wavefront per slice: its handed-over voices (two lane masks) go to list[off[slice] ...] in ascending voice order.
+// pairs: the slice's lanes hold voices (2 lane, 2 lane + 1) and both masks are the same (two-operator FM banks).
 __global__ __launch_bounds__(256) void sk_expand_moving_kernel(const int32_t *__restrict__ counts, const uint64_t *__restrict__ mask,
-                                                                const int32_t *__restrict__ off, int n, int32_t *__restrict__ list) {
+                                                                const int32_t *__restrict__ off, int n, int32_t *__restrict__ list, int pairs) {
   const int lane = threadIdx.x & 63, slice = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
   if (slice >= n || counts[slice] == 0) return;
   const uint64_t m0 = mask[2 * slice], m1 = mask[2 * slice + 1];
   const uint64_t below = ((uint64_t)1 << lane) - 1;
   const int o = off[slice];
+  if (pairs) {
+    if ((m0 >> lane) & 1) {
+      const int at = o + 2 * __popcll(m0 & below);
+      list[at] = slice * 128 + 2 * lane;
+      list[at + 1] = slice * 128 + 2 * lane + 1;
+    }
+    return;
+  }
   if ((m0 >> lane) & 1) list[o + __popcll(m0 & below)] = slice * 128 + lane;
   if ((m1 >> lane) & 1) list[o + __popcll(m0) + __popcll(m1 & below)] = slice * 128 + 64 + lane;
 }
@@ -927,27 +954,27 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
   if (env_follows) { first.finish = 0; first.wg_shift = 0; }
   dim3 grid_first((unsigned)(n_workgroups + first.wg_shift));
   const bool mixed = (args->fast_mode & SKM_MIXED) != 0;     // filter / envelope on some voices only: per-lane flags
+  const bool fmp = (args->fast_mode & SKM_FM_PAIR) != 0 && tab_lds;
   const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
 #define SK_FAST2_COLLECT()                                                                              \
   hipLaunchKernelGGL(sk_scan_moving_kernel, dim3(1), dim3(256), 0, stream, args->group_flag, args->n_groups * 2, args->env_off); \
   hipLaunchKernelGGL(sk_expand_moving_kernel, dim3((unsigned)((args->n_groups * 2 + 3) / 4)), dim3(256), 0, stream,          \
-                     args->group_flag, args->move_mask, args->env_off, args->n_groups * 2, args->env_list);
+                     args->group_flag, args->move_mask, args->env_off, args->n_groups * 2, args->env_list, fmp ? 1 : 0);
+#define SK_FAST2_LAUNCH(T, F, E, I, M, P)                                                               \
+  {                                                                                                     \
+    hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, M, P>), grid_first, block, lds_fast2, stream, first); \
+    if (E && !args->skip_env2) {                                                                        \
+      SK_FAST2_COLLECT()                                                                                \
+      hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, M, P>), grid, block_env, lds_env2, stream, second); \
+    }                                                                                                   \
+  }
+/* (two-operator FM banks: LDS-table banks only -- T is a constant there, which keeps the instantiations at 24 more) */
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
-    if (mixed) {                                                                                        \
-      hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, true>), grid_first, block, lds_fast2, stream, first);  \
-      if (E && !args->skip_env2) {                                                                      \
-        SK_FAST2_COLLECT()                                                                              \
-        hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, true>), grid, block_env, lds_env2, stream, second); \
-      }                                                                                                 \
-    } else {                                                                                            \
-      hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, false>), grid_first, block, lds_fast2, stream, first); \
-      if (E && !args->skip_env2) {                                                                      \
-        SK_FAST2_COLLECT()                                                                              \
-        hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, false>), grid, block_env, lds_env2, stream, second); \
-      }                                                                                                 \
-    }                                                                                                   \
+    if (fmp && T) { if (mixed) SK_FAST2_LAUNCH(true, F, E, I, true, true) else SK_FAST2_LAUNCH(true, F, E, I, false, true) } \
+    else if (mixed) SK_FAST2_LAUNCH(T, F, E, I, true, false)                                            \
+    else SK_FAST2_LAUNCH(T, F, E, I, false, false)                                                      \
     break;
   switch (key) {
     SK_FAST2_CASE(0, false, false, false, 0) SK_FAST2_CASE(1, false, false, false, 1)
@@ -960,6 +987,7 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
     SK_FAST2_CASE(14, true, true, true, 0)   SK_FAST2_CASE(15, true, true, true, 1)
   }
 #undef SK_FAST2_CASE
+#undef SK_FAST2_LAUNCH
 #undef SK_FAST2_COLLECT
   return (int)hipGetLastError();
 }

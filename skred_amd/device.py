@@ -255,6 +255,10 @@ class DeviceBank:
         """Bank size from which the two-voices-per-lane kernel is chosen (0 = always when eligible)."""
         _check(self.L.skred_bank_set_option(self.h, 2, int(n)), "skred_bank_set_option")
 
+    def fm2_min_voices(self, n: int):
+        """Bank size from which a two-operator FM bank keeps carrier and modulator in one lane (SKRED_OPT_FM2_MIN_VOICES)."""
+        _check(self.L.skred_bank_set_option(self.h, 5, int(n)), "skred_bank_set_option")
+
     def last_kernel(self) -> int:
         """0 = generic kernel, 1 = specialised fast kernel (SKRED_KERNEL_*)."""
         return int(self.L.skred_bank_last_kernel(self.h))

@@ -304,7 +304,7 @@ def test_empty_and_bad_arguments(dev):
 
 # ---------------------------------------------------------------- the specialised ("fast") kernel
 
-def _run_scenario(dev, bank, tables, g, interp, segments, force_generic, fast2=False):
+def _run_scenario(dev, bank, tables, g, interp, segments, force_generic, fast2=False, fm2=None):
     """Render `segments` = [(frames, event)] where event(bank_host, now) mutates the host bank
     between launches (host arrays are the source of truth: download -> edit -> upload)."""
     db = dev.DeviceBank(bank.n)
@@ -315,6 +315,8 @@ def _run_scenario(dev, bank, tables, g, interp, segments, force_generic, fast2=F
     db.force_generic(force_generic)
     if fast2:
         db.fast2_min_voices(0)
+    if fm2 is not None:
+        db.fm2_min_voices(fm2)
     mixes, kernels = [], []
     for frames, event in segments:
         if event is not None:
@@ -450,6 +452,44 @@ def test_stopping_one_shots_on_the_specialised_kernel(dev, recipe, interp):
     assert not gen_state.rw_equal(ref_state), gen_state.rw_equal(ref_state)
     assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
     assert rel_rms(mix, ref_mix) <= 1e-5
+
+
+@pytest.mark.parametrize("recipe,interp,mixed", [("c1", 0, False), ("c2", 0, False), ("c2", 1, False), ("c2", 0, True)])
+def test_two_operator_fm_pairs_share_a_lane(dev, recipe, interp, mixed):
+    """A two-operator FM bank (`v0 ... F1,depth` / `v1 ... m1` repeated: every carrier an even voice modulated by the voice
+    after it) on the two-voices-per-lane kernel with carrier and modulator in ONE lane (SKM_FM_PAIR): against the oracle and
+    against the one-per-lane kernel's exchange.  Deep modulation (negative and longer-than-a-loop increments), unmodulated
+    pairs in between, muted and unmuted modulators, carriers and modulators switched off between launches, note-offs, and
+    -- c2 -- envelopes in motion from the first frame (the pair is handed to the envelope kernel as a pair)."""
+    n = 6144 + 250
+    bank, tables, g = banks.RECIPES[recipe](n)
+    car = np.arange(0, n - 1, 2)
+    car = car[(car // 2) % 5 != 4]                      # every fifth pair stays unmodulated
+    mod = car + 1
+    bank["voice_freq_mod_osc"][car] = mod
+    bank["voice_freq_mod_depth"][car] = (np.float32(0.05) * (1 + (car % 97))).astype(np.float32)     # up to ~5: wild
+    bank["voice_freq_scale"][car] = (np.float32(0.5) + np.float32(0.01) * (car % 50)).astype(np.float32)
+    bank["voice_disconnect"][mod[::2]] = 1                                                          # `m1` on half of them
+    if mixed:                                           # filter / envelope on some voices only: per-lane flags
+        bank["voice_filter_mode"][mod[::3]] = 0
+        bank["voice_use_amp_envelope"][car[::4]] = 0
+
+    def kill_some(host, now):
+        host["voice_amp"][mod[::7]] = 0.0
+        host["voice_amp"][car[3::11]] = 0.0
+
+    segs = [(300, None), (257, _release_odd_voices), (512, kill_some), (700, None), (64, None)]
+    mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False, fm2=0)
+    omix, ostate, ko = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False, fm2=1 << 30)
+    ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
+    assert k == [3] * len(segs) and ko == [1] * len(segs), (k, ko)
+    assert not ostate.rw_equal(ref_state), ostate.rw_equal(ref_state)
+    assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
+    assert rel_rms(mix, ref_mix) <= 1e-5 and rel_rms(omix, ref_mix) <= 1e-5
+    # a bank in which ONE carrier looks further up is not of that shape: the one-per-lane kernel keeps it
+    bank["voice_freq_mod_osc"][car[0]] = car[0] + 2
+    _, _, k2 = _run_scenario(dev, bank, tables, g, interp, segs[:1], force_generic=False, fm2=0)
+    assert k2 == [1]
 
 
 @pytest.mark.parametrize("recipe,interp", [("c2", 0), ("c4", 1)])

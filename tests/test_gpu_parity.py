@@ -1014,6 +1014,34 @@ def test_two_per_lane_kernel_full_size_c3(dev):
     assert rel_rms(mix, ref_mix) <= 1e-5
 
 
+def test_two_operator_fm_full_size(dev):
+    """A 2^20-voice two-operator FM bank of C2 voices (the bank tools/measure_banks.py times) on the kernel that keeps
+    carrier and modulator in one lane, from the recipe's first frame (envelopes in motion: pairs are handed to the envelope
+    kernel as pairs), two launches of 64 frames (the modulator's last sample crosses the launch boundary in voice_sample)."""
+    n = 1 << 20
+    bank, tables, g = banks.bank_c2(n)
+    car = np.arange(0, n, 2)
+    bank["voice_freq_mod_osc"][car] = car + 1
+    bank["voice_freq_mod_depth"][car] = 0.2
+    bank["voice_disconnect"][car[::2] + 1] = 1
+    ref_bank, ref_g = bank.copy(), g.copy()
+    refs = []
+    for _ in range(2):
+        r = cpuref.render(ref_bank, ref_g, tables, 64, 0)
+        refs.append(cpuref.master(ref_g, r["sum64"].astype(np.float32)))
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    mixes = [db.render_host(64)[0] for _ in range(2)]
+    assert db.last_kernel() == 3
+    got = bank.copy()
+    db.download(got)
+    db.close()
+    assert not got.rw_equal(ref_bank), got.rw_equal(ref_bank)
+    assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_feature_mix_vs_oracle(dev, seed):
     """Fuzz: banks whose voices switch features on and off at random (tables, one-shot / loop / reverse,

@@ -644,8 +644,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
       fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, s1_, xx, yy, l1, r1, xf);                        \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); SK_FAST_REPACK() } \
-      { const int J_ = (J) + q_; (void)J_; SK_REDUCE4_AND_STORE(J_) }                                    \
+      xt[q_ * SK_XT + lane] = fold_lr(l0, r0);     /* (global-table banks: the tile has its own LDS behind the windows) */ \
+      xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                     \
     }                                                                                                    \
+    SK_FAST_TILE_REDUCE(J)                                                                               \
   }
 // after an EVEN frame the newest delay-line entries sit in x2 / y2 (roles swapped), after an ODD one in x1 / y1
 #define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2, true)
@@ -683,8 +685,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
   const int lane = tid & 63;
   const int wave = tid >> 6;
   float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (SK_WIN * 64);   // global-table banks: table windows
-  float *xt = win;                                     // LDS-table banks: the same per-wave region holds the reduction
-  (void)win; (void)xt;                                 // tile of SK_FAST_LDS_BLOCK (8 * SK_XT floats <= SK_WIN * 64)
+  // the reduction tile of the 8-frame blocks (8 * SK_XT floats): LDS-table banks keep it in the same per-wave region
+  // (no windows there), global-table banks behind the four windows
+  float *xt = TAB_LDS ? win : reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + 4 * (SK_WIN * 64) + wave * (8 * SK_XT);
+  (void)win; (void)xt;
   const int bid = (int)blockIdx.x - a.wg_shift;        // row of the partial mix; -1: the gain workgroup (sk_finish_block)
   if (bid < 0) { sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds)); return; }
 
@@ -961,6 +965,7 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
                                      hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
   lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);   // per wave: one table window, or the reduction tiles of SK_FAST_LDS_BLOCK
+  if (args->lds_table_floats == 0) lds_bytes += (size_t)4 * (8 * SK_XT) * sizeof(float);   // global-table banks: window AND tile
   dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block(SK_GROUP);
   const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);

@@ -445,6 +445,28 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
     }                                                                                                    \
     SK_WAVE_SYNC()                                                                                       \
   }
+// The same eight frames for a wave that is not tame (frequency-modulated carriers of an FMP bank, loops out of range ...):
+// general frames, no gather ahead (a carrier's increment needs the modulator's sample of the frame before), same tile.
+#define SK_FAST2_LDS_BLOCK_U(J, EM_)                                                                     \
+  {                                                                                                      \
+    float *const xt_ = reinterpret_cast<float *>(xp);                                                    \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      float l0, r0, l1, r1;                                                                              \
+      fast2_frame<TAB_LDS, FILTER, EM_, false, INTERP, MIXED, FMP>(r, e, r.x1, r.x2, r.y1, r.y2, SK_F2_ARGS, l0, r0);  \
+      fast2_frame<TAB_LDS, FILTER, EM_, false, INTERP, MIXED, FMP>(r, e, r.x2, r.x1, r.y2, r.y1, SK_F2_ARGS, l1, r1);  \
+      xt_[q_ * SK_XT2 + lane] = fold_lr(l0, r0);                                                         \
+      xt_[(q_ + 1) * SK_XT2 + lane] = fold_lr(l1, r1);                                                   \
+    }                                                                                                    \
+    SK_WAVE_SYNC()                                                                                       \
+    {                                                                                                    \
+      const float4 *src_ = reinterpret_cast<const float4 *>(xt_ + (lane & 7) * SK_XT2 + (lane >> 3) * 8); \
+      const float4 a_ = src_[0], b_ = src_[1];                                                           \
+      float t_ = ((((((a_.x + a_.y) + a_.z) + a_.w) + b_.x) + b_.y) + b_.z) + b_.w;                      \
+      t_ = row_pair_add(row_ror8_add(t_));                                                               \
+      if ((lane & 24) == 0) reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (J) + (lane & 7)])[lane >> 5] = t_; \
+    }                                                                                                    \
+    SK_WAVE_SYNC()                                                                                       \
+  }
 // `loz` (wave-uniform, set once per pass): see fast2_osc
 #define SK_FAST2_LDS_BLOCK(J, EM_)                                                                       \
   { if (loz) SK_FAST2_LDS_BLOCK_Z(J, EM_, true, false) else SK_FAST2_LDS_BLOCK_Z(J, EM_, false, false) }
@@ -477,6 +499,8 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
                 if (j < cn) SK_FAST2_ONE(j, EM_, true) }                        \
     else      { if (tame_m && TAB_LDS) { if ((EM_) == 0 && fast2_smoother_stalled(r)) for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK_M(j, (EM_) == 0 ? 3 : (EM_)) \
                                          else for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK_M(j, EM_) } \
+                else if (FMP && TAB_LDS) { if ((EM_) == 0 && fast2_smoother_stalled(r)) for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK_U(j, (EM_) == 0 ? 3 : (EM_)) \
+                                           else for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK_U(j, EM_) } \
                 for (; j + 1 < cn; j += 2) SK_FAST2_PAIR(j, EM_, false)         \
                 if (j < cn) SK_FAST2_ONE(j, EM_, false) }                       \
   }

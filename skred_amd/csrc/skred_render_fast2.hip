@@ -123,10 +123,11 @@ __device__ __forceinline__ void fast2_env_span(Fast2Regs &r, Env2Regs &e, int c,
 // sustain or release, release -> finished): the ramp constants of the stage after the change go to the second set and
 // `bnd` is the value of the first set's clock from which they apply -- the comparison the reference makes on that frame
 // (synth.c:403,408,420: `t < attack_time`, `t < decay_start + decay_time`, `t_release < release_time`).  A lane that keeps
-// its stage gets bnd = +inf.  `ok` stays true while no lane does anything else (two changes inside the span: attack or
+// its stage gets bnd = +inf.  r.rw is not touched (see `runs_out`).  `ok` stays true while no lane does anything else (two changes inside the span: attack or
 // decay shorter than the span, or a release that has already run out when the decay ends).
 __device__ __forceinline__ void fast2_env_span2(Fast2Regs &r, Env2Regs &e, int c, bool dead, bool released,
-                                                float t1, float tr1, float tN, float trN, float t0, float tr0, bool &ok) {
+                                                float t1, float tr1, float tN, float trN, float t0, float tr0, bool &ok,
+                                                bool &runs_out) {
   const bool act = (r.rw[c] & SKR_ENV_ACTIVE) != 0;
   const int code0 = env_stage_code(act, released, t1, tr1, e.att[c], e.attdec[c], e.rel[c]);
   const int code1 = env_stage_code(act, released, tN, trN, e.att[c], e.attdec[c], e.rel[c]);
@@ -151,9 +152,9 @@ __device__ __forceinline__ void fast2_env_span2(Fast2Regs &r, Env2Regs &e, int c
   }
   e.bnd[c] = !step ? __builtin_huge_valf() : (code0 == 1 ? e.att[c] : (code0 == 2 ? e.attdec[c] : e.rel[c]));
   ok = ok && (dead || ((!step || next_stage) && den[0] >= 0x1p-40f && den[0] <= 0x1p40f && den[1] >= 0x1p-40f && den[1] <= 0x1p40f));
-  // a release that runs out: the reference clears is_active on the first frame it notices (synth.c:429); nothing in this
-  // span reads the flag again
-  if (!dead && (code0 == 5 || code1 == 5)) r.rw[c] &= ~SKR_ENV_ACTIVE;
+  // a release that runs out in this span: the reference clears is_active on the first frame it notices (synth.c:429).  The
+  // caller clears it once it has decided to render the span in this form (the general frames read the flag themselves).
+  runs_out = !dead && (code0 == 5 || code1 == 5);
 }
 
 // General frames (a lane changes stage inside the block): amp_envelope_step as the reference writes it.
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
       if (!mine) {
         if (lane < cn) wsum[wave * SK_CHUNK + lane] = make_float2(0.0f, 0.0f);
       } else {
-      bool steady = true, exact = true, ramp = false;
+      bool steady = true, exact = true, ramp = false, step = false;
       float cb_tf[2] = {0.0f, 0.0f}, cb_trf[2] = {0.0f, 0.0f};     // clocks of the frame BEFORE the chunk
       if (!all_const_from_here) {
         const uint64_t base = a.count0 + (uint64_t)c0;              // frame c0+j has now = base + j + 1 (synth.c:521)
@@ -844,11 +845,28 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
         steady = __all(st);
         ramp = !steady && exact && __all(same);
         all_const_from_here = steady;       // constant levels are absorbing within a launch
+        if (!steady && !ramp && exact) {
+          // lanes change stage in this chunk.  Once each, to the stage that follows?  Then the whole chunk keeps the
+          // straight-line form with two constant sets per lane (fast2_env_span2) -- with every lane of the wave in motion
+          // (the hand-over is voice by voice) nearly every chunk is of this kind, and deciding per 8-frame block costs
+          // as much as the frames.
+          bool ok2 = true, out[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const uint64_t d_on = base - t_start[c], d_off = base - t_release[c];
+            fast2_env_span2(r, e, c, dead[c], released[c], (float)(d_on + 1), (float)(d_off + 1),
+                            (float)(d_on + (uint64_t)cn), (float)(d_off + (uint64_t)cn), cb_tf[c], cb_trf[c], ok2, out[c]);
+          }
+          step = __all(ok2);
+          if (step) { if (out[0]) r.rw[0] &= ~SKR_ENV_ACTIVE; if (out[1]) r.rw[1] &= ~SKR_ENV_ACTIVE; }
+        }
       }
       if (steady) {
         SK_FAST2_CHUNK(0)
       } else if (ramp) {
         SK_FAST2_CHUNK(1)
+      } else if (step) {
+        SK_FAST2_CHUNK(4)
       } else if (exact && tame && !(cn & 7)) {
         // some lane changes stage inside this chunk: re-decide per 8-frame block (clocks are exact floats here)
         for (int jb = 0; jb < cn; jb += 8) {
@@ -861,12 +879,13 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
           const bool b_const = __all(st), b_ramp = __all(same);
           bool b_step = false;
           if (!b_const && !b_ramp) {                  // some lane changes stage in this block: once, to the next stage?
-            bool ok2 = true;
+            bool ok2 = true, out[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
               fast2_env_span2(r, e, c, dead[c], released[c], cb_tf[c] + fb + 1.0f, cb_trf[c] + fb + 1.0f,
-                              cb_tf[c] + fb + 8.0f, cb_trf[c] + fb + 8.0f, cb_tf[c] + fb, cb_trf[c] + fb, ok2);
+                              cb_tf[c] + fb + 8.0f, cb_trf[c] + fb + 8.0f, cb_tf[c] + fb, cb_trf[c] + fb, ok2, out[c]);
             b_step = __all(ok2);
+            if (b_step) { if (out[0]) r.rw[0] &= ~SKR_ENV_ACTIVE; if (out[1]) r.rw[1] &= ~SKR_ENV_ACTIVE; }
           }
 #if SK_LDS_REDUCE
           if (TAB_LDS && b_const) SK_FAST2_LDS_BLOCK(jb, 0)

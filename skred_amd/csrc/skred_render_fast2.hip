@@ -929,22 +929,49 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
 // ---------------------------------------------------------------- launcher (C linkage)
 
 // counts[n] (voices handed over per 128-voice slice) -> off[n] exclusive prefix sums, off[n] = their total.  One
-// workgroup: every thread sums its contiguous share, an LDS scan places the shares, every thread writes its own.
+// workgroup, tiles of 8192 counts staged through LDS (coalesced loads in flight together -- a thread walking its
+// contiguous share in global memory pays one memory latency per element): every thread sums its 32 contiguous counts, the
+// 256 sums are scanned across lanes (shuffles inside each wavefront, four wave totals through LDS), every thread writes its
+// prefixes back into the tile, and the tile leaves coalesced.
+#define SK_SCAN_TILE 8192
 __global__ __launch_bounds__(256) void sk_scan_moving_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restrict__ off) {
-  __shared__ int base[257];
-  const int t = threadIdx.x;
-  const int per = (n + 255) / 256, lo = min(t * per, n), hi = min(lo + per, n);
-  int c = 0;
-  for (int i = lo; i < hi; ++i) c += counts[i];
-  base[t + 1] = c;
-  if (t == 0) base[0] = 0;
-  __syncthreads();
-  if (t == 0) for (int i = 1; i <= 256; ++i) base[i] += base[i - 1];
-  __syncthreads();
-  int w = base[t];
-  for (int i = lo; i < hi; ++i) { off[i] = w; w += counts[i]; }
-  if (t == 255) off[n] = base[256];
+  __shared__ int tile[SK_SCAN_TILE + SK_SCAN_TILE / 32];   // element k lives at k + k/32: a thread's 32 counts stay contiguous, the
+                                                           // threads' shares start in different banks
+#define SK_SCAN_AT(k) ((k) + ((k) >> 5))
+  __shared__ int wave_total[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int carry = 0;
+  for (int t0 = 0; t0 < n; t0 += SK_SCAN_TILE) {
+    const int m = min(SK_SCAN_TILE, n - t0);
+#pragma unroll 8
+    for (int k = t; k < SK_SCAN_TILE; k += 256) tile[SK_SCAN_AT(k)] = k < m ? counts[t0 + k] : 0;
+    __syncthreads();
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < SK_SCAN_TILE / 256; ++i) c += tile[SK_SCAN_AT(t * (SK_SCAN_TILE / 256) + i)];
+    int incl = c;                                      // inclusive scan of the shares inside the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    int base = carry;
+    for (int w = 0; w < wave; ++w) base += wave_total[w];
+    const int total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    int w = base + incl - c;                           // exclusive prefix of this thread's share
+#pragma unroll
+    for (int i = 0; i < SK_SCAN_TILE / 256; ++i) { int &e_ = tile[SK_SCAN_AT(t * (SK_SCAN_TILE / 256) + i)]; const int v = e_; e_ = w; w += v; }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = t; k < m; k += 256) off[t0 + k] = tile[SK_SCAN_AT(k)];
+    carry += total;
+    __syncthreads();
+  }
+  if (t == 0) off[n] = carry;
 }
+#undef SK_SCAN_AT
 
 // One wavefront per slice: its handed-over voices (two lane masks) go to list[off[slice] ...] in ascending voice order.
 // pairs: the slice's lanes hold voices (2 lane, 2 lane + 1) and both masks are the same (two-operator FM banks).

@@ -1,7 +1,7 @@
 """PCM banks (table windows): the C4 recipe and its extended variants at the bench size, wall clock per 512-frame block."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from skred_amd import banks, device
 def run(name, edit=None, n=262144, interp=1, F=512, steps=100):
     b, t, g = banks.RECIPES["c4"](n)

@@ -1,7 +1,7 @@
 """One voice per lane against two voices per lane at mid sizes (where the crossover SK_FAST2_MIN_VOICES sits)."""
 import sys, time, os
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from skred_amd import banks, device
 def run(rec, n, min2, F=512, steps=100):
     b, t, g = banks.RECIPES[rec](n)

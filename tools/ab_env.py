@@ -2,7 +2,7 @@
 in flight) and the bank under note traffic.  Wall clock per 512-frame block; SKRED_AMD_LIB selects the library build."""
 import sys, time, os
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from skred_amd import banks, device
 D = device
 n, F = 1 << 20, 512

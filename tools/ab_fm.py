@@ -2,7 +2,7 @@
 kernel's exchange, by bank size."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from skred_amd import banks, device
 def run(rec, n, fm2, F=512, steps=60):
     b, t, g = banks.RECIPES[rec](n)

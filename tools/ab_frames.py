@@ -2,7 +2,7 @@
 launches back to back).  SKRED_AMD_LIB selects the library build."""
 import sys, time, os
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from skred_amd import banks, device
 def run(name, rec, n, F, min2=None, steps=200):
     b, t, g = banks.RECIPES[rec](n)

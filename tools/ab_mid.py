@@ -1,6 +1,6 @@
 import sys, time, os
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from skred_amd import banks, device
 def run(name, rec, n, interp=0, F=512, steps=100, min2=None):
     b, t, g = banks.RECIPES[rec](n)

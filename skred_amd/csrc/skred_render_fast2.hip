@@ -689,6 +689,9 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
 // 16 waves, 4 per SIMD -- share a CU's LDS with ONE copy of the tables each (four per SIMD needs <= 40 KB per
 // 256-thread workgroup otherwise, and tables + tiles take ~46 KB); global-table banks keep 4 (their table windows
 // scale with the wave count).
+#ifndef SK_FAST2_MAX_SETTLING
+#define SK_FAST2_MAX_SETTLING 16   /* voices per 128-voice slice whose smoother alone still moves: up to this many are handed over */
+#endif
 /* store what this kernel rendered: not the voices handed over (lane masks m0 / m1) */
 #define SK_FAST2_STORE_MINE()                                                                        \
   {                                                                                                  \
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     bool wave_ok = true;
     if (ENV) {
       // constant envelope level on the first frame of the launch <=> for the whole launch (absorbing codes)
-      bool moving[2];
+      bool moving[2], settling[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const uint64_t d_on = a.count0 + 1 - t_start[c], d_off = a.count0 + 1 - t_release[c];
@@ -732,6 +735,15 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
         const float level = code == 3 ? e.susv[c] : 0.0f;
         r.gain_const[c] = e.ampv[c] * (level * e.velv[c]);                       // synth.c:582,588
         if (!dead[c] && code == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;                   // synth.c:429
+        const float nxt = r.sgain[c] + r.k[c] * (r.gain_const[c] - r.sgain[c]);
+        settling[c] = !dead[c] && !moving[c] && __float_as_uint(nxt) != __float_as_uint(r.sgain[c]);
+      }
+      // a voice that has just reached its constant level still moves its amp smoother for a few hundred frames, and ONE
+      // such lane keeps its whole wave off the stalled-smoother blocks: a few of them go with the moving voices until they
+      // rest (many of them -- a bank right after its upload -- stay: the wave then runs its smoothers for all lanes anyway)
+      if (__popcll(__ballot(settling[0])) + __popcll(__ballot(settling[1])) <= SK_FAST2_MAX_SETTLING) {
+        moving[0] = moving[0] || settling[0];
+        moving[1] = moving[1] || settling[1];
       }
       // hand-over per VOICE: a voice with its envelope in motion is left to sk_render_env2_kernel (which collects such
       // voices from the whole bank into full waves) and sits out this launch here with its pan gains at zero -- exact
@@ -757,8 +769,9 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
       }
       if (!__syncthreads_or(wave_ok ? 1 : 0)) {       // nothing of this pass is rendered here
 #pragma unroll
-        for (int c = 0; c < 2; ++c)                   // (really dead voices still get voice_sample = 0, synth.c:532,538)
-          if (dead[c]) reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][vidx[c]])[2] = 0u;
+        for (int c = 0; c < 2; ++c)                   // (really dead voices still get voice_sample = 0, synth.c:532,538 --
+          if (dead[c] && !(((c ? m1 : m0) >> lane) & 1))   //  unless they travel with a handed-over pair: its carrier reads it)
+            reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][vidx[c]])[2] = 0u;
         continue;
       }
     }
@@ -792,14 +805,15 @@ template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED, bool FMP = false>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
   constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
   SK_FAST2_PROLOGUE_((int)blockIdx.x - a.wg_shift < (a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows) &&
-                     ((int)blockIdx.x - a.wg_shift) * (NW * 128) < a.env_off[a.n_groups * 2])
+                     (int)blockIdx.x - a.wg_shift < (a.env_off[a.n_groups * 2] + NW * 128 - 1) / (NW * 128))
   (void)n_pass; (void)n_groups2;
   // the voices sk_render_fast2_kernel left to this kernel, in ascending order (sk_scan_moving_kernel +
   // sk_expand_moving_kernel): every workgroup pass takes 512 of them, so the launch costs what those voices cost
   const int n_mine = a.env_off[n_flags];
   constexpr bool publish = false;   // (a workgroup of this kernel may have no pass at all: sk_finish_block copies every row out)
   const int n_workers = a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows;
-  for (int g = bid < n_workers ? bid : n_mine; g * (NW * 128) < n_mine; g += n_workers) {
+  const int n_env_pass = (n_mine + NW * 128 - 1) / (NW * 128);
+  for (int g = bid < n_workers ? bid : n_env_pass; g < n_env_pass; g += n_workers) {
     const int p0 = g * (NW * 128) + wave * 128;          // this wave's first list entry
     const bool mine = p0 < n_mine;
     Fast2Regs r;

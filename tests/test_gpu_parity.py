@@ -478,7 +478,14 @@ def test_two_operator_fm_pairs_share_a_lane(dev, recipe, interp, mixed):
         host["voice_amp"][mod[::7]] = 0.0
         host["voice_amp"][car[3::11]] = 0.0
 
-    segs = [(300, None), (257, _release_odd_voices), (512, kill_some), (700, None), (64, None)]
+    def retrigger_all_and_kill_more(host, now):
+        # every envelope in motion again: whole passes of the steady kernel have nothing left to render, and the modulators
+        # switched off HERE still owe their last sample to their carriers' first frame (voice_sample is an input of the pair)
+        e = host["voice_amp_envelope"]
+        e["sample_start"][:] = now; e["sample_release"][:] = 0; e["is_active"][:] = 1
+        host["voice_amp"][mod[2::7]] = 0.0
+
+    segs = [(300, None), (257, _release_odd_voices), (512, kill_some), (700, None), (192, retrigger_all_and_kill_more), (64, None)]
     mix, state, k = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False, fm2=0)
     omix, ostate, ko = _run_scenario(dev, bank, tables, g, interp, segs, force_generic=False, fm2=1 << 30)
     ref_mix, ref_state = _oracle_scenario(bank, tables, g, interp, segs)
@@ -1165,10 +1172,16 @@ def test_non_finite_phase_increments(dev):
     assert ((ph_g.view(np.uint32) == ph_r.view(np.uint32)) | (np.isnan(ph_g) & np.isnan(ph_r))).all()
 
 
-def test_four_million_voices(dev):
-    """Maximum-size edge: 2^22 voices (0.8 GB of device state), 16 frames, against the oracle."""
+@pytest.mark.parametrize("all_in_attack", [False, True])
+def test_four_million_voices(dev, all_in_attack):
+    """Maximum-size edge: 2^22 voices (0.8 GB of device state), 16 frames, against the oracle; as the recipe has them, and
+    with every note starting on the block's first frame (every voice is handed to the envelope kernel: 2^22 list entries,
+    8192 passes)."""
     n, frames = 1 << 22, 16
     bank, tables, g = banks.bank_c2(n)
+    if all_in_attack:
+        e = bank["voice_amp_envelope"]
+        e["sample_start"][:] = g.synth_sample_count; e["sample_release"][:] = 0; e["is_active"][:] = 1
     ref_bank, ref_g = bank.copy(), g.copy()
     r = cpuref.render(ref_bank, ref_g, tables, frames, 0)     # parity build (-ffp-contract=off), not the timing build
     ref_mix = cpuref.master(ref_g, r["sum64"].astype(np.float32))

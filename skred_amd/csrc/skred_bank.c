@@ -346,6 +346,7 @@ static void poll_env_quiet(skred_bank_t *b) {
      * the answer only holds if no control action reached the bank since that launch was issued */
     const int deferred = b->h_quiet[i] == b->quiet_ticket[i];
     if (!deferred && b->quiet_epoch[i] == b->control_epoch) b->env_quiet = 1;
+    if (deferred) b->env_quiet = 0;
     if (deferred && b->quiet_skipped[i]) {
       /* self-check: a launch that ran WITHOUT sk_render_env2_kernel had a slice with an envelope in motion -- the
        * premise of the latch ("stages only move towards a constant level between control actions") was violated.
@@ -446,10 +447,16 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
    * sk_render_env2_kernel.  Envelope stages only move towards a constant level on their own, so once a launch
    * has deferred no group, none will be deferred until a control action arrives: the second launch is skipped. */
   const int two_env = !modulated && (a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
-  if (two_env) poll_env_quiet(b);
+  /* one-per-lane banks with envelopes (plain instantiation): the same report picks between the instantiation that also holds
+   * the block form of envelopes in motion and the lean one (skred_render_fast.hip: RAMPK); both render everything, so a stale
+   * answer costs speed, never samples */
+  const int one_env = !modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_TWO_PER_LANE | SKM_STOPS | SKM_FM | SKM_MIXED)) &&
+                      (a.fast_mode & SKM_ENV_ALL);
+  const int env_latch = two_env || one_env;
+  if (env_latch) poll_env_quiet(b);
   a.launch_ticket = ++b->launch_ticket;
   /* a voice whose note-on / note-off clock lies ahead of the bank's (cnt_future) can leave a constant level on its own */
-  a.skip_env2 = two_env && b->env_quiet && b->cnt_future == 0;
+  a.skip_env2 = env_latch && b->env_quiet && b->cnt_future == 0;
   const int timed = b->timing_every > 0 && (b->launch_ticket % (uint32_t)b->timing_every) == 0;
   if (timed) HIP_TRY(hipEventRecord(b->ev0[tslot], s));
   hipError_t e;
@@ -464,7 +471,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     HIP_TRY(hipEventRecord(b->ev1[tslot], s));
     b->n_timed++;
   }
-  if (two_env && (!a.skip_env2 || (a.launch_ticket & 63u) == 0) && b->quiet_pending < SK_QUIET_RING) {
+  if (env_latch && (!a.skip_env2 || (a.launch_ticket & 63u) == 0) && b->quiet_pending < SK_QUIET_RING) {
     /* ask (asynchronously) whether this launch deferred any group; while the latch holds, every 64th launch is
      * still asked, as a self-check of the latch's premise (poll_env_quiet) */
     const int i = b->quiet_head % SK_QUIET_RING;
@@ -474,7 +481,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     HIP_TRY(hipEventRecord(b->quiet_ev[i], s));
     b->quiet_ticket[i] = a.launch_ticket;
     b->quiet_epoch[i] = b->control_epoch;
-    b->quiet_skipped[i] = (uint8_t)a.skip_env2;
+    b->quiet_skipped[i] = (uint8_t)(two_env && a.skip_env2);   /* (only there is a skipped launch a lost slice) */
     b->quiet_head++;
     b->quiet_pending++;
   }

@@ -223,9 +223,80 @@ __device__ __forceinline__ float fast_holdq(FastRegs &r, float s) {
   return s;
 }
 
-template <bool FILTER, bool ENV, bool STALL, bool EXT, bool NEWEST_X, bool PAN = true>
+// Envelopes in motion on the block paths (round 2; the two-per-lane envelope kernel's form, skred_render_fast2.hip:
+// fast2_env_span2, one voice per lane).  Over a span of frames in which a lane keeps its stage or changes it ONCE, to the
+// stage that follows, the level is e = C * (A + B * q), q = (clk - base) / den, bit-identical to the reference's stage
+// expressions (synth.c:405,413,425): attack q = 1*(0 + 1*q), decay 1 - q*(1-sus) = 1*(1 + (-(1-sus))*q), release
+// sus*(1 - q) = sus*(1 + (-1)*q), a held or silent stage level*(1 + 0*q).  Two constant sets per lane: the stage on the
+// span's first frame and the one after the change; `bnd` is the value of the first set's clock from which the second
+// applies -- the comparison the reference makes on that frame (`t < attack_time`, `t < decay_start + decay_time`,
+// `t_release < release_time`); +inf when the lane keeps its stage.  q is the correctly rounded quotient: the FMA tail of
+// the IEEE fp32 division expansion with a reciprocal refined once per span (denominators in [2^-40, 2^40], where
+// div_scale / div_fixup would not intervene).
+struct FastEnv {
+  float clk, base, den, rinv, A, B, C;
+  float clk2, base2, den2, rinv2, A2, B2, C2, bnd;
+};
+
+__device__ __forceinline__ int fast_stage_code(bool active, bool released, float t, float tr, float att, float attdec, float rel) {
+  if (!active) return 0;
+  if (t < att) return 1;
+  if (t < attdec) return 2;
+  if (!released) return 3;
+  return (tr < rel) ? 4 : 5;
+}
+
+// (t1,tr1) / (tN,trN): clocks of the span's first / last frame; (t0,tr0): of the frame before it.  `ok` stays true while
+// the lane can be rendered in this form; `runs_out`: its release ends in the span (the caller clears is_active, synth.c:429).
+__device__ __forceinline__ void fast_env_span2(const FastRegs &r, FastEnv &e, bool dead, bool released, float t1, float tr1,
+                                               float tN, float trN, float t0, float tr0, bool &ok, bool &runs_out) {
+  const bool act = (r.rw & SKR_ENV_ACTIVE) != 0;
+  const int code0 = fast_stage_code(act, released, t1, tr1, r.att, r.attdec, r.rel);
+  const int code1 = fast_stage_code(act, released, tN, trN, r.att, r.attdec, r.rel);
+  const bool step = code0 != code1;
+  const bool next_stage = (code0 == 1 && code1 == 2) || (code0 == 2 && (code1 == 3 || code1 == 4)) || (code0 == 4 && code1 == 5);
+  float den[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int code = h ? code1 : code0;
+    const float level = code == 3 ? r.sus : 0.0f;
+    const float A = code == 1 ? 0.0f : 1.0f;
+    const float B = code == 1 ? 1.0f : (code == 2 ? -r.one_m_sus : (code == 4 ? -1.0f : 0.0f));
+    const float C = code == 4 ? r.sus : ((code == 1 || code == 2) ? 1.0f : level);
+    const float clk = code == 4 ? tr0 : t0;
+    const float base = code == 2 ? r.att : 0.0f;
+    const float d = code == 1 ? r.att : (code == 2 ? r.dec : (code == 4 ? r.rel : 1.0f));
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float ri = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    den[h] = d;
+    if (h == 0) { e.A = A; e.B = B; e.C = C; e.clk = clk; e.base = base; e.den = d; e.rinv = ri; }
+    else        { e.A2 = A; e.B2 = B; e.C2 = C; e.clk2 = clk; e.base2 = base; e.den2 = d; e.rinv2 = ri; }
+  }
+  e.bnd = !step ? __builtin_huge_valf() : (code0 == 1 ? r.att : (code0 == 2 ? r.attdec : r.rel));
+  ok = ok && (dead || ((!step || next_stage) && den[0] >= 0x1p-40f && den[0] <= 0x1p40f && den[1] >= 0x1p-40f && den[1] <= 0x1p40f));
+  runs_out = !dead && (code0 == 5 || code1 == 5);
+}
+
+// this frame's gain amp * (e * velocity) (synth.c:582,588) from the two constant sets
+__device__ __forceinline__ float fast_env_gain(const FastRegs &r, FastEnv &e) {
+  e.clk += 1.0f;                                       // exact: the clocks stay below 2^24 in this form
+  e.clk2 += 1.0f;
+  const bool after = e.clk >= e.bnd;                   // the reference's `t < limit` failed on this frame
+  const float num = after ? e.clk2 - e.base2 : e.clk - e.base;
+  const float den = after ? e.den2 : e.den, rinv = after ? e.rinv2 : e.rinv;
+  const float A = after ? e.A2 : e.A, B = after ? e.B2 : e.B, C = after ? e.C2 : e.C;
+  float q = num * rinv;
+  float rem = __builtin_fmaf(-den, q, num);
+  q = __builtin_fmaf(rem, rinv, q);
+  rem = __builtin_fmaf(-den, q, num);
+  q = __builtin_fmaf(rem, rinv, q);
+  const float lvl = C * (A + B * q);
+  return r.amp * (lvl * r.vel);
+}
+
+template <bool FILTER, bool ENV, bool STALL, bool EXT, bool NEWEST_X, bool PAN = true, bool RAMP = false>
 __device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float s, v2f &xx, v2f &yy, float &out_l, float &out_r,
-                                            const int xf = 0) {
+                                            const int xf = 0, FastEnv *ev = nullptr) {
   if (EXT && (xf & XF_HOLDQ)) s = fast_holdq(r, s);           // (wave-uniform: some lane of the wave holds or crushes)
   if (FILTER) {
     const v2f t = (NEWEST_X ? k.b12 : k.b21) * xx;
@@ -240,7 +311,7 @@ __device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float 
       s = y;
     }
   }
-  const float gain = ENV ? r.gain_sustain : r.amp;     // (an un-enveloped voice of a mixed bank carries amp in gain_sustain)
+  const float gain = RAMP ? fast_env_gain(r, *ev) : (ENV ? r.gain_sustain : r.amp);   // (an un-enveloped voice of a mixed bank carries amp in gain_sustain)
   if (EXT && (xf & XF_NOSMOOTH)) {                     // some lane runs without the smoother: its gain applies directly,
     if (!STALL) { const float nx = r.sgain + r.k * (gain - r.sgain); r.sgain = r.nosmooth ? r.sgain : nx; }   // voice_smoother_gain rests
     s *= r.nosmooth ? gain : r.sgain;
@@ -481,25 +552,26 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_OSC8(DST)                                                                                \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                       \
     DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));
-#define SK_FAST_POST8(SRC, STALL_)                                                                       \
+#define SK_FAST_POST8_(SRC, STALL_, RAMP_)                                                                      \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
     float f0_, f1_;                                                                                      \
     if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
       float s0_, s1_, u_;                                                                                \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SRC[q_], xx, yy, s0_, u_, xf);         \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf);    \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false, RAMP_>(r, pk, SRC[q_], xx, yy, s0_, u_, xf, &ev_);         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false, RAMP_>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf, &ev_);    \
       fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
     } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
       float l0_, r0_, l1_, r1_;                                                                          \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf);               \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1_, r1_, xf);          \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf, &ev_);               \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SRC[q_ + 1], xx, yy, l1_, r1_, xf, &ev_);          \
       f0_ = fold_lr(l0_, r0_); f1_ = fold_lr(l1_, r1_);                                                  \
     }                                                                                                    \
     xt[q_ * SK_XT + lane] = f0_;                                                                         \
     xt[(q_ + 1) * SK_XT + lane] = f1_;                                                                   \
   }
+#define SK_FAST_POST8(SRC, STALL_) SK_FAST_POST8_(SRC, STALL_, false)
 /* the two strands written frame pair by frame pair, the way they should issue: oscillator of the NEXT block, chains of this one */
-#define SK_FAST_OSC_POST8(DST, SRC, STALL_)                                                              \
+#define SK_FAST_OSC_POST8(DST, SRC, STALL_)                                                               \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
     float f0_, f1_;                                                                                      \
     DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));             \
@@ -632,23 +704,24 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     pend_j = (J);                                                                                        \
   }
 // eight steady frames of a tame wave of a global-table bank through the table window
-#define SK_FAST_WIN_BLOCK(J, STALL_)                                                                     \
+#define SK_FAST_WIN_BLOCK_(J, STALL_, RAMP_)                                                                  \
   {                                                                                                      \
     FastWin w_;                                                                                          \
     fast_win_fill(r, dead, w_, win, lane, glb_tab);                                                      \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, s0_, xx, yy, l0, r0, xf);                         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, s0_, xx, yy, l0, r0, xf, &ev_);                       \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); SK_FAST_REPACK() } \
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, s1_, xx, yy, l1, r1, xf);                        \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, s1_, xx, yy, l1, r1, xf, &ev_);                       \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); SK_FAST_REPACK() } \
       xt[q_ * SK_XT + lane] = fold_lr(l0, r0);     /* (global-table banks: the tile has its own LDS behind the windows) */ \
       xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                     \
     }                                                                                                    \
     SK_FAST_TILE_REDUCE(J)                                                                               \
   }
+#define SK_FAST_WIN_BLOCK(J, STALL_) SK_FAST_WIN_BLOCK_(J, STALL_, false)
 // after an EVEN frame the newest delay-line entries sit in x2 / y2 (roles swapped), after an ODD one in x1 / y1
 #define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2, true)
 #define SK_FAST_ODD(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1, false)
@@ -674,7 +747,11 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // STOPS (the "extended" instantiation): the bank holds forward one-shots that play to their table end and finish
 // (checked frame by frame) and / or carriers frequency-modulated by a higher-indexed voice of their 64-voice group.
 // Such banks run the plain frame loop (no frame pairs); table windows only in waves without carriers.
-template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS>
+// RAMPK: the instantiation that also holds the block form of envelopes in motion (fast_env_span2).  It is a separate
+// instantiation because its registers perturb the allocation of the steady loops (+4..6 % per frame on C1 / C2 / the
+// 2^17-voice shard when both lived in one kernel): the host launches it while envelopes may be moving and the lean one
+// once a launch has reported that none did (the general frames are in both, so the choice only decides speed).
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS, bool RAMPK = false>
 __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES : SK_FAST_MIN_WAVES) : (STOPS ? SK_FAST_WIN_EXT_MIN_WAVES : SK_FAST_WIN_MIN_WAVES)) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
@@ -834,9 +911,15 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     const float half_span = 0.5f * r.span;
     (void)fm_only; (void)half_span;
 
+    bool moved = false;                               // (wave-uniform) some chunk of this pass had an envelope in motion
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
-      bool steady = true, exact = true;
+      FastEnv ev_;                                    // (RAMPK) envelopes in motion on the block paths; per chunk
+      ev_.clk = ev_.base = ev_.A = ev_.B = ev_.C = ev_.clk2 = ev_.base2 = ev_.A2 = ev_.B2 = ev_.C2 = 0.0f;
+      ev_.den = ev_.rinv = ev_.den2 = ev_.rinv2 = 1.0f; ev_.bnd = 0.0f;
+      bool steady = true, exact = true, ramp_ok = false;
+      float ramp_tf = 0.0f, ramp_trf = 0.0f;
+      (void)ramp_tf; (void)ramp_trf; (void)ramp_ok;
       if (ENV) {
         // Envelope clocks for this chunk from the integer timeline: frame c0+j has
         // now = count0 + c0 + j + 1 (synth.c:521).  d_* are the clocks of "frame c0 - 1".
@@ -850,6 +933,16 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         // sustain is absorbing within a launch: the clock only grows and note-off arrives between launches
         const float tf_first = (float)(d_on + 1);
         steady = __all(dead || !r.use_env || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
+        moved = moved || !steady;
+        // envelopes in motion: can the chunk's 8-frame blocks keep the straight-line form (fast_env_span2)?
+        if (RAMPK && !steady && exact && tame && !stems_on && cn >= 8) {
+          const uint64_t n8 = (uint64_t)(cn & ~7);
+          bool ok = true, runs_out = false;
+          fast_env_span2(r, ev_, dead, released, tf_first, (float)(d_off + 1), (float)(d_on + n8), (float)(d_off + n8), r.tf, r.trf, ok, runs_out);
+          ramp_ok = __all(ok);
+          if (ramp_ok && runs_out) r.rw &= ~SKR_ENV_ACTIVE;      // synth.c:429 (the frames after the blocks read the flag themselves)
+          ramp_tf = (float)(d_on + n8); ramp_trf = released ? (float)(d_off + n8) : 0.0f;   // clocks of the blocks' last frame
+        }
       }
       // a stopping voice that cannot reach its table end within this chunk (forward, unmodulated: phase + 64*inc,
       // rounding included, stays below it) needs no per-frame finish test yet
@@ -903,6 +996,31 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         if (stems_on) for (; j + 1 < cn; j += 2) { SK_FAST_EVEN(j, true) SK_FAST_ODD(j + 1, true) }   // frame by frame, stems written
         else { SK_FAST_PACK_IN() for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, false) SK_FAST_PACK_OUT() }
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
+      } else if (RAMPK && ramp_ok) {
+        // envelopes in motion, block paths: the stalled-smoother skip aside, the steady blocks with a gain that is evaluated
+        // per frame (block by block, not the software-pipelined chunk); what is left of the chunk after its last whole block
+        // takes the general frames
+        int j = 0;
+        SK_FAST_PACK_IN()
+        if (TAB_LDS) {
+          for (; j + 8 <= cn; j += 8) {
+            float s_[8];
+            SK_FAST_OSC8(s_)
+            SK_FAST_POST8_(s_, false, true)
+            SK_FAST_TILE_REDUCE(j)
+          }
+        } else {
+          for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK_(j, false, true)
+        }
+        SK_FAST_PACK_OUT()
+        r.tf = ramp_tf; r.trf = ramp_trf;
+        for (; j + 1 < cn; j += 2) {
+          r.tf += 1.0f; r.trf += 1.0f;
+          SK_FAST_EVEN(j, false)
+          r.tf += 1.0f; r.trf += 1.0f;
+          SK_FAST_ODD(j + 1, false)
+        }
+        if (j < cn) { r.tf += 1.0f; r.trf += 1.0f; SK_FAST_EVEN(j, false) SK_FAST_FIX_ODD_TAIL() }
       } else if (exact) {
         int j = 0;
         for (; j + 1 < cn; j += 2) {                 // clocks == (float)(now - sample_start), exact below 2^24
@@ -936,6 +1054,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
 #endif
     }
 
+    // "an envelope moved in this launch": what the host's choice between the two instantiations rests on
+    if (ENV && !STOPS && moved && lane == 0) a.group_flag[a.n_groups * 2] = (int32_t)a.launch_ticket;
     // store the recurrences; skipped voices keep their state and get voice_sample = 0 (synth.c:532,538)
     if (!dead) {
       uint4 s0, s1;
@@ -969,8 +1089,10 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
   dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block(SK_GROUP);
   const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
+  const bool rampk = !args->skip_env2;   /* envelopes may be moving (skip_env2: a launch has reported that none did) */
 #define SK_FAST_CASE(K, T, F, E, I)                                                                                        \
-  case K: hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false>), grid, block, lds_bytes, stream, *args); break;     \
+  case K: if (E && rampk) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false, E>), grid, block, lds_bytes, stream, *args); \
+          else hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false, false>), grid, block, lds_bytes, stream, *args); break;  \
   case 16 + K: hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, true>), grid, block, lds_bytes, stream, *args); break;
   switch (key) {
     SK_FAST_CASE(0, false, false, false, 0) SK_FAST_CASE(1, false, false, false, 1)

@@ -933,7 +933,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         // sustain is absorbing within a launch: the clock only grows and note-off arrives between launches
         const float tf_first = (float)(d_on + 1);
         steady = __all(dead || !r.use_env || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
-        moved = moved || !steady;
+        if (RAMPK) moved = moved || !steady;
         // envelopes in motion: can the chunk's 8-frame blocks keep the straight-line form (fast_env_span2)?
         if (RAMPK && !steady && exact && tame && !stems_on && cn >= 8) {
           const uint64_t n8 = (uint64_t)(cn & ~7);
@@ -1055,7 +1055,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     }
 
     // "an envelope moved in this launch": what the host's choice between the two instantiations rests on
-    if (ENV && !STOPS && moved && lane == 0) a.group_flag[a.n_groups * 2] = (int32_t)a.launch_ticket;
+    // (only the RAMPK instantiation reports: while the lean one runs, envelopes can start moving through a control action
+    // only, and every control action sends the host back to RAMPK by itself)
+    if (RAMPK && moved && lane == 0) a.group_flag[a.n_groups * 2] = (int32_t)a.launch_ticket;
     // store the recurrences; skipped voices keep their state and get voice_sample = 0 (synth.c:532,538)
     if (!dead) {
       uint4 s0, s1;

@@ -317,7 +317,7 @@ int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */
 
 /* Self-check of the "no envelope in motion" latch of the two-voices-per-lane path ("Envelopes in motion"):
- * the number of launches that skipped sk_render_env2_kernel although a 128-voice slice turned out to need it.  Must
+ * the number of launches that skipped sk_render_env2_kernel although a voice turned out to need it.  Must
  * stay 0; a non-zero value means a voice left a constant envelope level without a control action reaching the bank
  * (skred_amd_last_error() names the launch), after which the latch is re-armed by itself. */
 unsigned skred_bank_env_latch_misses(const skred_bank_t *bank);

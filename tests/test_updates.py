@@ -131,6 +131,56 @@ def test_updates_without_ever_downloading(dev):
     assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
 
 
+def test_updates_on_a_two_operator_fm_bank(dev):
+    """The same 40 blocks of control actions on a two-operator FM bank (every carrier an even voice modulated by the voice
+    after it: the two-per-lane kernel with the pair in one lane, envelope hand-over pair by pair), never downloading.  At block
+    14 one carrier is rewired to the voice two above it (the bank is no longer of the pair shape: the one-per-lane exchange
+    takes over), at block 22 it gets its own modulator back; modulation depths change on the way."""
+    D = dev
+    n = 4096
+    bank, tables, g = banks.bank_c2(n)
+    car = np.arange(0, n, 2)
+    bank["voice_freq_mod_osc"][car] = car + 1
+    bank["voice_freq_mod_depth"][car] = (np.float32(0.1) * (1 + car % 13)).astype(np.float32)
+    bank["voice_disconnect"][car[::3] + 1] = 1
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    mirror = bank.copy()
+    truth, gl = bank.copy(), g.copy()
+    rng = np.random.default_rng(23)
+    mixes, refs, kernels = [], [], []
+    for k in range(40):
+        now = gl.synth_sample_count
+        acts = actions_for_block(k, n, rng, D)
+        acts = [a for a in acts if a.store.__name__ not in ("toggle_filter", "toggle_env")] if k % 3 else acts
+
+        def set_depth(b, vs, now_, st, kk=k):                    # `F1,depth` again with another depth
+            b["voice_freq_mod_depth"][vs] = np.float32(0.05 * (1 + kk % 9))
+        acts.append(Action(car[rng.choice(len(car), 3, replace=False)], D.DIRTY_PARAMS, set_depth))
+        if k in (14, 22):
+            def rewire(b, vs, now_, st, far=(k == 14)):
+                b["voice_freq_mod_osc"][vs] = vs + (2 if far else 1)
+            acts.append(Action([200], D.DIRTY_PARAMS, rewire))
+        for a in acts:
+            a.apply_to(truth, now)
+            a.apply_to(mirror, now, true_state=truth)
+            db.update(mirror, a.voices, a.dirty)
+        m, _ = db.render_host(F, 2, 0)
+        mixes.append(m)
+        kernels.append(db.last_kernel())
+        r = cpuref.render(truth, gl, tables, F, 0)
+        refs.append(cpuref.master(gl, r["sum64"].astype(np.float32)))
+    got = bank.copy()
+    db.download(got)
+    db.close()
+    assert kernels[0] == 3 and set(kernels[14:22]) == {1} and kernels[-1] == 3, kernels
+    bad = got.rw_equal(truth)
+    assert not bad, bad
+    assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
+
+
 PARAM_FIELDS = ["voice_phase_inc", "voice_amp", "voice_table_offset", "voice_table_size", "voice_one_shot",
                 "voice_loop_enabled", "voice_loop_valid", "voice_loop_start_f", "voice_loop_end_f", "voice_direction",
                 "voice_wave_table_index", "voice_use_amp_envelope", "voice_filter_mode", "voice_smoother_enable",
@@ -244,9 +294,12 @@ def test_stamped_note_off_survives_a_later_parameter_update(dev):
     assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
 
 
-def test_quiet_two_per_lane_bank_wakes_up_on_control(dev):
+@pytest.mark.parametrize("two_per_lane", [True, False])
+def test_quiet_two_per_lane_bank_wakes_up_on_control(dev, two_per_lane):
     """Two-per-lane kernels: once a launch has deferred no group to sk_render_env2_kernel the host stops launching
-    it; a stamped trigger / release (or any other control action) must bring it back for the very next block."""
+    it; a stamped trigger / release (or any other control action) must bring it back for the very next block.
+    One-per-lane kernel: the same report swaps the instantiation that holds the block form of envelopes in motion for the
+    lean one and back; both render everything, so the samples must not depend on which one ran."""
     D = dev
     n = 4096
     bank, tables, g = banks.bank_c2(n)
@@ -254,7 +307,7 @@ def test_quiet_two_per_lane_bank_wakes_up_on_control(dev):
     db.set_tables(tables)
     db.upload(bank)
     db.set_globals(g)
-    db.fast2_min_voices(0)
+    db.fast2_min_voices(0 if two_per_lane else 1 << 30)
     mirror, truth, gl = bank.copy(), bank.copy(), g.copy()
     mixes, refs = [], []
     plan = {30: (np.arange(5, n, 97, dtype=np.int32), D.STAMP_RELEASE),
@@ -269,7 +322,7 @@ def test_quiet_two_per_lane_bank_wakes_up_on_control(dev):
             db.update(mirror, vs, dirty)
             apply_captured(truth, mirror, vs, dirty, gl.synth_sample_count, D)
         m, _ = db.render_host(F, 2, 0)
-        assert db.last_kernel() == 3
+        assert db.last_kernel() == (3 if two_per_lane else 1)
         mixes.append(m)
         r = cpuref.render(truth, gl, tables, F, 0)
         refs.append(cpuref.master(gl, r["sum64"].astype(np.float32)))

@@ -26,6 +26,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // envelope at all): its loop has no envelope code and a small register footprint.  Groups with any voice
 // in attack / decay / release are only flagged by it and rendered right afterwards by
 // sk_render_env2_kernel, which carries the envelope machinery (and its registers) alone.
+// This source is compiled twice (Makefile): as skred_render_fast2.o with the plain instantiations and the launcher
+// sk_launch_render_fast2, and -- with SK_FAST2_FMP_TU defined -- as skred_render_fm2.o with the FMP (two-operator FM)
+// instantiations and sk_launch_render_fm2, so that the two halves of the template matrix compile side by side.
+#define SK_FAST2_TU_LOCAL static
+
 struct Fast2Regs {
   v2f inc, lo, hi, span, span2;
   int toff4[2], tsize_m1[2];
@@ -948,7 +953,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
 // 256 sums are scanned across lanes (shuffles inside each wavefront, four wave totals through LDS), every thread writes its
 // prefixes back into the tile, and the tile leaves coalesced.
 #define SK_SCAN_TILE 8192
-__global__ __launch_bounds__(256) void sk_scan_moving_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restrict__ off) {
+SK_FAST2_TU_LOCAL __global__ __launch_bounds__(256) void sk_scan_moving_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restrict__ off) {
   __shared__ int tile[SK_SCAN_TILE + SK_SCAN_TILE / 32];   // element k lives at k + k/32: a thread's 32 counts stay contiguous, the
                                                            // threads' shares start in different banks
 #define SK_SCAN_AT(k) ((k) + ((k) >> 5))
@@ -989,7 +994,7 @@ __global__ __launch_bounds__(256) void sk_scan_moving_kernel(const int32_t *__re
 
 // One wavefront per slice: its handed-over voices (two lane masks) go to list[off[slice] ...] in ascending voice order.
 // pairs: the slice's lanes hold voices (2 lane, 2 lane + 1) and both masks are the same (two-operator FM banks).
-__global__ __launch_bounds__(256) void sk_expand_moving_kernel(const int32_t *__restrict__ counts, const uint64_t *__restrict__ mask,
+SK_FAST2_TU_LOCAL __global__ __launch_bounds__(256) void sk_expand_moving_kernel(const int32_t *__restrict__ counts, const uint64_t *__restrict__ mask,
                                                                 const int32_t *__restrict__ off, int n, int32_t *__restrict__ list, int pairs) {
   const int lane = threadIdx.x & 63, slice = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
   if (slice >= n || counts[slice] == 0) return;
@@ -1010,9 +1015,18 @@ __global__ __launch_bounds__(256) void sk_expand_moving_kernel(const int32_t *__
 
 // sk_render_fast2_kernel renders the constant-envelope slices and flags the others; when the bank has
 // envelopes at all, sk_render_env2_kernel follows on the same stream and renders the flagged groups.
-extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
-                                      hipStream_t stream) {
+#ifdef SK_FAST2_FMP_TU
+#define SK_FAST2_LAUNCHER sk_launch_render_fm2
+#else
+#define SK_FAST2_LAUNCHER sk_launch_render_fast2
+extern "C" int sk_launch_render_fm2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+#endif
+extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
+                                 hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
+#ifndef SK_FAST2_FMP_TU
+  if ((args->fast_mode & SKM_FM_PAIR) && tab_lds) return sk_launch_render_fm2(args, n_workgroups, lds_bytes, stream);
+#endif
   (void)lds_bytes;
   // LDS: [tables] + wsum[2][NW][SK_CHUNK] + per wave the transposition tile and row sums (LDS-table banks) or the table
   // windows (global-table banks).  n_workgroups = partial rows = passes of sk_render_fast2_kernel; the env2 kernel
@@ -1053,13 +1067,20 @@ extern "C" int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgr
       hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, M, P>), grid, block_env, lds_env2, stream, second); \
     }                                                                                                   \
   }
-/* (two-operator FM banks: LDS-table banks only -- T is a constant there, which keeps the instantiations at 24 more) */
+/* (two-operator FM banks: LDS-table banks only -- T is a constant there, which keeps the instantiations at 24 more; they live
+   in the other translation unit) */
+#ifdef SK_FAST2_FMP_TU
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
-    if (fmp && T) { if (mixed) SK_FAST2_LAUNCH(true, F, E, I, true, true) else SK_FAST2_LAUNCH(true, F, E, I, false, true) } \
-    else if (mixed) SK_FAST2_LAUNCH(T, F, E, I, true, false)                                            \
+    if (mixed) SK_FAST2_LAUNCH(true, F, E, I, true, true) else SK_FAST2_LAUNCH(true, F, E, I, false, true) \
+    break;
+#else
+#define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
+  case K:                                                                                               \
+    if (mixed) SK_FAST2_LAUNCH(T, F, E, I, true, false)                                                 \
     else SK_FAST2_LAUNCH(T, F, E, I, false, false)                                                      \
     break;
+#endif
   switch (key) {
     SK_FAST2_CASE(0, false, false, false, 0) SK_FAST2_CASE(1, false, false, false, 1)
     SK_FAST2_CASE(2, false, false, true, 0)  SK_FAST2_CASE(3, false, false, true, 1)

@@ -237,6 +237,7 @@ static int classify(skred_bank_t *b) {
     if (b->cnt_stops) m |= SKM_STOPS;
     if (b->cnt_fm) m |= SKM_FM;
     if (b->cnt_fm && !b->cnt_fm_odd && !b->cnt_stops) m |= SKM_FM_PAIR;   /* every carrier: an even voice modulated by the next one */
+    if ((m & SKM_FM_PAIR) && b->cnt_pair_ap) m |= SKM_PAIR_AP;
   }
   b->fast_mode = m;
   b->class_dirty = 0;
@@ -410,7 +411,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   if (fast_ok && (a.fast_mode & SKM_FM_PAIR) && a.lds_table_floats > 0 && !d_stems && b->n_voices >= b->fm2_min_voices)
     a.fast_mode |= SKM_TWO_PER_LANE;
   else
-    a.fast_mode &= ~SKM_FM_PAIR;
+    a.fast_mode &= ~(SKM_FM_PAIR | SKM_PAIR_AP);
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
   if (!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) {

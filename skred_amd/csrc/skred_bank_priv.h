@@ -55,6 +55,7 @@ struct skred_bank {
   int max_level;
   int class_dirty;
   int cnt_real, cnt_filter, cnt_env, cnt_exotic, cnt_stops, cnt_fm;   /* voices per SKC_* bit (kept incrementally) */
+  int cnt_pair_ap;            /* pair-shaped carriers whose amplitude or pan is modulated too (SKC_PAIR_AP) */
   int cnt_fm_odd;             /* SKC_FM voices that are not the even half of a (carrier, next voice) pair (SKC_FM_ODD) */
   int cnt_escapes;            /* voices naming a modulator outside their aligned 64-voice group (SKC_ESCAPES) */
   uint64_t future_horizon;    /* the latest such clock value: once the bank's clock reaches it, no voice is "future" any more */
@@ -103,6 +104,7 @@ struct skred_bank {
                            so "no envelope in motion" may not be latched while such a voice exists */
 #define SKC_FM_ODD 256u /* an SKC_FM voice that is anything but: even index, frequency-modulated by the voice after it and by nothing else
                           -- the shape sk_render_fast2_kernel<FMP> renders with carrier and modulator in one lane */
+#define SKC_PAIR_AP 512u /* a pair-shaped carrier whose amplitude or pan is modulated (by the voice after it or by itself) */
 #define SKC_ESCAPES 128u /* names a modulator outside its aligned 64-voice group: the bank cannot be rendered until that is fixed */
 
 

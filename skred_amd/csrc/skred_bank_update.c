@@ -90,8 +90,14 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
     if ((has_mod && !fm_only) || (!finite && !noise))        /* (a noise voice never runs its oscillator: synth.c:543-546) */
       c |= SKC_EXOTIC;
     if (fm_only) c |= SKC_FM;
-    if (fm_only && !((dst & 1) == 0 && h->voice_freq_mod_osc[v] - v == 1 && h->voice_amp_mod_osc[v] < 0 && h->voice_pan_mod_osc[v] < 0))
-      c |= SKC_FM_ODD;
+    {
+      /* the pair shape: an even voice whose frequency, amplitude and pan modulators are each the voice after it -- or, amplitude
+       * and pan, the voice itself (`F1`, `A1`, `P1`, `A0`, `P0` on voice 0) */
+      const int fo = h->voice_freq_mod_osc[v] == v ? -1 : h->voice_freq_mod_osc[v], ao = h->voice_amp_mod_osc[v], po = h->voice_pan_mod_osc[v];
+      const int pair = (dst & 1) == 0 && (fo < 0 || fo - v == 1) && (ao < 0 || ao - v == 1 || ao == v) && (po < 0 || po - v == 1 || po == v);
+      if (fm_only && !pair) c |= SKC_FM_ODD;
+      if (fm_only && pair && (ao >= 0 || po >= 0)) c |= SKC_PAIR_AP;
+    }
     {
       /* a note-on or note-off stamped AHEAD of the clock (a host scheduling a note by writing sample_start itself): until
        * the clock catches up the reference reads the wrapped difference as a huge elapsed time (synth.c:401,422) */
@@ -160,8 +166,8 @@ void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m, int param
   uint16_t now = params_travel ? (uint16_t)(m->cls & ~SKC_FUTURE) : (uint16_t)(old & ~SKC_FUTURE);
   now |= clock_travels ? (m->cls & SKC_FUTURE) : (old & SKC_FUTURE);
   if (old != now) {
-    if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; if (old & SKC_STOPS) b->cnt_stops--; if (old & SKC_FM) b->cnt_fm--; if (old & SKC_FM_ODD) b->cnt_fm_odd--; }
-    if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; if (now & SKC_STOPS) b->cnt_stops++; if (now & SKC_FM) b->cnt_fm++; if (now & SKC_FM_ODD) b->cnt_fm_odd++; }
+    if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; if (old & SKC_STOPS) b->cnt_stops--; if (old & SKC_FM) b->cnt_fm--; if (old & SKC_FM_ODD) b->cnt_fm_odd--; if (old & SKC_PAIR_AP) b->cnt_pair_ap--; }
+    if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; if (now & SKC_STOPS) b->cnt_stops++; if (now & SKC_FM) b->cnt_fm++; if (now & SKC_FM_ODD) b->cnt_fm_odd++; if (now & SKC_PAIR_AP) b->cnt_pair_ap++; }
     /* per-voice bits that are not kernel classes: counted whether or not the voice can sound, and recounted whenever the
      * voice is written again -- a routing that escaped its group stops blocking the bank once it is fixed */
     b->cnt_escapes += ((now & SKC_ESCAPES) != 0) - ((old & SKC_ESCAPES) != 0);

@@ -27,8 +27,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // in attack / decay / release are only flagged by it and rendered right afterwards by
 // sk_render_env2_kernel, which carries the envelope machinery (and its registers) alone.
 // This source is compiled twice (Makefile): as skred_render_fast2.o with the plain instantiations and the launcher
-// sk_launch_render_fast2, and -- with SK_FAST2_FMP_TU defined -- as skred_render_fm2.o with the FMP (two-operator FM)
-// instantiations and sk_launch_render_fm2, so that the two halves of the template matrix compile side by side.
+// sk_launch_render_fast2, and -- with -DSK_FAST2_FMP_TU=1 / =2 -- as skred_render_fm2.o / skred_render_fm2ap.o with the
+// FMP (two-operator FM; ... with amplitude / pan modulation) instantiations and sk_launch_render_fm2 / _fm2ap, so that the two halves of the template matrix compile side by side.
 #define SK_FAST2_TU_LOCAL static
 
 struct Fast2Regs {
@@ -47,6 +47,11 @@ struct Fast2Regs {
   // frequency-modulated by voice 1's sample of the previous frame (synth.c:548-555: the carrier comes first in index order)
   bool fm_on;
   float fm_k, fm_depth;                    // voice_phase_inc[m] * voice_freq_scale[n];  voice_freq_mod_depth[n]
+  // ... and its amplitude / pan may be modulated by voice 1's previous sample or by its own sample of this frame
+  // (synth.c:583-588 post-filter, synth.c:597-602 post-gain; see fast_post in skred_render_fast.hip)
+  bool am_on, am_self, pm_on, pm_self, pan_dirty;
+  float am_depth, pm_depth, mprev;         // mprev: voice 1's sample of the previous frame, read before this frame changes it
+  uint32_t misc_x, misc_y;                 // voice 0's sample & hold words: they travel back with a modulated pan (one 16-byte store)
 };
 
 struct Env2Regs {                 // sk_render_env2_kernel only
@@ -188,10 +193,14 @@ __device__ __forceinline__ float fast2_env_general(Fast2Regs &r, Env2Regs &e, in
 // Oscillator half of a frame: advance both phases, wrap, fetch the two table samples.
 // LOZ: every lane of the wave has lo == 0 (no loop window: the plain LUT case).  Then ph0 - lo == ph0 and
 // lo + y == y exactly, so the wrapped phase lo + ((ph0 - lo) - span) is ph0 - span: one packed add instead of three.
-template <bool TAB_LDS, bool TAME, int INTERP, bool LOZ = false, bool FMP = false>
+template <bool TAB_LDS, bool TAME, int INTERP, bool LOZ = false, int FMP = 0>
 __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, const char *__restrict__ glb_tab) {
   v2f inc = r.inc;
-  if (FMP && !TAME) inc.x = r.fm_on ? r.inc.x + r.fm_k * (r.sample.y * r.fm_depth) : r.inc.x;   // synth.c:551-554
+  if (FMP && !TAME) {
+    const float ms = r.sample.y;                       // voice_sample[m] as the previous frame left it
+    if (FMP == 2) r.mprev = ms;
+    inc.x = r.fm_on ? r.inc.x + r.fm_k * (ms * r.fm_depth) : r.inc.x;        // synth.c:551-554
+  }
   const v2f ph0 = r.phase + inc;
   const v2f x = LOZ ? ph0 : ph0 - r.lo;
   const v2f phw = LOZ ? x - r.span : r.lo + (x - r.span);
@@ -221,7 +230,7 @@ __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, cons
 // EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
 // with the short exact division; 2 general; 3 constant gain AND the amp smoother has stalled in every lane
 // (fast2_smoother_stalled: its update no longer changes it, so it is skipped).  TAME: see fast_frame.
-template <bool FILTER, int EM, bool TAME, bool MIXED = false, bool MUTESEL = false>
+template <bool FILTER, int EM, bool TAME, bool MIXED = false, bool MUTESEL = false, int FMP = 0>
 __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
                                            const bool rel0, const bool rel1, const bool silent0,
                                            const bool silent1, float &out_l, float &out_r) {
@@ -284,9 +293,16 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
     gain.x = fast2_env_general(r, e, 0, rel0);
     gain.y = fast2_env_general(r, e, 1, rel1);
   }
+  if (FMP == 2 && !TAME && r.am_on)                    // final = amp * env * mod (synth.c:583-588): voice 0 only
+    gain.x = gain.x * ((r.am_self ? s.x : r.mprev) * r.am_depth);
   if (EM != 3) r.sgain = r.sgain + r.k * (gain - r.sgain);
   s = s * r.sgain;
   r.sample = s;
+  if (FMP == 2 && !TAME && r.pm_on && !silent0) {      // synth.c:597-602 (inside the `not disconnected` branch)
+    const float q = (r.pm_self ? s.x : r.mprev) * r.pm_depth;
+    r.pan_lr[0] = (v2f){(1.0f - q) / 2.0f, (1.0f + q) / 2.0f};
+    r.pan_dirty = true;
+  }
   // ---- pan, lane-local sum of the two voices ----
   v2f so = s;
   if (!TAME || MUTESEL) {   // plain TAME loops run only when no live lane is muted (dead lanes already yield exact zeros);
@@ -308,16 +324,16 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
 // evaluates, compared bitwise), made once per 64-frame chunk of a constant-gain wave.
 __device__ __forceinline__ bool fast2_smoother_stalled(const Fast2Regs &r) {
   const v2f nxt = r.sgain + r.k * (r.gain_const - r.sgain);
-  return __all(__float_as_uint(nxt.x) == __float_as_uint(r.sgain.x) && __float_as_uint(nxt.y) == __float_as_uint(r.sgain.y));
+  return __all(!r.am_on && __float_as_uint(nxt.x) == __float_as_uint(r.sgain.x) && __float_as_uint(nxt.y) == __float_as_uint(r.sgain.y));
 }
 
-template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP, bool MIXED = false, bool FMP = false>
+template <bool TAB_LDS, bool FILTER, int EM, bool TAME, int INTERP, bool MIXED = false, int FMP = 0>
 __device__ __forceinline__ void fast2_frame(Fast2Regs &r, Env2Regs &e, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
                                             const bool rel0, const bool rel1, const bool silent0,
                                             const bool silent1, const char *lds_tab,
                                             const char *__restrict__ glb_tab, float &out_l, float &out_r) {
   const v2f s = fast2_osc<TAB_LDS, TAME, INTERP, false, FMP>(r, lds_tab, glb_tab);
-  fast2_post<FILTER, EM, TAME, MIXED>(r, e, s, xn, xo, yn, yo, rel0, rel1, silent0, silent1, out_l, out_r);
+  fast2_post<FILTER, EM, TAME, MIXED, false, FMP>(r, e, s, xn, xo, yn, yo, rel0, rel1, silent0, silent1, out_l, out_r);
 }
 
 // ---- table windows for pools that do not fit in LDS (PCM banks) ----
@@ -549,7 +565,7 @@ __device__ __forceinline__ void fast2_make_inert(Fast2Regs &r, Env2Regs &e, int 
 // vidx[c]: the lane's two voices (sk_render_fast2_kernel: vbase + c*64 + lane of its 128-voice slice; sk_render_env2_kernel:
 // two entries of the hand-over list); absent[c]: no voice in that slot (the list's ragged end) -- treated as dead and
 // never stored.
-template <bool FILTER, bool ENV, bool MIXED, bool FMP = false>
+template <bool FILTER, bool ENV, bool MIXED, int FMP = 0>
 __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, const int vidx[2], const bool absent[2], int lane, Fast2Regs &r,
                                            Env2Regs &e, bool dead[2], bool silent[2], bool released[2],
                                            uint64_t t_start[2], uint64_t t_release[2], bool &tame_m) {
@@ -576,6 +592,7 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, const int 
     r.y1[c] = __uint_as_float(s1.x);    r.y2[c] = __uint_as_float(s1.y);
     r.sample[c] = __uint_as_float(s1.z); r.rw[c] = s1.w;
     r.pan_lr[c].x = __uint_as_float(s2.z); r.pan_lr[c].y = __uint_as_float(s2.w);
+    if (FMP == 2 && c == 0) { r.misc_x = s2.x; r.misc_y = s2.y; }
     r.b2[c] = 0.0f; r.a1[c] = 0.0f; r.a2[c] = 0.0f;
     if (FILTER) {
       const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
@@ -615,14 +632,22 @@ __device__ __forceinline__ bool fast2_load(const sk_render_args_t &a, const int 
   r.span2 = r.span + r.span;
   if (MIXED) { r.ox1 = r.x1; r.ox2 = r.x2; r.oy1 = r.y1; r.oy2 = r.y2; }
   r.fm_on = false; r.fm_k = 0.0f; r.fm_depth = 0.0f;
+  r.am_on = r.am_self = r.pm_on = r.pm_self = r.pan_dirty = false; r.am_depth = r.pm_depth = r.mprev = 0.0f;
+  if (FMP != 2) { r.misc_x = 0; r.misc_y = 0; }
   if (FMP) {
     const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][vidx[0]]);
     const uint4 mf = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODF][vidx[0]]);
-    r.fm_on = !dead[0] && (int)mi.x >= 0;            // (the host vouches that the modulator is the voice after it)
+    const int own = vidx[0] & 63;                    // (the host vouches that a modulator is the voice after it, or -- amplitude,
+    r.fm_on = !dead[0] && (int)mi.x >= 0;            //  pan -- the voice itself)
     r.fm_k = inc_raw1 * __uint_as_float(mf.y);
     r.fm_depth = __uint_as_float(mf.x);
+    if (FMP == 2) {
+      r.am_on = !dead[0] && (int)mi.y >= 0; r.am_self = (int)mi.y == own; r.am_depth = __uint_as_float(mf.z);
+      r.pm_on = !dead[0] && (int)mi.z >= 0; r.pm_self = (int)mi.z == own; r.pm_depth = __uint_as_float(mf.w);
+    }
   }
-  bool tame_lane = !(FMP && r.fm_on), muted_lane = false;   // a modulated increment may be negative or long: general wrap
+  // a modulated increment may be negative or long (general wrap); a modulated gain or pan needs the general frames too
+  bool tame_lane = !(FMP && (r.fm_on || r.am_on || r.pm_on)), muted_lane = false;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     muted_lane = muted_lane || (silent[c] && !dead[c]);
@@ -651,6 +676,8 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
       s1.z = __float_as_uint(r.sample[c]); s1.w = (MIXED && r.fake_active[c]) ? (r.rw[c] & ~SKR_ENV_ACTIVE) : r.rw[c];
       *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
       *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;
+      if (c == 0 && r.pan_dirty)   // pan modulation rewrote voice_pan_left / _right (synth.c:600-601)
+        *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = make_uint4(r.misc_x, r.misc_y, __float_as_uint(r.pan_lr[0].x), __float_as_uint(r.pan_lr[0].y));
     } else {
       reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][v])[2] = 0u;     // voice_sample = 0, synth.c:532,538
     }
@@ -706,7 +733,8 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
 template <bool TAB_LDS> struct Fast2Shape { static constexpr int NW = TAB_LDS ? SK_FAST2_NW_LDS : 4; };
 
 // FMP: a two-operator FM bank (SKM_FM_PAIR) -- a lane holds voices 2i and 2i+1 of its slice, carrier and modulator.
-template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED, bool FMP = false>
+// FMP == 2 (SKM_PAIR_AP): some carrier's amplitude or pan is modulated too (by the voice after it or by itself).
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED, int FMP = 0>
 __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
   constexpr int NW = Fast2Shape<TAB_LDS>::NW;
   SK_FAST2_PROLOGUE()
@@ -769,6 +797,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
           if (moving[c]) {     // (two numbers, not fast2_make_inert's twenty-five: the kernel sits at its register budget)
             r.pan_lr[c] = (v2f){0.0f, 0.0f};           // it walks its oscillator for nothing and adds exact zeros
             r.k[c] = 0.0f;                             // its smoother counts as stalled (fast2_smoother_stalled is a wave vote)
+            if (FMP == 2) r.am_on = r.pm_on = false;   // (and its pan stays at zero)
           }
         wave_ok = __any((!dead[0] && !moving[0]) || (!dead[1] && !moving[1]));   // (nothing left to render: zeros to the chunk sums)
       }
@@ -806,7 +835,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
 #ifndef SK_ENV2_MIN_WAVES
 #define SK_ENV2_MIN_WAVES 3      /* the envelope machinery wants ~170 VGPRs: 3 waves per SIMD measured best (2: no spills, 4: 220 B of scratch) */
 #endif
-template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED, bool FMP = false>
+template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED, int FMP = 0>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
   constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
   SK_FAST2_PROLOGUE_((int)blockIdx.x - a.wg_shift < (a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows) &&
@@ -1015,17 +1044,22 @@ SK_FAST2_TU_LOCAL __global__ __launch_bounds__(256) void sk_expand_moving_kernel
 
 // sk_render_fast2_kernel renders the constant-envelope slices and flags the others; when the bank has
 // envelopes at all, sk_render_env2_kernel follows on the same stream and renders the flagged groups.
-#ifdef SK_FAST2_FMP_TU
+#if defined(SK_FAST2_FMP_TU) && SK_FAST2_FMP_TU == 2
+#define SK_FAST2_LAUNCHER sk_launch_render_fm2ap
+#elif defined(SK_FAST2_FMP_TU)
 #define SK_FAST2_LAUNCHER sk_launch_render_fm2
 #else
 #define SK_FAST2_LAUNCHER sk_launch_render_fast2
 extern "C" int sk_launch_render_fm2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+extern "C" int sk_launch_render_fm2ap(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 #endif
 extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
                                  hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
 #ifndef SK_FAST2_FMP_TU
-  if ((args->fast_mode & SKM_FM_PAIR) && tab_lds) return sk_launch_render_fm2(args, n_workgroups, lds_bytes, stream);
+  if ((args->fast_mode & SKM_FM_PAIR) && tab_lds)
+    return (args->fast_mode & SKM_PAIR_AP) ? sk_launch_render_fm2ap(args, n_workgroups, lds_bytes, stream)
+                                           : sk_launch_render_fm2(args, n_workgroups, lds_bytes, stream);
 #endif
   (void)lds_bytes;
   // LDS: [tables] + wsum[2][NW][SK_CHUNK] + per wave the transposition tile and row sums (LDS-table banks) or the table
@@ -1072,13 +1106,13 @@ extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups,
 #ifdef SK_FAST2_FMP_TU
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
-    if (mixed) SK_FAST2_LAUNCH(true, F, E, I, true, true) else SK_FAST2_LAUNCH(true, F, E, I, false, true) \
+    if (mixed) SK_FAST2_LAUNCH(true, F, E, I, true, SK_FAST2_FMP_TU) else SK_FAST2_LAUNCH(true, F, E, I, false, SK_FAST2_FMP_TU) \
     break;
 #else
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
-    if (mixed) SK_FAST2_LAUNCH(T, F, E, I, true, false)                                                 \
-    else SK_FAST2_LAUNCH(T, F, E, I, false, false)                                                      \
+    if (mixed) SK_FAST2_LAUNCH(T, F, E, I, true, 0)                                                     \
+    else SK_FAST2_LAUNCH(T, F, E, I, false, 0)                                                          \
     break;
 #endif
   switch (key) {

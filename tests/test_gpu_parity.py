@@ -473,6 +473,15 @@ def test_two_operator_fm_pairs_share_a_lane(dev, recipe, interp, mixed):
     if mixed:                                           # filter / envelope on some voices only: per-lane flags
         bank["voice_filter_mode"][mod[::3]] = 0
         bank["voice_use_amp_envelope"][car[::4]] = 0
+    # amplitude and pan modulation of the same shape (`A1`, `P1`: by the voice after the carrier; `A0`, `P0`: by the carrier
+    # itself), on carriers with and without FM, one of them muted (a muted voice's pan is not modulated, synth.c:596)
+    am = car[3::11]; bank["voice_amp_mod_osc"][am] = am + 1; bank["voice_amp_mod_depth"][am] = np.float32(3.0)
+    pm = car[7::13]; bank["voice_pan_mod_osc"][pm] = pm + 1; bank["voice_pan_mod_depth"][pm] = np.float32(8.0)
+    sa = car[9::29]; bank["voice_amp_mod_osc"][sa] = sa; bank["voice_amp_mod_depth"][sa] = np.float32(2.5)
+    sp = car[11::31]; bank["voice_pan_mod_osc"][sp] = sp; bank["voice_pan_mod_depth"][sp] = np.float32(6.0)
+    free = np.arange(8, n - 1, 10)                      # the unmodulated pairs' even voices: pan modulation only
+    bank["voice_pan_mod_osc"][free[::2]] = free[::2] + 1; bank["voice_pan_mod_depth"][free[::2]] = np.float32(4.0)
+    bank["voice_disconnect"][pm[::4]] = 1
 
     def kill_some(host, now):
         host["voice_amp"][mod[::7]] = 0.0

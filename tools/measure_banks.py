@@ -124,6 +124,15 @@ def fm():
             if mute:
                 b["voice_disconnect"][car + 1] = 1
             run(f"{rec} 2^20 two-operator FM" + (", modulators muted (m1)" if mute else ""), b, t, g, steps=40)
+    b, t, g = banks.bank_c2(1 << 20)
+    car = np.arange(0, 1 << 20, 2)
+    b["voice_pan_mod_osc"][car] = car + 1
+    b["voice_pan_mod_depth"][car] = 0.5
+    b["voice_disconnect"][car + 1] = 1
+    run("c2 2^20 pan modulated by the next voice (P1 / m1)", b, t, g, steps=40)
+    b["voice_freq_mod_osc"][car] = car + 1
+    b["voice_freq_mod_depth"][car] = 0.2
+    run("c2 2^20 two-operator FM + pan modulation (F1 P1 / m1)", b, t, g, steps=40)
 
 
 def noise():

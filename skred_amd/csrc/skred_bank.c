@@ -406,6 +406,13 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   if ((a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_STOPS | SKM_FM)) && b->n_voices >= b->fast2_min_voices &&
       (a.lds_table_floats > 0 || b->fast2_min_user) && !d_stems)      /* (per-voice stems: the one-voice kernel writes them) */
     a.fast_mode |= SKM_TWO_PER_LANE;        /* (voices that finish mid-launch are handled by the one-per-lane kernel only) */
+  /* ... but while envelopes move (no launch has reported a quiet bank since the last control action) the one-voice kernel's
+   * block form of them beats the two-per-lane kernel + envelope kernel on banks up to ~400 000 voices (tools/ab_env_mid.py:
+   * 262 144 voices 184 vs 213 us per block, 393 216 voices 256 vs 267, 524 288 voices 327 vs 279): such banks change kernels
+   * with their state (both read and write the same planes) */
+  if ((a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL) && !(a.fast_mode & SKM_MIXED) && !b->env_quiet &&
+      !b->fast2_min_user && b->n_voices < SK_FAST2_MOTION_MIN_VOICES)
+    a.fast_mode &= ~SKM_TWO_PER_LANE;
   /* two-operator FM (every carrier an even voice, modulated by the voice after it): carrier and modulator share a lane of
    * the two-per-lane kernel, so the per-frame exchange of the one-per-lane kernel disappears.  LDS-table banks. */
   if (fast_ok && (a.fast_mode & SKM_FM_PAIR) && a.lds_table_floats > 0 && !d_stems && b->n_voices >= b->fm2_min_voices)

@@ -333,6 +333,40 @@ def test_quiet_two_per_lane_bank_wakes_up_on_control(dev, two_per_lane):
     assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
 
 
+def test_mid_size_bank_changes_kernels_with_its_state(dev):
+    """An enveloped bank between the two-per-lane threshold and 393 216 voices renders on the one-voice kernel while
+    envelopes move and on the two-per-lane kernel once a launch has reported a quiet bank; a note-on sends it back.  The
+    two kernel families share the voice planes: the samples must not show the hand-overs."""
+    D = dev
+    n, Fm = 229376, 256
+    bank, tables, g = banks.bank_c2(n)
+    e = bank["voice_amp_envelope"]                      # everyone long in sustain except a few fresh notes
+    e["sample_start"][:] = g.synth_sample_count - 48000
+    e["sample_start"][::997] = g.synth_sample_count - 100
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    mirror, truth, gl = bank.copy(), bank.copy(), g.copy()
+    mixes, refs, kernels = [], [], []
+    for k in range(36):
+        if k == 30:
+            vs = np.arange(3, n, 4001, dtype=np.int32)
+            db.update(mirror, vs, D.STAMP_TRIGGER)
+            apply_captured(truth, mirror, vs, D.STAMP_TRIGGER, gl.synth_sample_count, D)
+        m, _ = db.render_host(Fm, 2, 0)                  # (synchronous: the report of block k is in before block k+1 is issued)
+        kernels.append(db.last_kernel())
+        mixes.append(m)
+        r = cpuref.render(truth, gl, tables, Fm, 0)
+        refs.append(cpuref.master(gl, r["sum64"].astype(np.float32)))
+    got = bank.copy()
+    db.download(got)
+    db.close()
+    assert kernels[0] == 1 and 3 in kernels[:30] and kernels[29] == 3 and kernels[30] == 1, kernels
+    assert not got.rw_equal(truth), got.rw_equal(truth)
+    assert rel_rms(np.concatenate(mixes), np.concatenate(refs)) <= 1e-5
+
+
 def test_update_argument_checks(dev):
     n = 256
     bank, tables, g = banks.bank_c1(n)

@@ -488,6 +488,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_DRAW()                                                                                   \
   float white_ = 0.0f;                                                                                   \
   if (STOPS && (xf & XF_NOISE)) { rng = rng * LCG_A + LCG_C; white_ = (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f; }
+/* block paths: the oscillator sample S of this frame, or -- a noise lane -- the frame's shared draw (synth.c:543-546); the
+   wave advances the LCG once per frame it renders, in frame order, as SK_FAST_DRAW does on the frame paths */
+#define SK_FAST_BLOCK_SAMPLE(S)                                                                          \
+  ((STOPS && (xf & XF_NOISE)) ? (rng = rng * LCG_A + LCG_C, (r.noise ? (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f : (S))) : (S))
 #define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO, SWAPPED_)                                              \
   {                                                                                                      \
     float l, rr;                                                                                         \
@@ -507,8 +511,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     float l0, r0, l1, r1;                                                                                \
     const float sa_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
     const float sb_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
-    fast_post_v<FILTER, ENV, false, STOPS, true>(r, pk, sa_, xx, yy, l0, r0, xf);                           \
-    fast_post_v<FILTER, ENV, false, STOPS, false>(r, pk, sb_, xx, yy, l1, r1, xf);                           \
+    fast_post_v<FILTER, ENV, false, STOPS, true>(r, pk, SK_FAST_BLOCK_SAMPLE(sa_), xx, yy, l0, r0, xf);     \
+    fast_post_v<FILTER, ENV, false, STOPS, false>(r, pk, SK_FAST_BLOCK_SAMPLE(sb_), xx, yy, l1, r1, xf);    \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
@@ -557,13 +561,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     float f0_, f1_;                                                                                      \
     if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
       float s0_, s1_, u_;                                                                                \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false, RAMP_>(r, pk, SRC[q_], xx, yy, s0_, u_, xf, &ev_);         \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false, RAMP_>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf, &ev_);    \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_]), xx, yy, s0_, u_, xf, &ev_);         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1]), xx, yy, s1_, u_, xf, &ev_);    \
       fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
     } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
       float l0_, r0_, l1_, r1_;                                                                          \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf, &ev_);               \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SRC[q_ + 1], xx, yy, l1_, r1_, xf, &ev_);          \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_]), xx, yy, l0_, r0_, xf, &ev_);               \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1]), xx, yy, l1_, r1_, xf, &ev_);          \
       f0_ = fold_lr(l0_, r0_); f1_ = fold_lr(l1_, r1_);                                                  \
     }                                                                                                    \
     xt[q_ * SK_XT + lane] = f0_;                                                                         \
@@ -578,13 +582,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     DST[q_ + 1] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));         \
     if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
       float s0_, s1_, u_;                                                                                \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SRC[q_], xx, yy, s0_, u_, xf);         \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf);    \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_]), xx, yy, s0_, u_, xf);         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1]), xx, yy, s1_, u_, xf);    \
       fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
     } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
       float l0_, r0_, l1_, r1_;                                                                          \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf);               \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1_, r1_, xf);          \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_]), xx, yy, l0_, r0_, xf);               \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1]), xx, yy, l1_, r1_, xf);          \
       f0_ = fold_lr(l0_, r0_); f1_ = fold_lr(l1_, r1_);                                                  \
     }                                                                                                    \
     xt[q_ * SK_XT + lane] = f0_;                                                                         \
@@ -711,10 +715,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, s0_, xx, yy, l0, r0, xf, &ev_);                       \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s0_), xx, yy, l0, r0, xf, &ev_);                       \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); SK_FAST_REPACK() } \
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, s1_, xx, yy, l1, r1, xf, &ev_);                       \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s1_), xx, yy, l1, r1, xf, &ev_);                       \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); SK_FAST_REPACK() } \
       xt[q_ * SK_XT + lane] = fold_lr(l0, r0);     /* (global-table banks: the tile has its own LDS behind the windows) */ \
       xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                     \
@@ -897,7 +901,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     }
     // features the block paths do not serve (modulation exchange, reverse, the noise source): such a wave walks frame by
     // frame; sample & hold, bit-crush and smoother-off ride the block paths (fast_post_v), stopping voices while far from their end
-    const bool any_fm = (xf & ~(XF_STOP | XF_HOLDQ | XF_NOSMOOTH)) != 0;
+    const bool any_fm = (xf & ~(XF_STOP | XF_HOLDQ | XF_NOSMOOTH | XF_NOISE)) != 0;   // (what keeps a wave off the block paths)
     const bool any_stop = (xf & XF_STOP) != 0;
     uint64_t rng = a.rng0;                                // noise LCG state before the first frame of the launch
     (void)any_stop; (void)any_fm; (void)rng;

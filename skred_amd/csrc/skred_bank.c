@@ -458,8 +458,8 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   /* one-per-lane banks with envelopes (plain instantiation): the same report picks between the instantiation that also holds
    * the block form of envelopes in motion and the lean one (skred_render_fast.hip: RAMPK); both render everything, so a stale
    * answer costs speed, never samples */
-  const int one_env = !modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_TWO_PER_LANE | SKM_STOPS | SKM_FM | SKM_MIXED)) &&
-                      (a.fast_mode & SKM_ENV_ALL);
+  const int one_env = !modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
+  /* (plain and extended instantiations alike; a wave with frequency-modulated carriers never takes the block form) */
   const int env_latch = two_env || one_env;
   if (env_latch) poll_env_quiet(b);
   a.launch_ticket = ++b->launch_ticket;

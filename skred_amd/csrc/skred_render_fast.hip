@@ -250,7 +250,7 @@ __device__ __forceinline__ int fast_stage_code(bool active, bool released, float
 // the lane can be rendered in this form; `runs_out`: its release ends in the span (the caller clears is_active, synth.c:429).
 __device__ __forceinline__ void fast_env_span2(const FastRegs &r, FastEnv &e, bool dead, bool released, float t1, float tr1,
                                                float tN, float trN, float t0, float tr0, bool &ok, bool &runs_out) {
-  const bool act = (r.rw & SKR_ENV_ACTIVE) != 0;
+  const bool act = (r.rw & SKR_ENV_ACTIVE) != 0 && r.use_env;   // (a voice without envelope takes `amp`: fast_env_gain; its sets are inert)
   const int code0 = fast_stage_code(act, released, t1, tr1, r.att, r.attdec, r.rel);
   const int code1 = fast_stage_code(act, released, tN, trN, r.att, r.attdec, r.rel);
   const bool step = code0 != code1;
@@ -274,7 +274,7 @@ __device__ __forceinline__ void fast_env_span2(const FastRegs &r, FastEnv &e, bo
   }
   e.bnd = !step ? __builtin_huge_valf() : (code0 == 1 ? r.att : (code0 == 2 ? r.attdec : r.rel));
   ok = ok && (dead || ((!step || next_stage) && den[0] >= 0x1p-40f && den[0] <= 0x1p40f && den[1] >= 0x1p-40f && den[1] <= 0x1p40f));
-  runs_out = !dead && (code0 == 5 || code1 == 5);
+  runs_out = !dead && r.use_env && (code0 == 5 || code1 == 5);
 }
 
 // this frame's gain amp * (e * velocity) (synth.c:582,588) from the two constant sets
@@ -291,7 +291,7 @@ __device__ __forceinline__ float fast_env_gain(const FastRegs &r, FastEnv &e) {
   rem = __builtin_fmaf(-den, q, num);
   q = __builtin_fmaf(rem, rinv, q);
   const float lvl = C * (A + B * q);
-  return r.amp * (lvl * r.vel);
+  return r.use_env ? r.amp * (lvl * r.vel) : r.amp;    // (extended banks: a voice without envelope, synth.c:580-582)
 }
 
 template <bool FILTER, bool ENV, bool STALL, bool EXT, bool NEWEST_X, bool PAN = true, bool RAMP = false>
@@ -918,6 +918,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     bool moved = false;                               // (wave-uniform) some chunk of this pass had an envelope in motion
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
+      // a stopping voice that cannot reach its table end within this chunk (forward, unmodulated: phase + 64*inc,
+      // rounding included, stays below it) needs no per-frame finish test yet
+      const bool stop_near = STOPS && any_stop && __any(r.stop && !(r.phase + (float)SK_CHUNK * r.inc + 2.0f < r.hi));
       FastEnv ev_;                                    // (RAMPK) envelopes in motion on the block paths; per chunk
       ev_.clk = ev_.base = ev_.A = ev_.B = ev_.C = ev_.clk2 = ev_.base2 = ev_.A2 = ev_.B2 = ev_.C2 = 0.0f;
       ev_.den = ev_.rinv = ev_.den2 = ev_.rinv2 = 1.0f; ev_.bnd = 0.0f;
@@ -939,7 +942,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         steady = __all(dead || !r.use_env || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
         if (RAMPK) moved = moved || !steady;
         // envelopes in motion: can the chunk's 8-frame blocks keep the straight-line form (fast_env_span2)?
-        if (RAMPK && !steady && exact && tame && !stems_on && cn >= 8) {
+        if (RAMPK && !steady && exact && tame && !stems_on && cn >= 8 && (!STOPS || (!any_fm && !stop_near))) {
           const uint64_t n8 = (uint64_t)(cn & ~7);
           bool ok = true, runs_out = false;
           fast_env_span2(r, ev_, dead, released, tf_first, (float)(d_off + 1), (float)(d_on + n8), (float)(d_off + n8), r.tf, r.trf, ok, runs_out);
@@ -948,9 +951,6 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
           ramp_tf = (float)(d_on + n8); ramp_trf = released ? (float)(d_off + n8) : 0.0f;   // clocks of the blocks' last frame
         }
       }
-      // a stopping voice that cannot reach its table end within this chunk (forward, unmodulated: phase + 64*inc,
-      // rounding included, stays below it) needs no per-frame finish test yet
-      const bool stop_near = STOPS && any_stop && __any(r.stop && !(r.phase + (float)SK_CHUNK * r.inc + 2.0f < r.hi));
       if (STOPS && (!ENV || steady) && tame && !any_fm && !stop_near && TAB_LDS && !stems_on) {
         // an extended bank, but nothing in THIS wave needs the frame loop now (e.g. only some voices filtered, or one-shots
         // still far from their end): frame pairs
@@ -1099,7 +1099,8 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
 #define SK_FAST_CASE(K, T, F, E, I)                                                                                        \
   case K: if (E && rampk) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false, E>), grid, block, lds_bytes, stream, *args); \
           else hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false, false>), grid, block, lds_bytes, stream, *args); break;  \
-  case 16 + K: hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, true>), grid, block, lds_bytes, stream, *args); break;
+  case 16 + K: if (E && rampk) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, true, E>), grid, block, lds_bytes, stream, *args); \
+               else hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, true, false>), grid, block, lds_bytes, stream, *args); break;
   switch (key) {
     SK_FAST_CASE(0, false, false, false, 0) SK_FAST_CASE(1, false, false, false, 1)
     SK_FAST_CASE(2, false, false, true, 0)  SK_FAST_CASE(3, false, false, true, 1)

@@ -490,8 +490,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
   if (STOPS && (xf & XF_NOISE)) { rng = rng * LCG_A + LCG_C; white_ = (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f; }
 /* block paths: the oscillator sample S of this frame, or -- a noise lane -- the frame's shared draw (synth.c:543-546); the
    wave advances the LCG once per frame it renders, in frame order, as SK_FAST_DRAW does on the frame paths */
-#define SK_FAST_BLOCK_SAMPLE(S)                                                                          \
-  ((STOPS && (xf & XF_NOISE)) ? (rng = rng * LCG_A + LCG_C, (r.noise ? (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f : (S))) : (S))
+/* NOISE_ is a compile-time constant: a test of xf per frame splits the block into eight scheduling regions (measured: 4-7 % on
+   every extended bank), so waves with noise lanes get their own copy of the (non-pipelined) block loops instead */
+#define SK_FAST_BLOCK_SAMPLE(S, NOISE_)                                                                  \
+  ((STOPS && (NOISE_)) ? (rng = rng * LCG_A + LCG_C, (r.noise ? (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f : (S))) : (S))
 #define SK_FAST_FRAME(J, STEADY_, XN, XO, YN, YO, SWAPPED_)                                              \
   {                                                                                                      \
     float l, rr;                                                                                         \
@@ -506,16 +508,17 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // Both oscillator halves run first (the phase recurrence does not depend on the samples): the two table reads are
 // in flight together and the second frame's read latency hides behind the first frame's biquad / gain chain -- a
 // small bank has one wave per SIMD and nothing else to hide it behind.
-#define SK_FAST_PAIR_STEADY(J, TAME_) /* TAME_ loops run only when no live lane is muted: no output select */ \
+#define SK_FAST_PAIR_STEADY_(J, TAME_, NOISE_) /* TAME_ loops run only when no live lane is muted: no output select */ \
   {                                                                                                      \
     float l0, r0, l1, r1;                                                                                \
     const float sa_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
     const float sb_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
-    fast_post_v<FILTER, ENV, false, STOPS, true>(r, pk, SK_FAST_BLOCK_SAMPLE(sa_), xx, yy, l0, r0, xf);     \
-    fast_post_v<FILTER, ENV, false, STOPS, false>(r, pk, SK_FAST_BLOCK_SAMPLE(sb_), xx, yy, l1, r1, xf);    \
+    fast_post_v<FILTER, ENV, false, STOPS, true>(r, pk, SK_FAST_BLOCK_SAMPLE(sa_, NOISE_), xx, yy, l0, r0, xf); \
+    fast_post_v<FILTER, ENV, false, STOPS, false>(r, pk, SK_FAST_BLOCK_SAMPLE(sb_, NOISE_), xx, yy, l1, r1, xf); \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
+#define SK_FAST_PAIR_STEADY(J, TAME_) SK_FAST_PAIR_STEADY_(J, TAME_, false)
 // Eight steady frames (J..J+7) of a tame wave of an LDS-table bank with the cross-lane sum through LDS instead of
 // the VALU.  Every lane folds its (L,R) of a frame into one float (fold_lr: L pair sums in lanes 0..31, R pair sums in
 // lanes 32..63) and parks it in the wave-private tile xt[8 frames][SK_XT]: one ds_write_b32 per frame.  Then lane
@@ -556,24 +559,24 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_OSC8(DST)                                                                                \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                       \
     DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));
-#define SK_FAST_POST8_(SRC, STALL_, RAMP_)                                                                      \
+#define SK_FAST_POST8_(SRC, STALL_, RAMP_, NOISE_)                                                                      \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
     float f0_, f1_;                                                                                      \
     if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
       float s0_, s1_, u_;                                                                                \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_]), xx, yy, s0_, u_, xf, &ev_);         \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1]), xx, yy, s1_, u_, xf, &ev_);    \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_], NOISE_), xx, yy, s0_, u_, xf, &ev_);         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1], NOISE_), xx, yy, s1_, u_, xf, &ev_);    \
       fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
     } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
       float l0_, r0_, l1_, r1_;                                                                          \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_]), xx, yy, l0_, r0_, xf, &ev_);               \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1]), xx, yy, l1_, r1_, xf, &ev_);          \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_], NOISE_), xx, yy, l0_, r0_, xf, &ev_);               \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1], NOISE_), xx, yy, l1_, r1_, xf, &ev_);          \
       f0_ = fold_lr(l0_, r0_); f1_ = fold_lr(l1_, r1_);                                                  \
     }                                                                                                    \
     xt[q_ * SK_XT + lane] = f0_;                                                                         \
     xt[(q_ + 1) * SK_XT + lane] = f1_;                                                                   \
   }
-#define SK_FAST_POST8(SRC, STALL_) SK_FAST_POST8_(SRC, STALL_, false)
+#define SK_FAST_POST8(SRC, STALL_) SK_FAST_POST8_(SRC, STALL_, false, false)
 /* the two strands written frame pair by frame pair, the way they should issue: oscillator of the NEXT block, chains of this one */
 #define SK_FAST_OSC_POST8(DST, SRC, STALL_)                                                               \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
@@ -582,13 +585,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     DST[q_ + 1] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));         \
     if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
       float s0_, s1_, u_;                                                                                \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_]), xx, yy, s0_, u_, xf);         \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1]), xx, yy, s1_, u_, xf);    \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SRC[q_], xx, yy, s0_, u_, xf);         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf);    \
       fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
     } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
       float l0_, r0_, l1_, r1_;                                                                          \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_]), xx, yy, l0_, r0_, xf);               \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1]), xx, yy, l1_, r1_, xf);          \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf);               \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1_, r1_, xf);          \
       f0_ = fold_lr(l0_, r0_); f1_ = fold_lr(l1_, r1_);                                                  \
     }                                                                                                    \
     xt[q_ * SK_XT + lane] = f0_;                                                                         \
@@ -708,24 +711,24 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     pend_j = (J);                                                                                        \
   }
 // eight steady frames of a tame wave of a global-table bank through the table window
-#define SK_FAST_WIN_BLOCK_(J, STALL_, RAMP_)                                                                  \
+#define SK_FAST_WIN_BLOCK_(J, STALL_, RAMP_, NOISE_)                                                                  \
   {                                                                                                      \
     FastWin w_;                                                                                          \
     fast_win_fill(r, dead, w_, win, lane, glb_tab);                                                      \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s0_), xx, yy, l0, r0, xf, &ev_);                       \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s0_, NOISE_), xx, yy, l0, r0, xf, &ev_);                       \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); SK_FAST_REPACK() } \
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s1_), xx, yy, l1, r1, xf, &ev_);                       \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s1_, NOISE_), xx, yy, l1, r1, xf, &ev_);                       \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); SK_FAST_REPACK() } \
       xt[q_ * SK_XT + lane] = fold_lr(l0, r0);     /* (global-table banks: the tile has its own LDS behind the windows) */ \
       xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                     \
     }                                                                                                    \
     SK_FAST_TILE_REDUCE(J)                                                                               \
   }
-#define SK_FAST_WIN_BLOCK(J, STALL_) SK_FAST_WIN_BLOCK_(J, STALL_, false)
+#define SK_FAST_WIN_BLOCK(J, STALL_) SK_FAST_WIN_BLOCK_(J, STALL_, false, false)
 // after an EVEN frame the newest delay-line entries sit in x2 / y2 (roles swapped), after an ODD one in x1 / y1
 #define SK_FAST_EVEN(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x1, r.x2, r.y1, r.y2, true)
 #define SK_FAST_ODD(J, STEADY_) SK_FAST_FRAME(J, STEADY_, r.x2, r.x1, r.y2, r.y1, false)
@@ -956,16 +959,27 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         // still far from their end): frame pairs
         int j = 0;
         SK_FAST_PACK_IN()
-        if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
-        for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
+        if (xf & XF_NOISE) {          // a wave with noise lanes: its own copy of the block loop (see SK_FAST_BLOCK_SAMPLE)
+          if (fast_smoother_stalled<ENV>(r)) { for (; j + 8 <= cn; j += 8) { float s_[8]; SK_FAST_OSC8(s_) SK_FAST_POST8_(s_, true, false, true) SK_FAST_TILE_REDUCE(j) } }
+          else { for (; j + 8 <= cn; j += 8) { float s_[8]; SK_FAST_OSC8(s_) SK_FAST_POST8_(s_, false, false, true) SK_FAST_TILE_REDUCE(j) } }
+          for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY_(j, true, true)
+        } else {
+          if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
+          for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
+        }
         SK_FAST_PACK_OUT()
         if (j < cn) { SK_FAST_EVEN(j, true) SK_FAST_FIX_ODD_TAIL() }
       } else if (STOPS && (!ENV || steady)) {
         int j = 0;
         if (!TAB_LDS && tame && !any_fm && !stems_on) {   // a voice about to finish is `direct` in its window block; the block checks per frame
           SK_FAST_PACK_IN()
-          if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
-          else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
+          if (xf & XF_NOISE) {
+            if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK_(j, true, false, true)
+            else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK_(j, false, false, true)
+          } else {
+            if (fast_smoother_stalled<ENV>(r)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, true)
+            else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
+          }
           SK_FAST_PACK_OUT()
         } else if (fm_only && !stems_on) {
           int pend_j = -1;
@@ -1007,14 +1021,11 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         int j = 0;
         SK_FAST_PACK_IN()
         if (TAB_LDS) {
-          for (; j + 8 <= cn; j += 8) {
-            float s_[8];
-            SK_FAST_OSC8(s_)
-            SK_FAST_POST8_(s_, false, true)
-            SK_FAST_TILE_REDUCE(j)
-          }
+          if (STOPS && (xf & XF_NOISE)) { for (; j + 8 <= cn; j += 8) { float s_[8]; SK_FAST_OSC8(s_) SK_FAST_POST8_(s_, false, true, true) SK_FAST_TILE_REDUCE(j) } }
+          else { for (; j + 8 <= cn; j += 8) { float s_[8]; SK_FAST_OSC8(s_) SK_FAST_POST8_(s_, false, true, false) SK_FAST_TILE_REDUCE(j) } }
         } else {
-          for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK_(j, false, true)
+          if (STOPS && (xf & XF_NOISE)) for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK_(j, false, true, true)
+          else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK_(j, false, true, false)
         }
         SK_FAST_PACK_OUT()
         r.tf = ramp_tf; r.trf = ramp_trf;

@@ -513,8 +513,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     float l0, r0, l1, r1;                                                                                \
     const float sa_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
     const float sb_ = fast_fetch<TAB_LDS, INTERP, TAME_>(lds_tab, glb_tab, r, fast_advance<TAME_>(r));    \
-    fast_post_v<FILTER, ENV, false, STOPS, true>(r, pk, SK_FAST_BLOCK_SAMPLE(sa_, NOISE_), xx, yy, l0, r0, xf); \
-    fast_post_v<FILTER, ENV, false, STOPS, false>(r, pk, SK_FAST_BLOCK_SAMPLE(sb_, NOISE_), xx, yy, l1, r1, xf); \
+    fast_post_v<FILTER, ENV, false, STOPS, true>(r, pk, SK_FAST_BLOCK_SAMPLE(sa_, NOISE_), xx, yy, l0, r0, xf_blk); \
+    fast_post_v<FILTER, ENV, false, STOPS, false>(r, pk, SK_FAST_BLOCK_SAMPLE(sb_, NOISE_), xx, yy, l1, r1, xf_blk); \
     if (!(TAME_)) { l0 = silent ? 0.0f : l0; r0 = silent ? 0.0f : r0; l1 = silent ? 0.0f : l1; r1 = silent ? 0.0f : r1; } \
     SK_REDUCE4_AND_STORE(J)                                                                              \
   }
@@ -564,13 +564,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     float f0_, f1_;                                                                                      \
     if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
       float s0_, s1_, u_;                                                                                \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_], NOISE_), xx, yy, s0_, u_, xf, &ev_);         \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1], NOISE_), xx, yy, s1_, u_, xf, &ev_);    \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_], NOISE_), xx, yy, s0_, u_, xf_blk, &ev_);         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1], NOISE_), xx, yy, s1_, u_, xf_blk, &ev_);    \
       fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
     } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
       float l0_, r0_, l1_, r1_;                                                                          \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_], NOISE_), xx, yy, l0_, r0_, xf, &ev_);               \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1], NOISE_), xx, yy, l1_, r1_, xf, &ev_);          \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_], NOISE_), xx, yy, l0_, r0_, xf_blk, &ev_);               \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1], NOISE_), xx, yy, l1_, r1_, xf_blk, &ev_);          \
       f0_ = fold_lr(l0_, r0_); f1_ = fold_lr(l1_, r1_);                                                  \
     }                                                                                                    \
     xt[q_ * SK_XT + lane] = f0_;                                                                         \
@@ -585,13 +585,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     DST[q_ + 1] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));         \
     if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
       float s0_, s1_, u_;                                                                                \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SRC[q_], xx, yy, s0_, u_, xf);         \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf);    \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SRC[q_], xx, yy, s0_, u_, xf_blk);         \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf_blk);    \
       fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
     } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
       float l0_, r0_, l1_, r1_;                                                                          \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf);               \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1_, r1_, xf);          \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf_blk);               \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false>(r, pk, SRC[q_ + 1], xx, yy, l1_, r1_, xf_blk);          \
       f0_ = fold_lr(l0_, r0_); f1_ = fold_lr(l1_, r1_);                                                  \
     }                                                                                                    \
     xt[q_ * SK_XT + lane] = f0_;                                                                         \
@@ -718,10 +718,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float l0, r0, l1, r1;                                                                              \
       const float s0_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s0_, NOISE_), xx, yy, l0, r0, xf, &ev_);                       \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s0_, NOISE_), xx, yy, l0, r0, xf_blk, &ev_);                       \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, true, false, misc_xy); SK_FAST_REPACK() } \
       const float s1_ = fast_fetch_win<INTERP, STOPS>(r, w_, win, lane, glb_tab, fast_advance<true, STOPS>(r)); \
-      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s1_, NOISE_), xx, yy, l1, r1, xf, &ev_);                       \
+      fast_post_v<FILTER, ENV, STALL_, STOPS, false, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(s1_, NOISE_), xx, yy, l1, r1, xf_blk, &ev_);                       \
       if (STOPS && __any(r.fin)) { SK_FAST_PACK_OUT() fast_finish(a, r, v, dead, silent, sample_final, false, c0 + (J) + q_ + 1 == a.num_frames - 1, misc_xy); SK_FAST_REPACK() } \
       xt[q_ * SK_XT + lane] = fold_lr(l0, r0);     /* (global-table banks: the tile has its own LDS behind the windows) */ \
       xt[(q_ + 1) * SK_XT + lane] = fold_lr(l1, r1);                                                     \
@@ -924,6 +924,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       // a stopping voice that cannot reach its table end within this chunk (forward, unmodulated: phase + 64*inc,
       // rounding included, stays below it) needs no per-frame finish test yet
       const bool stop_near = STOPS && any_stop && __any(r.stop && !(r.phase + (float)SK_CHUNK * r.inc + 2.0f < r.hi));
+      const int xf_blk = xf;                          // the feature mask the block paths test per frame (shadowed by a literal 0
+      (void)xf_blk;                                   //  where a wave has nothing to test: one scheduling region per block)
       FastEnv ev_;                                    // (RAMPK) envelopes in motion on the block paths; per chunk
       ev_.clk = ev_.base = ev_.A = ev_.B = ev_.C = ev_.clk2 = ev_.base2 = ev_.A2 = ev_.B2 = ev_.C2 = 0.0f;
       ev_.den = ev_.rinv = ev_.den2 = ev_.rinv2 = 1.0f; ev_.bnd = 0.0f;
@@ -963,7 +965,11 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
           if (fast_smoother_stalled<ENV>(r)) { for (; j + 8 <= cn; j += 8) { float s_[8]; SK_FAST_OSC8(s_) SK_FAST_POST8_(s_, true, false, true) SK_FAST_TILE_REDUCE(j) } }
           else { for (; j + 8 <= cn; j += 8) { float s_[8]; SK_FAST_OSC8(s_) SK_FAST_POST8_(s_, false, false, true) SK_FAST_TILE_REDUCE(j) } }
           for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY_(j, true, true)
-        } else {
+        } else if (xf & (XF_HOLDQ | XF_NOSMOOTH)) {
+          if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
+          for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
+        } else {                      // only per-lane filter / envelope flags, or one-shots far from their end: nothing to test per frame
+          const int xf_blk = 0;
           if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
           for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
         }

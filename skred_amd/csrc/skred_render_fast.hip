@@ -944,7 +944,12 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         r.trf = released ? (float)d_off : 0.0f;
         // sustain is absorbing within a launch: the clock only grows and note-off arrives between launches
         const float tf_first = (float)(d_on + 1);
-        steady = __all(dead || !r.use_env || ((r.rw & SKR_ENV_ACTIVE) && !released && !(tf_first < r.attdec)));
+        // ... and so is an envelope that is not running (never triggered, or its release has run out: is_active == 0, e = 0,
+        // synth.c:400-401): a constant gain of amp * (0 * velocity) until a control action -- notes END all the time in a live
+        // bank, and their waves must come back to the steady blocks
+        const bool idle = r.use_env && !(r.rw & SKR_ENV_ACTIVE);
+        if (idle && !dead) r.gain_sustain = r.amp * (0.0f * r.vel);
+        steady = __all(dead || !r.use_env || idle || (!released && !(tf_first < r.attdec)));
         if (RAMPK) moved = moved || !steady;
         // envelopes in motion: can the chunk's 8-frame blocks keep the straight-line form (fast_env_span2)?
         if (RAMPK && !steady && exact && tame && !stems_on && cn >= 8 && (!STOPS || (!any_fm && !stop_near))) {

@@ -774,7 +774,9 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
       // a voice that has just reached its constant level still moves its amp smoother for a few hundred frames, and ONE
       // such lane keeps its whole wave off the stalled-smoother blocks: a few of them go with the moving voices until they
       // rest (many of them -- a bank right after its upload -- stay: the wave then runs its smoothers for all lanes anyway)
-      if (__popcll(__ballot(settling[0])) + __popcll(__ballot(settling[1])) <= SK_FAST2_MAX_SETTLING) {
+      // (never in a launch that runs WITHOUT the envelope kernel: "no envelope moves" may have been reported by the one-voice
+      // kernel, which does not look at smoothers -- a settling voice then simply stays here, in a wave that runs its smoothers)
+      if (!a.skip_env2 && __popcll(__ballot(settling[0])) + __popcll(__ballot(settling[1])) <= SK_FAST2_MAX_SETTLING) {
         moving[0] = moving[0] || settling[0];
         moving[1] = moving[1] || settling[1];
       }

@@ -343,6 +343,8 @@ def test_mid_size_bank_changes_kernels_with_its_state(dev):
     e = bank["voice_amp_envelope"]                      # everyone long in sustain except a few fresh notes
     e["sample_start"][:] = g.synth_sample_count - 48000
     e["sample_start"][::997] = g.synth_sample_count - 100
+    bank["voice_smoother_smoothing"][::997] = np.float32(0.002)   # their amp smoothers are still settling when the envelopes rest:
+    # the one-voice kernel's report ("no envelope moved") must not make the two-per-lane kernel drop them
     db = dev.DeviceBank(n)
     db.set_tables(tables)
     db.upload(bank)

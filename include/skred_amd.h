@@ -160,6 +160,9 @@ int  skred_amd_abi_version(void);
 int  skred_amd_device_count(void);                 /* <=0: no usable GPU */
 const char *skred_amd_last_error(void);            /* thread-local text of the last failure */
 
+/* The largest bank a GPU holds: voice and list indices inside the kernels are 32-bit (a bank of this size takes 3.2 GB of
+ * HBM); skred_bank_create() refuses more with SKRED_E_RANGE before it touches the device. */
+#define SKRED_MAX_VOICES (1 << 24)
 int  skred_bank_create(int device, int n_voices, skred_bank_t **out);
 void skred_bank_destroy(skred_bank_t *bank);
 int  skred_bank_n_voices(const skred_bank_t *bank);
@@ -208,10 +211,6 @@ int  skred_bank_master(skred_bank_t *bank, const float *d_sum, int num_frames,
  * both forms add the rows in the same fixed order).  `d_out` as for skred_bank_master.  Asynchronous. */
 int  skred_bank_render_mix(skred_bank_t *bank, int num_frames, int interp, float *d_out, int num_channels,
                            float *d_stems_or_null, void *stream);
-
-/* Kept for callers of the earlier two-stream form (SKRED_OPT_OVERLAP_TAIL): a block is one launch now, `d_out` is
- * complete when the launch is; this call does nothing. */
-int  skred_bank_wait_mix(skred_bank_t *bank, void *stream);
 
 /* Whole synth() contract on host buffers: render + master + D2H (+ stems). Synchronous. */
 int  skred_bank_render_host(skred_bank_t *bank, float *buffer, int num_frames,
@@ -307,8 +306,6 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
        SKRED_OPT_KERNEL_TIMING = 4 /* n: an event pair brackets the render kernels of every n-th launch (default 1: every
                                       launch; 0: none).  skred_bank_last_render_ms / _timing_summary report the bracketed
                                       launches; an event pair costs ~6 us of stream time on an MI355X, hence the knob */,
-       SKRED_OPT_OVERLAP_TAIL = 3 /* accepted and ignored (the block's mix-down and master stage run inside the render
-                                     kernel: there is no tail left to overlap) */,
        SKRED_OPT_FM2_MIN_VOICES = 5 /* bank size from which a two-operator FM bank (every carrier an even voice, frequency-
                                        modulated by the voice after it and by nothing else) keeps carrier and modulator in
                                        one lane of the two-voices-per-lane kernel */ };

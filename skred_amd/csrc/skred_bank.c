@@ -98,6 +98,11 @@ static int bank_build(skred_bank_t *b) {
 int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   if (!out || n_voices <= 0) return fail(SKRED_E_BAD_ARG, "skred_bank_create: bad arguments");
   *out = NULL;
+  /* voice, slice and list indices inside the kernels are 32-bit ints (scaled by up to 128 before they are widened): the
+   * documented ceiling keeps every such product below 2^31 with room to spare; tests/test_gpu_parity.py renders a bank of
+   * exactly this size */
+  if (n_voices > SKRED_MAX_VOICES)
+    return fail(SKRED_E_RANGE, "skred_bank_create: %d voices exceed SKRED_MAX_VOICES (%d)", n_voices, SKRED_MAX_VOICES);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(SKRED_E_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
@@ -270,7 +275,6 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
     case SKRED_OPT_FAST2_MIN_VOICES: b->fast2_min_voices = value; b->fast2_min_user = 1; return SKRED_OK;
     case SKRED_OPT_FM2_MIN_VOICES: b->fm2_min_voices = value; return SKRED_OK;
     case SKRED_OPT_KERNEL_TIMING: b->timing_every = value < 0 ? 0 : value; return SKRED_OK;
-    case SKRED_OPT_OVERLAP_TAIL: return SKRED_OK;   /* accepted and ignored: a block is one launch, there is no tail to overlap */
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
 }
@@ -318,7 +322,7 @@ int skred_bank_set_globals(skred_bank_t *b, const skred_globals_t *g) {
   if (!b || !g) return fail(SKRED_E_BAD_ARG, "set_globals");
   HIP_TRY(hipSetDevice(b->device));
   /* the carried master gain lives on the device and a block's tail may still be writing it (on the caller's
-   * non-blocking stream, or on the bank's tail stream under SKRED_OPT_OVERLAP_TAIL): wait for the device first */
+   * non-blocking stream): wait for the device first */
   HIP_TRY(hipDeviceSynchronize());
   b->g = *g;
   b->gains_frames = 0;                /* gains prepared for a pending skred_bank_master no longer hold */
@@ -448,7 +452,9 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   a.tickets = b->d_tickets;
   a.vol_target = b->g.volume_final;
   a.vol_k = b->g.volume_smoother_smoothing;
-  if (getenv("SKRED_DEBUG_NO_FINISH")) { a.finish = 0; a.wg_shift = 0; b->gains_frames = 0; }   /* timing experiments only: the block's output is then garbage */
+#ifdef SK_ABLATE_FINISH   /* timing experiments only (tools/ab_libs.sh builds such a library under _ab/): the block's output is then garbage */
+  a.finish = 0; a.wg_shift = 0; b->gains_frames = 0;
+#endif
 
   const int tslot = b->n_timed % SK_TIMING_RING;
   /* two-per-lane banks with envelopes: sk_render_fast2_kernel hands groups with envelopes in motion to
@@ -511,14 +517,6 @@ int skred_bank_render_mix(skred_bank_t *b, int num_frames, int interp, float *d_
                           float *d_stems, void *stream) {
   if (!b || !d_out || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "render_mix: bad arguments");
   return render_block(b, num_frames, interp, d_stems, NULL, d_out, num_channels, (hipStream_t)stream);
-}
-
-/* (since the mix-down moved into the render kernel a block has no tail left to overlap: kept for callers of the
- * earlier form, nothing to wait for) */
-int skred_bank_wait_mix(skred_bank_t *b, void *stream) {
-  (void)stream;
-  if (!b) return fail(SKRED_E_BAD_ARG, "wait_mix");
-  return SKRED_OK;
 }
 
 int skred_bank_master(skred_bank_t *b, const float *d_sum, int num_frames, int num_channels, float *d_out, void *stream) {

@@ -458,6 +458,8 @@ int skred_bank_run_queue(skred_bank_t *b, int frame_count, void *stream) {
     const int n = skred_seq_tick(b->seq, frame_count, b->seq_rate > 0.0f ? b->seq_rate : 44100.0f, fired, SKRED_PATTERNS_MAX);
     if (n < 0) return n;
     for (int i = 0; i < n; i++) {
+      /* a step switched on through the bank's clock itself (skred_seq_step_set on skred_bank_seq()) holds no batch: a rest */
+      if (!b->pat) { applied++; continue; }
       const sk_pat_step_t *st = &b->pat[(size_t)(fired[i] >> 16) * SKRED_SEQ_STEPS_MAX + (fired[i] & 0xFFFF)];
       if (st->n > 0) {
         const int rc = apply_batch(b, st->rec, st->meta, st->n, (hipStream_t)stream);

@@ -104,6 +104,9 @@ int skred_fxbank_set_tables_i16(skred_fxbank_t *fx, const int16_t *pool, size_t 
 }
 
 static uint32_t recip32(uint32_t x) { return x ? (uint32_t)(0x100000000ull / x) : 0u; }
+/* the fields the biquad and the one-shots brought (filter_mode .. y2): a caller that zero-initialises the struct and leaves
+ * them NULL gets what it got before they existed -- no filter, no one-shot, a delay line at rest */
+#define FX_OPT(arr, v) ((arr) ? (arr)[v] : 0)
 
 int skred_fxbank_upload(skred_fxbank_t *fx, const skred_fxpt_bank_t *h, int src_first, int dst_first, int count) {
   if (!fx || !h || count < 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx upload: bad arguments");
@@ -127,11 +130,11 @@ int skred_fxbank_upload(skred_fxbank_t *fx, const skred_fxpt_bank_t *h, int src_
     if (h->use_envelope[v]) flags |= SKXF_USE_ENV;
     if (h->smoother_enable[v]) flags |= SKXF_SMOOTH;
     if (h->disconnect[v]) flags |= SKXF_MUTED;
-    if (h->filter_mode[v]) { flags |= SKXF_FILTER; fx->n_filter++; }
-    if (h->one_shot[v]) flags |= SKXF_ONE_SHOT;
+    if (FX_OPT(h->filter_mode, v)) { flags |= SKXF_FILTER; fx->n_filter++; }
+    if (FX_OPT(h->one_shot, v)) flags |= SKXF_ONE_SHOT;
     {
       const int64_t lim = (int64_t)1 << 29;      /* the delay line the definition can produce: |x|, |y| < 2^29 */
-      const int32_t d[4] = { h->x1[v], h->x2[v], h->y1[v], h->y2[v] };
+      const int32_t d[4] = { FX_OPT(h->x1, v), FX_OPT(h->x2, v), FX_OPT(h->y1, v), FX_OPT(h->y2, v) };
       for (int k = 0; k < 4; k++)
         if (d[k] < -lim || d[k] >= lim) { free(st); return skred_amd_set_error(SKRED_E_RANGE, "fx voice %d: filter state %d outside +-2^29", v, d[k]); }
     }
@@ -146,13 +149,13 @@ int skred_fxbank_upload(skred_fxbank_t *fx, const skred_fxpt_bank_t *h, int src_
     P(SKX_RECIP).w[2] = recip32(h->release_frames[v]);
     P(SKX_TIME).w[0] = (uint32_t)h->sample_start[v]; P(SKX_TIME).w[1] = (uint32_t)(h->sample_start[v] >> 32);
     P(SKX_TIME).w[2] = (uint32_t)h->sample_release[v]; P(SKX_TIME).w[3] = (uint32_t)(h->sample_release[v] >> 32);
-    P(SKX_FILT).w[0] = (uint32_t)h->b0_q30[v]; P(SKX_FILT).w[1] = (uint32_t)h->b1_q30[v];
-    P(SKX_FILT).w[2] = (uint32_t)h->b2_q30[v]; P(SKX_FILT).w[3] = (uint32_t)h->a1_q30[v];
-    P(SKX_FILT2).w[0] = (uint32_t)h->a2_q30[v];
+    P(SKX_FILT).w[0] = (uint32_t)FX_OPT(h->b0_q30, v); P(SKX_FILT).w[1] = (uint32_t)FX_OPT(h->b1_q30, v);
+    P(SKX_FILT).w[2] = (uint32_t)FX_OPT(h->b2_q30, v); P(SKX_FILT).w[3] = (uint32_t)FX_OPT(h->a1_q30, v);
+    P(SKX_FILT2).w[0] = (uint32_t)FX_OPT(h->a2_q30, v);
     P(SKX_COUNT).w[0] = h->phase[v]; P(SKX_COUNT).w[1] = (uint32_t)h->smoother_gain_q15[v];
-    P(SKX_COUNT).w[2] = (uint32_t)h->voice_sample[v]; P(SKX_COUNT).w[3] = (h->is_active[v] ? 1u : 0u) | (h->finished[v] ? 2u : 0u);
-    P(SKX_COUNT + 1).w[0] = (uint32_t)h->x1[v]; P(SKX_COUNT + 1).w[1] = (uint32_t)h->x2[v];
-    P(SKX_COUNT + 1).w[2] = (uint32_t)h->y1[v]; P(SKX_COUNT + 1).w[3] = (uint32_t)h->y2[v];
+    P(SKX_COUNT).w[2] = (uint32_t)h->voice_sample[v]; P(SKX_COUNT).w[3] = (h->is_active[v] ? 1u : 0u) | (FX_OPT(h->finished, v) ? 2u : 0u);
+    P(SKX_COUNT + 1).w[0] = (uint32_t)FX_OPT(h->x1, v); P(SKX_COUNT + 1).w[1] = (uint32_t)FX_OPT(h->x2, v);
+    P(SKX_COUNT + 1).w[2] = (uint32_t)FX_OPT(h->y1, v); P(SKX_COUNT + 1).w[3] = (uint32_t)FX_OPT(h->y2, v);
 #undef P
   }
   const size_t bytes = (size_t)count * sizeof(skx_plane_t);
@@ -186,8 +189,11 @@ int skred_fxbank_download(skred_fxbank_t *fx, skred_fxpt_bank_t *h, int src_firs
     h->smoother_gain_q15[v] = (int32_t)st[i].w[1];
     h->voice_sample[v] = (int32_t)st[i].w[2];
     h->is_active[v] = (int32_t)(st[i].w[3] & 1u);
-    h->finished[v] = (int32_t)((st[i].w[3] >> 1) & 1u);
-    h->x1[v] = (int32_t)f->w[0]; h->x2[v] = (int32_t)f->w[1]; h->y1[v] = (int32_t)f->w[2]; h->y2[v] = (int32_t)f->w[3];
+    if (h->finished) h->finished[v] = (int32_t)((st[i].w[3] >> 1) & 1u);
+    if (h->x1) h->x1[v] = (int32_t)f->w[0];
+    if (h->x2) h->x2[v] = (int32_t)f->w[1];
+    if (h->y1) h->y1[v] = (int32_t)f->w[2];
+    if (h->y2) h->y2[v] = (int32_t)f->w[3];
   }
   free(st);
   return SKRED_OK;

@@ -231,6 +231,7 @@ int skred_shard_render_mix(skred_shard_t *s, int num_frames, int interp, float *
   int rc = s->ops.render(s->ops.ctx, num_frames, interp, partial, stream);
   if (rc) return rc;
   if (s->world > 1 || s->always_reduce) {
+    if (!s->ops.reduce) return fail(SKRED_E_BAD_ARG, "shard_render_mix: a reduce step is required (always_reduce) but none was given");
     rc = s->ops.reduce(s->ops.reduce_ctx, partial, (size_t)num_frames * 2, s->root, stream);
     if (rc) return rc;
   }

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "skred_bank_create", "skred_bank_destroy", "skred_bank_n_voices",
     "skred_bank_set_tables_f32", "skred_bank_upload", "skred_bank_download",
     "skred_bank_set_globals", "skred_bank_get_globals",
-    "skred_bank_render", "skred_bank_master", "skred_bank_render_mix", "skred_bank_wait_mix", "skred_bank_render_host",
+    "skred_bank_render", "skred_bank_master", "skred_bank_render_mix", "skred_bank_render_host",
     "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
     "skred_bank_set_option", "skred_bank_last_kernel", "skred_bank_env_latch_misses",
     "skred_bank_update", "skred_bank_defer", "skred_bank_run_queue", "skred_bank_queue_pending",
@@ -80,7 +80,6 @@ def load() -> C.CDLL:
     L.skred_bank_render.argtypes = [vp, i32, i32, vp, vp, vp]
     L.skred_bank_master.argtypes = [vp, vp, i32, i32, vp, vp]
     L.skred_bank_render_mix.argtypes = [vp, i32, i32, vp, i32, vp, vp]
-    L.skred_bank_wait_mix.argtypes = [vp, vp]
     L.skred_bank_render_host.argtypes = [vp, vp, i32, i32, i32, vp]
     L.skred_bank_last_render_ms.argtypes = [vp]
     L.skred_bank_last_render_ms.restype = C.c_float
@@ -189,16 +188,9 @@ class DeviceBank:
         _check(self.L.skred_bank_render_mix(self.h, frames, interp, d_out, channels, d_stems, stream),
                "skred_bank_render_mix")
 
-    def overlap_tail(self, on: bool = True):
-        """SKRED_OPT_OVERLAP_TAIL: accepted and ignored (a block is one launch; nothing is left to overlap)."""
-        _check(self.L.skred_bank_set_option(self.h, 3, 1 if on else 0), "skred_bank_set_option")
-
     def kernel_timing(self, every: int = 1):
         """SKRED_OPT_KERNEL_TIMING: event pair around the render kernels of every n-th launch (0: never)."""
         _check(self.L.skred_bank_set_option(self.h, 4, int(every)), "skred_bank_set_option")
-
-    def wait_mix(self, stream: int = 0):
-        _check(self.L.skred_bank_wait_mix(self.h, stream), "skred_bank_wait_mix")
 
     def master(self, d_sum: int, frames: int, d_out: int, channels: int = 2, stream: int = 0):
         _check(self.L.skred_bank_master(self.h, d_sum, frames, channels, d_out, stream or None), "skred_bank_master")

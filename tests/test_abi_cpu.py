@@ -50,3 +50,47 @@ def test_struct_sizes_match_header():
     assert MMF_DTYPE.itemsize == 48 and ENV_DTYPE.itemsize == 56      # synth-types.h:13-38
     assert C.sizeof(GlobalsC) == 32
     assert C.sizeof(VoiceBankC) == 8 + 8 * len(FIELDS)
+
+
+def test_bank_size_ceiling_is_enforced_before_the_device():
+    """SKRED_MAX_VOICES (include/skred_amd.h): voice and list indices inside the kernels are 32-bit; a bank above the
+    documented ceiling is refused with SKRED_E_RANGE, GPU or not (the GPU suite renders a bank of exactly the ceiling)."""
+    text = open(os.path.join(ROOT, "include", "skred_amd.h")).read()
+    m = re.search(r"#define\s+SKRED_MAX_VOICES\s+\(1\s*<<\s*(\d+)\)", text)
+    assert m, "SKRED_MAX_VOICES missing from the header"
+    ceiling = 1 << int(m.group(1))
+    L = device.load()
+    h = C.c_void_p()
+    for n in (ceiling + 1, 2**31 - 1):
+        assert L.skred_bank_create(0, n, C.byref(h)) == -4            # SKRED_E_RANGE
+        assert b"SKRED_MAX_VOICES" in L.skred_amd_last_error()
+        assert not h.value
+    assert L.skred_bank_create(0, 0, C.byref(h)) == -2                # SKRED_E_BAD_ARG
+
+
+def test_shard_reduce_step_must_exist_when_it_is_required():
+    """A one-rank shard made without a reduce step and then told to always reduce must fail, not call a NULL pointer."""
+    L = device.load()
+    vp, i32 = C.c_void_p, C.c_int
+
+    class Ops(C.Structure):
+        _fields_ = [("ctx", vp), ("render", vp), ("master", vp), ("reduce_ctx", vp), ("reduce", vp)]
+
+    RENDER = C.CFUNCTYPE(i32, vp, i32, i32, vp, vp)
+    MASTER = C.CFUNCTYPE(i32, vp, vp, i32, i32, vp, vp)
+    render = RENDER(lambda ctx, f, interp, partial, stream: 0)
+    master = MASTER(lambda ctx, s, f, ch, out, stream: 0)
+    ops = Ops(None, C.cast(render, vp), C.cast(master, vp), None, None)
+    L.skred_shard_create_custom.argtypes = [i32, i32, i32, i32, C.POINTER(Ops), C.POINTER(vp)]
+    L.skred_shard_set_ops.argtypes = [vp, C.POINTER(Ops), i32]
+    L.skred_shard_render_mix.argtypes = [vp, i32, i32, vp, vp, i32, vp]
+    L.skred_shard_destroy.argtypes = [vp]
+    L.skred_shard_destroy.restype = None
+    sh = vp()
+    assert L.skred_shard_create_custom(0, 1, 0, 64, C.byref(ops), C.byref(sh)) == 0
+    assert L.skred_shard_set_ops(sh, None, 1) == 0
+    buf = (C.c_float * 128)()
+    assert L.skred_shard_render_mix(sh, 64, 0, buf, buf, 2, None) == -2   # SKRED_E_BAD_ARG
+    assert L.skred_shard_set_ops(sh, None, 0) == 0
+    assert L.skred_shard_render_mix(sh, 64, 0, buf, buf, 2, None) == 0
+    L.skred_shard_destroy(sh)

@@ -200,25 +200,27 @@ def test_fused_mix_equals_render_plus_master(dev):
         assert gio.bits_equal(outs[0], outs[1]), (n, frames)
 
 
-def test_overlapped_tail_gives_the_same_blocks(dev):
-    """Six consecutive asynchronous blocks, each into its own buffer, with and without SKRED_OPT_OVERLAP_TAIL (an option
-    of the earlier two-stream form, still accepted: a block is one launch now): same bytes, same state."""
+def test_async_blocks_into_separate_buffers(dev):
+    """Six consecutive asynchronous blocks, each into its own buffer, nothing synchronised in between, against the same
+    six blocks rendered one by one through the synchronous host form: same bytes, same state (a block's mix-down happens
+    inside its launch; the next launch re-uses the rows, the tickets and the gain slot)."""
     import torch
     n, frames, blocks = 70000, 300, 6
     bank, tables, g = banks.bank_c2(n)
     res = []
-    for overlap in (False, True):
+    for asynchronous in (False, True):
         db = dev.DeviceBank(n)
         db.set_tables(tables)
         db.upload(bank)
         db.set_globals(g)
-        db.overlap_tail(overlap)
-        outs = [torch.zeros(frames, 2, device="cuda") for _ in range(blocks)]
-        for o in outs:
-            db.render_mix(frames, o.data_ptr(), 2)
-        db.wait_mix(0)
-        torch.cuda.synchronize()
-        res.append(np.concatenate([o.cpu().numpy() for o in outs]))
+        if asynchronous:
+            outs = [torch.zeros(frames, 2, device="cuda") for _ in range(blocks)]
+            for o in outs:
+                db.render_mix(frames, o.data_ptr(), 2)
+            torch.cuda.synchronize()
+            res.append(np.concatenate([o.cpu().numpy() for o in outs]))
+        else:
+            res.append(np.concatenate([db.render_host(frames)[0] for _ in range(blocks)]))
         got = bank.copy()
         db.download(got)
         res.append(got)

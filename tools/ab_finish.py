@@ -1,3 +1,6 @@
+# cost of the in-kernel mix-down: run once with the in-tree library and once with a library built with
+#   make -C skred_amd/csrc OBJ=_obj_nofin OUT=../../_ab/nofinish/libskred_amd.so EXTRA=-DSK_ABLATE_FINISH
+# (tools/ab_libs.sh ab_finish.py nofinish ...): that build skips sk_finish_block, its output is garbage
 import sys, time, os
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -16,7 +19,7 @@ def run(name, rec, n, interp=0, F=512, steps=100, min2=None):
         for _ in range(steps): db.render_mix(F, out.data_ptr(), 2, 0, interp)
         torch.cuda.synchronize()
         res.append((time.perf_counter() - t0) / steps * 1e3)
-    print(f"{name:40s} kernel={db.last_kernel()} ms/block min {min(res):.4f} med {sorted(res)[1]:.4f}  NO_FINISH={os.environ.get('SKRED_DEBUG_NO_FINISH','')}", flush=True)
+    print(f"{name:40s} kernel={db.last_kernel()} ms/block min {min(res):.4f} med {sorted(res)[1]:.4f}  lib={os.environ.get('SKRED_AMD_LIB','in-tree')}", flush=True)
     db.close()
 run("c1 4096", "c1", 4096)
 run("c2 65536", "c2", 65536)

@@ -53,7 +53,6 @@ def run(name, bank, tables, g, interp=0, F=512, steps=60, min2=None, generic=Fal
         for _ in range(steps):
             db.render_mix(F, out.data_ptr(), 2, 0, interp)
         t1 = time.perf_counter()
-        db.wait_mix(0)
         torch.cuda.synchronize()
         d_ = (time.perf_counter() - t0) / steps
         if best is None or d_ < best[0]:
@@ -173,8 +172,7 @@ def live():
                     db.update(bank, vs[:k // 2], D.STAMP_RELEASE)
                     db.update(bank, vs[k // 2:], D.STAMP_TRIGGER | D.DIRTY_PHASE | D.DIRTY_PARAMS)
                 db.render_mix(F, out.data_ptr(), 2)
-            db.wait_mix(0)
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 60
         print(f"{frac * 100:.2f} % of the voices get a note-off / note-on per block: {dt * 1e3:.3f} ms/block  "
               f"{n * F / dt:.3e} voice-samples/s")

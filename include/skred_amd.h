@@ -188,8 +188,9 @@ int  skred_bank_get_globals(skred_bank_t *bank, skred_globals_t *g);
 /*
  * Render `num_frames` frames of every voice (the two nested loops of
  * synth.c:520-613) and leave this GPU's PRE-master-volume stereo sum in
- * `d_partial` (device pointer, float[num_frames][2]): one kernel launch (plus
- * the envelope kernel of the two-voices-per-lane path while notes ramp).  `d_stems` (device,
+ * `d_partial` (device pointer, float[num_frames][2]): one kernel launch (plus,
+ * while notes ramp on the two-voices-per-lane path, the envelope kernel beside it on
+ * a stream of the bank's own, joined back into `stream` before the call returns).  `d_stems` (device,
  * float[num_frames][n_voices][2], the `user` buffer layout of synth.c:533-534,
  * 607-611) may be NULL.  Advances synth_sample_count and the noise LCG.
  * `stream` is a hipStream_t (NULL = default stream).  Asynchronous.
@@ -313,11 +314,13 @@ enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED =
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */
 
-/* Self-check of the "no envelope in motion" latch of the two-voices-per-lane path ("Envelopes in motion"):
- * the number of launches that skipped sk_render_env2_kernel although a voice turned out to need it.  Must
- * stay 0; a non-zero value means a voice left a constant envelope level without a control action reaching the bank
- * (skred_amd_last_error() names the launch), after which the latch is re-armed by itself. */
-unsigned skred_bank_env_latch_misses(const skred_bank_t *bank);
+/* Cross-check of the motion list of the two-voices-per-lane path ("The motion list"): voices whose envelope may be
+ * in motion are kept on a per-voice list ON THE DEVICE (every control action lists the voices it touches, the envelope kernel
+ * keeps its voices listed until they rest) and rendered by the envelope kernel beside the steady kernel, which never has to be
+ * told by the host whether anything moves.  The steady kernel still classifies every voice it renders; this is the number of
+ * voices it ever found in motion without being listed, as far as reported (asynchronously).  0 by construction; should it move,
+ * the list is rebuilt from the voice state by itself and skred_amd_last_error() names the launch. */
+unsigned skred_bank_list_violations(const skred_bank_t *bank);
 
 /* ---- voices sharded over the GPUs of one node (BASELINE config 3) -----------------------------------
  *

@@ -74,20 +74,31 @@ static int bank_build(skred_bank_t *b) {
   memset(b->h_mod, -1, (size_t)b->n_padded * 4);
   HIP_TRY(hipMalloc((void **)&b->d_level, (size_t)b->n_padded * sizeof(int)));
   HIP_TRY(hipMemset(b->d_level, 0, (size_t)b->n_padded * sizeof(int)));
-  /* one hand-over flag per 128-voice wave slice of the two-per-lane kernels, plus the ticket slot */
+  /* per 128-voice wave slice of the two-per-lane kernels: listed voices; one more slot: the one-voice family's ticket */
   HIP_TRY(hipMalloc((void **)&b->d_group_flag, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
   HIP_TRY(hipMemset(b->d_group_flag, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
   HIP_TRY(hipMalloc((void **)&b->d_env_list, (size_t)b->n_groups * SK_GROUP * sizeof(int32_t)));
   HIP_TRY(hipMemset(b->d_env_list, 0, (size_t)b->n_groups * SK_GROUP * sizeof(int32_t)));
   HIP_TRY(hipMalloc((void **)&b->d_env_off, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
   HIP_TRY(hipMemset(b->d_env_off, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
-  HIP_TRY(hipMalloc((void **)&b->d_move_mask, (size_t)b->n_groups * 4 * sizeof(uint64_t)));
-  HIP_TRY(hipMemset(b->d_move_mask, 0, (size_t)b->n_groups * 4 * sizeof(uint64_t)));
+  /* the motion list, double-buffered (a bit per voice), and the violation counter behind it: one allocation */
+  {
+    const size_t words = (size_t)b->n_groups * 4;
+    HIP_TRY(hipMalloc((void **)&b->d_mask[0], (2 * words + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(b->d_mask[0], 0, (2 * words + 1) * sizeof(uint64_t)));
+    b->d_mask[1] = b->d_mask[0] + words;
+    b->d_violations = (uint32_t *)(b->d_mask[0] + 2 * words);
+    b->mask_dirty = 1;
+  }
+  HIP_TRY(hipStreamCreateWithPriority(&b->side, hipStreamNonBlocking, -1));   /* (the envelope kernel's few workgroups should not queue behind a full machine) */
+  HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
   HIP_TRY(hipMalloc((void **)&b->d_gain_state, 4 * sizeof(float)));
   HIP_TRY(hipMemset(b->d_gain_state, 0, 4 * sizeof(float)));
   /* arrival tickets of the in-kernel mix-down: zero once, every last arriver re-arms its own */
-  HIP_TRY(hipMalloc((void **)&b->d_tickets, (SK_FINISH_SLABS + 1) * sizeof(uint32_t)));
-  HIP_TRY(hipMemset(b->d_tickets, 0, (SK_FINISH_SLABS + 1) * sizeof(uint32_t)));
+  /* slabs, final, the envelope kernel's own; behind them one "an envelope moved" word per workgroup row (one-voice family) */
+  HIP_TRY(hipMalloc((void **)&b->d_tickets, (SK_FINISH_SLABS + 2 + SK_MAX_WORKGROUPS) * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(b->d_tickets, 0, (SK_FINISH_SLABS + 2 + SK_MAX_WORKGROUPS) * sizeof(uint32_t)));
   for (int i = 0; i < SK_TIMING_RING; i++) {
     HIP_TRY(hipEventCreate(&b->ev0[i]));
     HIP_TRY(hipEventCreate(&b->ev1[i]));
@@ -150,13 +161,15 @@ void skred_bank_destroy(skred_bank_t *b) {
     if (b->upd[i].ev) hipEventDestroy(b->upd[i].ev);
   }
   free(b->upd_mark);
-  if (b->h_quiet) hipHostFree(b->h_quiet);
-  for (int i = 0; i < SK_QUIET_RING; i++) if (b->quiet_ev[i]) hipEventDestroy(b->quiet_ev[i]);
+  if (b->h_report) hipHostFree((void *)b->h_report);
   if (b->d_level) hipFree(b->d_level);
   if (b->d_group_flag) hipFree(b->d_group_flag);
   if (b->d_env_list) hipFree(b->d_env_list);
   if (b->d_env_off) hipFree(b->d_env_off);
-  if (b->d_move_mask) hipFree(b->d_move_mask);
+  if (b->d_mask[0]) hipFree(b->d_mask[0]);
+  if (b->side) hipStreamDestroy(b->side);
+  if (b->ev_fork) hipEventDestroy(b->ev_fork);
+  if (b->ev_join) hipEventDestroy(b->ev_join);
   for (int i = 0; i < SK_TIMING_RING; i++) {
     if (b->ev0[i]) hipEventDestroy(b->ev0[i]);
     if (b->ev1[i]) hipEventDestroy(b->ev1[i]);
@@ -212,9 +225,10 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
   free(st);
   if (e != hipSuccess) { free(meta); HIP_TRY(e); }
   if (dst_first == 0 && count == b->n_voices) b->features = 0;                /* whole bank replaced */
-  for (int i = 0; i < count; i++) sk_apply_meta(b, dst_first + i, &meta[i], 1, 1);
+  for (int i = 0; i < count; i++) sk_apply_meta(b, dst_first + i, &meta[i], 1);
   free(meta);
   sk_control_changed(b);
+  b->mask_dirty = 1;                    /* the motion list is rebuilt from the planes before the next two-per-lane block */
   return SKRED_OK;
 }
 
@@ -223,16 +237,8 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
  * noise, modulated, smoother off, non-finite phase data), and the biquad / the envelope are each used
  * by all of them or by none.  Anything else runs the generic kernel; both give identical samples. */
 static int classify(skred_bank_t *b) {
-  if (b->cnt_future > 0 && b->g.synth_sample_count >= b->future_horizon) {
-    /* the clock has passed every note-on / note-off that was written ahead of it: those voices are ordinary again */
-    for (int v = 0; v < b->n_padded; v++) b->h_class[v] &= (uint16_t)~SKC_FUTURE;
-    b->cnt_future = 0;
-    b->class_dirty = 1;
-  }
   if (!b->class_dirty) return SKRED_OK;
-  /* a voice whose envelope clock lies ahead of the bank's changes stage on its own in mid-launch (SKC_FUTURE): only
-   * the generic kernel, which evaluates the stage per frame from the integer clocks, renders that */
-  const int real = b->cnt_real, filt = b->cnt_filter, env = b->cnt_env, exotic = b->cnt_exotic + b->cnt_future;
+  const int real = b->cnt_real, filt = b->cnt_filter, env = b->cnt_env, exotic = b->cnt_exotic;
   uint32_t m = 0;
   if (real > 0 && !exotic) {
     m = SKM_FAST;
@@ -280,7 +286,7 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
 }
 
 int skred_bank_last_kernel(const skred_bank_t *b) { return b ? b->last_kernel : -1; }
-unsigned skred_bank_env_latch_misses(const skred_bank_t *b) { return b ? b->quiet_misses : 0u; }
+unsigned skred_bank_list_violations(const skred_bank_t *b) { return b ? b->violations_seen : 0u; }
 
 int skred_bank_download(skred_bank_t *b, skred_voice_bank_t *h, int src_first, int dst_first, int count) {
   if (!b || !h || count < 0) return fail(SKRED_E_BAD_ARG, "download: bad arguments");
@@ -328,6 +334,7 @@ int skred_bank_set_globals(skred_bank_t *b, const skred_globals_t *g) {
   b->gains_frames = 0;                /* gains prepared for a pending skred_bank_master no longer hold */
   HIP_TRY(hipMemcpy(b->d_gain_state, &g->volume_smoother_gain, sizeof(float), hipMemcpyHostToDevice));
   sk_control_changed(b);              /* the clock may have moved: envelope stages are a function of it */
+  b->mask_dirty = 1;
   return SKRED_OK;
 }
 
@@ -342,27 +349,50 @@ int skred_bank_get_globals(skred_bank_t *b, skred_globals_t *g) {
 
 /* ------------------------------------------------------------------ render */
 
-/* Did the launch whose result sits in quiet ring slot `i` flag any group for sk_render_env2_kernel? */
-static void poll_env_quiet(skred_bank_t *b) {
-  while (b->quiet_pending > 0) {
-    const int i = b->quiet_tail % SK_QUIET_RING;
-    if (hipEventQuery(b->quiet_ev[i]) != hipSuccess) return;         /* that launch has not finished yet */
-    /* the kernel stores its launch ticket into the slot when it defers a group: an older ticket = none deferred;
-     * the answer only holds if no control action reached the bank since that launch was issued */
-    const int deferred = b->h_quiet[i] == b->quiet_ticket[i];
-    if (!deferred && b->quiet_epoch[i] == b->control_epoch) b->env_quiet = 1;
-    if (deferred) b->env_quiet = 0;
-    if (deferred && b->quiet_skipped[i]) {
-      /* self-check: a launch that ran WITHOUT sk_render_env2_kernel had a slice with an envelope in motion -- the
-       * premise of the latch ("stages only move towards a constant level between control actions") was violated.
-       * Re-arm at once and say so; that block's slice was silent. */
-      b->env_quiet = 0;
-      b->quiet_misses++;
-      (void)fail(SKRED_E_UNSUPPORTED, "launch %u skipped the envelope kernel but a slice had an envelope in motion", b->quiet_ticket[i]);
+/* What earlier launches found, as far as their answers have arrived (never waits): the block's final arriver stores
+ * (launch ticket << 32 | finding) into two pinned host words (skred_kernel_common.hpp: sk_final_cols). */
+static void poll_reports(skred_bank_t *b) {
+  if (!b->h_report) return;
+  const uint64_t w0 = __atomic_load_n(&b->h_report[0], __ATOMIC_RELAXED), w1 = __atomic_load_n(&b->h_report[1], __ATOMIC_RELAXED);
+  const uint32_t t0 = (uint32_t)(w0 >> 32);
+  if (t0 != 0 && t0 != b->report_seen && t0 == (uint32_t)(w1 >> 32)) {     /* a new report, both words of the same launch */
+    b->report_seen = t0;
+    const int slot = (int)(t0 % SK_REPORT_RING);
+    if (b->report_ticket[slot] == t0) {                                    /* (else: asked so long ago that its slot was re-used) */
+      const int fresh = b->report_epoch[slot] == b->control_epoch;         /* no control action reached the bank since it was issued */
+      const uint32_t found = (uint32_t)w0;
+      if (b->report_kind[slot] == 1) {
+        /* one-voice family: did an envelope move in that launch */
+        if (!found && fresh) b->env_quiet = 1;
+        if (found) b->env_quiet = 0;
+      } else {
+        /* two-per-lane family: the length of the list that block rendered.  Empty, and nothing added since: every later list is
+         * empty too (a list is the survivors of the one before plus what control actions add) -- a structural fact, not an
+         * inference about envelopes.  And the cross-check counter of sk_render_fast2_kernel: should it ever move, rebuild. */
+        if (b->report_kind[slot] == 2 && found == 0 && fresh) b->list_empty = 1;
+        if ((uint32_t)w1 != b->violations_seen) {
+          b->violations_seen = (uint32_t)w1;
+          b->mask_dirty = 1;
+          b->list_empty = 0;
+          (void)fail(SKRED_E_UNSUPPORTED, "launch %u or one before it rendered a voice at a constant level whose envelope was in motion (not on the motion list): list rebuilt", t0);
+        }
+      }
     }
-    b->quiet_tail++;
-    b->quiet_pending--;
   }
+}
+
+/* this launch will report: remember what its ticket means (kind 1: one-voice "moved"; 2: list length; 3: violations only) */
+static int expect_report(skred_bank_t *b, sk_render_args_t *a, int kind) {
+  if (!b->h_report) {
+    HIP_TRY(hipHostMalloc((void **)&b->h_report, 2 * sizeof(uint64_t), hipHostMallocDefault));
+    b->h_report[0] = b->h_report[1] = 0;
+  }
+  const int slot = (int)(a->launch_ticket % SK_REPORT_RING);
+  b->report_ticket[slot] = a->launch_ticket;
+  b->report_epoch[slot] = b->control_epoch;
+  b->report_kind[slot] = (uint8_t)kind;
+  a->report = (unsigned long long *)b->h_report;
+  return SKRED_OK;
 }
 
 /* One block: picks and launches the render kernel(s), whose last-arriving workgroups also add the per-workgroup rows
@@ -378,6 +408,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   HIP_TRY(hipSetDevice(b->device));
   int rc = classify(b);
   if (rc) return rc;
+  poll_reports(b);
   /* the modulated kernel serves every kind of modulation; banks whose only modulation is previous-frame FM stay on
    * the one-per-lane kernel when they are otherwise clean */
   const int fast_ok = (b->fast_mode & SKM_FAST) && !b->force_generic;
@@ -393,7 +424,9 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   a.group_flag = b->d_group_flag;
   a.env_list = b->d_env_list;
   a.env_off = b->d_env_off;
-  a.move_mask = b->d_move_mask;
+  a.mask_cur = b->d_mask[b->mask_p];
+  a.mask_next = b->d_mask[b->mask_p ^ 1];
+  a.violations = b->d_violations;
   a.count0 = b->g.synth_sample_count;
   a.rng0 = b->g.noise_rng;
   a.n_voices = b->n_voices;
@@ -410,10 +443,9 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   if ((a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_STOPS | SKM_FM)) && b->n_voices >= b->fast2_min_voices &&
       (a.lds_table_floats > 0 || b->fast2_min_user) && !d_stems)      /* (per-voice stems: the one-voice kernel writes them) */
     a.fast_mode |= SKM_TWO_PER_LANE;        /* (voices that finish mid-launch are handled by the one-per-lane kernel only) */
-  /* ... but while envelopes move (no launch has reported a quiet bank since the last control action) the one-voice kernel's
-   * block form of them beats the two-per-lane kernel + envelope kernel on banks up to ~400 000 voices (tools/ab_env_mid.py:
-   * 262 144 voices 184 vs 213 us per block, 393 216 voices 256 vs 267, 524 288 voices 327 vs 279): such banks change kernels
-   * with their state (both read and write the same planes) */
+  /* ... but while envelopes move the one-voice kernel's block form of them beats the two-per-lane kernel + envelope kernel on
+   * mid-size banks (tools/ab_env_mid.py): such banks change kernels with their state (both families read and write the same
+   * planes).  "Envelopes move": from a control action until a one-voice launch has reported that none did -- a speed hint. */
   if ((a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL) && !(a.fast_mode & SKM_MIXED) && !b->env_quiet &&
       !b->fast2_min_user && b->n_voices < SK_FAST2_MOTION_MIN_VOICES)
     a.fast_mode &= ~SKM_TWO_PER_LANE;
@@ -425,18 +457,46 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     a.fast_mode &= ~(SKM_FM_PAIR | SKM_PAIR_AP);
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
+  if (modulated) b->last_kernel = SKRED_KERNEL_MODULATED;
   if (!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) {
     /* passes of sk_render_fast2_kernel: 1024 voices each for LDS-table banks, 512 otherwise (skred_render_fast2.hip) */
     const int passes = a.lds_table_floats > 0 ? b->n_groups * 2 / SK_FAST2_NW_LDS : b->n_groups / 2;
     n_wg = passes < SK_MAX_WORKGROUPS ? passes : SK_MAX_WORKGROUPS;
   }
-  /* rows of the partial mix, the slab sums of the two-level mix-down and the per-frame master gains: one allocation */
+  /* two-per-lane banks with envelopes: the voices on the motion list are rendered by sk_render_env2_kernel BESIDE the steady
+   * kernel, on the bank's second stream (its own rows, its own ticket; skred_kernel_common.hpp: sk_finish_env) */
+  const int two_env = !modulated && (a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
+  /* one-per-lane banks with envelopes: a launch's report picks between the instantiation that also holds the block form of
+   * envelopes in motion and the lean one (skred_render_fast.hip: RAMPK); both render everything, so a stale answer costs
+   * speed, never samples */
+  const int one_env = !modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
+  if (two_env) {
+    if (b->last_family != SKRED_KERNEL_FAST2) b->mask_dirty = 1;     /* another family rendered meanwhile: it does not keep the list */
+    if (b->mask_dirty) {
+      const hipError_t ec = (hipError_t)sk_launch_classify(&a, b->d_mask[b->mask_p], s);
+      if (ec != hipSuccess) return fail(SKRED_E_NO_DEVICE, "classify launch -> %s", hipGetErrorString(ec));
+      b->mask_dirty = 0;
+      b->list_empty = 0;
+    }
+  }
+  const int env_beside = two_env && !b->list_empty;
+  const int n_env = env_beside ? sk_env2_grid(&a) : 0;
+  /* rows of the partial mix, the slab sums of the two-level mix-down, the per-frame master gains, and (when the envelope kernel
+   * runs beside) its rows and its sum: one allocation */
   const size_t row = (size_t)num_frames * 2;
-  if ((rc = grow(&b->d_partial, &b->partial_cap, ((size_t)n_wg + SK_FINISH_SLABS) * row + (size_t)num_frames))) return rc;
+  const size_t gains_at = ((size_t)n_wg + SK_FINISH_SLABS) * row;
+  const size_t env_at = (gains_at + (size_t)num_frames + 3) & ~(size_t)3;          /* 16-byte aligned */
+  if ((rc = grow(&b->d_partial, &b->partial_cap, env_at + ((size_t)n_env + 1) * row))) return rc;
   a.partial = b->d_partial;
   a.slab_rows = b->d_partial + (size_t)n_wg * row;
-  a.gains = a.slab_rows + (size_t)SK_FINISH_SLABS * row;
-  b->gains_offset = (size_t)(a.gains - b->d_partial);
+  a.gains = b->d_partial + gains_at;
+  a.env_rows = b->d_partial + env_at;
+  a.env_sum = a.env_rows + (size_t)n_env * row;
+  a.env_ticket = b->d_tickets + SK_FINISH_SLABS + 1;
+  a.moved = b->d_tickets + SK_FINISH_SLABS + 2;
+  a.n_env_rows = n_env;
+  a.env_beside = env_beside;
+  b->gains_offset = gains_at;
   a.n_rows = n_wg;
   a.finish = 1;
   /* The gain workgroup walks the master gain of every frame beside the renderers.  Single-GPU form: the last arriver applies
@@ -452,53 +512,44 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   a.tickets = b->d_tickets;
   a.vol_target = b->g.volume_final;
   a.vol_k = b->g.volume_smoother_smoothing;
-#ifdef SK_ABLATE_FINISH   /* timing experiments only (tools/ab_libs.sh builds such a library under _ab/): the block's output is then garbage */
+#ifdef SK_ABLATE_FINISH   /* timing experiments only (tools/ab_finish.py says how such a library is built): the block's output is then garbage */
   a.finish = 0; a.wg_shift = 0; b->gains_frames = 0;
 #endif
 
   const int tslot = b->n_timed % SK_TIMING_RING;
-  /* two-per-lane banks with envelopes: sk_render_fast2_kernel hands groups with envelopes in motion to
-   * sk_render_env2_kernel.  Envelope stages only move towards a constant level on their own, so once a launch
-   * has deferred no group, none will be deferred until a control action arrives: the second launch is skipped. */
-  const int two_env = !modulated && (a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
-  /* one-per-lane banks with envelopes (plain instantiation): the same report picks between the instantiation that also holds
-   * the block form of envelopes in motion and the lean one (skred_render_fast.hip: RAMPK); both render everything, so a stale
-   * answer costs speed, never samples */
-  const int one_env = !modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
-  /* (plain and extended instantiations alike; a wave with frequency-modulated carriers never takes the block form) */
-  const int env_latch = two_env || one_env;
-  if (env_latch) poll_env_quiet(b);
   a.launch_ticket = ++b->launch_ticket;
-  /* a voice whose note-on / note-off clock lies ahead of the bank's (cnt_future) can leave a constant level on its own */
-  a.skip_env2 = env_latch && b->env_quiet && b->cnt_future == 0;
+  a.skip_env2 = two_env ? (uint32_t)b->list_empty : (uint32_t)(one_env && b->env_quiet);
   const int timed = b->timing_every > 0 && (b->launch_ticket % (uint32_t)b->timing_every) == 0;
   if (timed) HIP_TRY(hipEventRecord(b->ev0[tslot], s));
   hipError_t e;
+  if (two_env && (env_beside || (a.launch_ticket & 63u) == 0)) { if ((rc = expect_report(b, &a, env_beside ? 2 : 3))) return rc; }
+  else if (one_env && (!a.skip_env2 || (a.launch_ticket & 15u) == 0)) { if ((rc = expect_report(b, &a, 1))) return rc; }
+  if (env_beside) {
+    /* the list of this block, then fork: everything queued on `s` so far (updates, the classify pass, the list) is ahead of
+     * the envelope kernel too; both render kernels become ready together */
+    e = (hipError_t)sk_launch_collect(&a, s);
+    if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "collect launch -> %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(b->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(b->side, b->ev_fork, 0));
+    e = (hipError_t)sk_launch_env_fast2(&a, b->side);
+    if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "envelope kernel launch -> %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(b->ev_join, b->side));
+  }
   if (modulated) {
-    b->last_kernel = SKRED_KERNEL_MODULATED;
     e = (hipError_t)sk_launch_render_mod(&a, n_wg, b->d_level, b->max_level, s);
   } else {
     e = (hipError_t)sk_launch_render(&a, n_wg, s);
   }
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "render launch -> %s", hipGetErrorString(e));
+  if (env_beside) {
+    HIP_TRY(hipStreamWaitEvent(s, b->ev_join, 0));                   /* join: the block is complete on `s` */
+    b->mask_p ^= 1;                                                  /* the survivors are the next block's list */
+  }
   if (timed) {
     HIP_TRY(hipEventRecord(b->ev1[tslot], s));
     b->n_timed++;
   }
-  if (env_latch && (!a.skip_env2 || (a.launch_ticket & 63u) == 0) && b->quiet_pending < SK_QUIET_RING) {
-    /* ask (asynchronously) whether this launch deferred any group; while the latch holds, every 64th launch is
-     * still asked, as a self-check of the latch's premise (poll_env_quiet) */
-    const int i = b->quiet_head % SK_QUIET_RING;
-    if (!b->h_quiet) HIP_TRY(hipHostMalloc((void **)&b->h_quiet, SK_QUIET_RING * sizeof(uint32_t), hipHostMallocDefault));
-    if (!b->quiet_ev[i]) HIP_TRY(hipEventCreateWithFlags(&b->quiet_ev[i], hipEventDisableTiming));
-    HIP_TRY(hipMemcpyAsync(&b->h_quiet[i], b->d_group_flag + b->n_groups * 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(b->quiet_ev[i], s));
-    b->quiet_ticket[i] = a.launch_ticket;
-    b->quiet_epoch[i] = b->control_epoch;
-    b->quiet_skipped[i] = (uint8_t)(two_env && a.skip_env2);   /* (only there is a skipped launch a lost slice) */
-    b->quiet_head++;
-    b->quiet_pending++;
-  }
+  b->last_family = b->last_kernel;
 
   /* advance the timeline exactly as synth.c:521,525 do: one count and one LCG draw per frame */
   b->g.synth_sample_count += (uint64_t)num_frames;

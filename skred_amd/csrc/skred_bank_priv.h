@@ -15,7 +15,7 @@
 #include "skred_launch.h"
 
 #define SK_TIMING_RING 256
-#define SK_QUIET_RING 8
+#define SK_REPORT_RING 64
 #define SK_UPD_RING 8
 
 typedef struct {
@@ -49,18 +49,28 @@ struct skred_bank {
   int8_t *h_mod;              /* [4][n_padded] modulator lane inside the 64-voice group (fm, am, pm, cz) or -1 */
   int *h_level;               /* [n_padded] dependency level of each voice (modulated banks) */
   int *d_level;
-  int32_t *d_env_list;        /* the voices handed to sk_render_env2_kernel, in ascending order (sk_expand_moving_kernel) */
+  int32_t *d_env_list;        /* the voices on the motion list, in ascending order (sk_collect_expand_kernel) */
   int32_t *d_env_off;         /* per 128-voice wave slice: where its voices start in d_env_list; one more slot: their number */
-  uint64_t *d_move_mask;      /* per slice, two lane masks: which of its voices were handed over */
-  int32_t *d_group_flag;      /* per 128-voice wave slice: voices handed over; one more slot: the ticket */
+  int32_t *d_group_flag;      /* per 128-voice wave slice: listed voices; one more slot: the one-voice family's "an envelope moved" ticket */
+  /* THE MOTION LIST of the two-per-lane family (skred_device_layout.h: mask_cur): a bit per voice, double-buffered -- the
+   * block reads d_mask[mask_p] and builds d_mask[mask_p ^ 1] (survivors), control actions OR into d_mask[mask_p] */
+  uint64_t *d_mask[2];
+  int mask_p;
+  int mask_dirty;             /* the list must be rebuilt from the planes before the next two-per-lane block (upload, clock change,
+                                 a stretch on another kernel family, a violation report) */
+  int list_empty;             /* STRUCTURAL: the last list the device built was empty and nothing was added since (no control action);
+                                 the envelope kernel is then not launched -- with an empty list it has nothing to render */
+  uint32_t *d_violations;     /* sticky device counter: sk_render_fast2_kernel found a moving voice that was not listed */
+  uint32_t violations_seen;   /* ... as last read back */
+  hipStream_t side;           /* the envelope kernel's stream, beside the caller's */
+  hipEvent_t ev_fork, ev_join;
+  int last_family;            /* SKRED_KERNEL_* of the previous block (the list is only maintained while the two-per-lane family renders) */
   int max_level;
   int class_dirty;
   int cnt_real, cnt_filter, cnt_env, cnt_exotic, cnt_stops, cnt_fm;   /* voices per SKC_* bit (kept incrementally) */
   int cnt_pair_ap;            /* pair-shaped carriers whose amplitude or pan is modulated too (SKC_PAIR_AP) */
   int cnt_fm_odd;             /* SKC_FM voices that are not the even half of a (carrier, next voice) pair (SKC_FM_ODD) */
   int cnt_escapes;            /* voices naming a modulator outside their aligned 64-voice group (SKC_ESCAPES) */
-  uint64_t future_horizon;    /* the latest such clock value: once the bank's clock reaches it, no voice is "future" any more */
-  int cnt_future;             /* enveloped voices whose note-on / note-off clock lay ahead of the bank's when they were written (SKC_FUTURE) */
   int mod_dirty;              /* modulator lanes changed: dependency levels must be recomputed */
   uint32_t fast_mode;         /* SKM_* from classify() */
   int force_generic;          /* SKRED_OPT_FORCE_GENERIC */
@@ -72,16 +82,16 @@ struct skred_bank {
   uint32_t features;
   hipEvent_t ev0[SK_TIMING_RING], ev1[SK_TIMING_RING]; /* around the render kernel of each call */
   int n_timed;                /* render calls since the last timing reset */
-  /* "no group has an envelope in motion" (see render_rows): asynchronous read-back ring of the kernel's answer */
+  /* what a launch found, reported by its final arriver into two pinned host words (no copy, no event): one-voice family --
+   * "did an envelope move" (picks the lean instantiation: a speed hint); two-per-lane family -- the length of the list it
+   * rendered, and the violation counter */
   uint32_t launch_ticket;     /* one per render launch */
   uint32_t control_epoch;     /* bumped by every upload / update / globals change */
-  int env_quiet;              /* the last answered launch deferred no group and nothing changed since */
-  uint32_t *h_quiet;          /* pinned: SK_QUIET_RING tickets read back from d_group_flag[n_groups*2] */
-  hipEvent_t quiet_ev[SK_QUIET_RING];
-  uint32_t quiet_ticket[SK_QUIET_RING], quiet_epoch[SK_QUIET_RING];
-  uint8_t quiet_skipped[SK_QUIET_RING];   /* that launch ran with skip_env2 (a deferral it reports was NOT rendered) */
-  int quiet_head, quiet_tail, quiet_pending;
-  uint32_t quiet_misses;      /* launches that ran without sk_render_env2_kernel although a slice needed it (self-check; must stay 0) */
+  int env_quiet;              /* one-voice family: the last answered launch saw no envelope move and nothing changed since */
+  volatile uint64_t *h_report;            /* pinned: [0] ticket << 32 | finding, [1] ticket << 32 | violations */
+  uint32_t report_seen;                   /* ticket of the last report taken */
+  uint32_t report_ticket[SK_REPORT_RING], report_epoch[SK_REPORT_RING];   /* what the launches that will report were issued under */
+  uint8_t report_kind[SK_REPORT_RING];
   skred_seq_t *seq;             /* the pattern step clock (skred_seq.c), created on first use */
   struct sk_pat_step *pat;      /* [SKRED_PATTERNS_MAX][SKRED_SEQ_STEPS_MAX] batches the steps apply (skred_bank_update.c) */
   float seq_rate;               /* sample rate the step clock counts blocks in (0: the reference's 44100) */
@@ -100,9 +110,6 @@ struct skred_bank {
 #define SKC_EXOTIC 8u   /* needs the generic kernel: see classify() */
 #define SKC_FM    32u   /* carrier of a higher-indexed modulator of its 64-voice group, nothing else modulated */
 #define SKC_STOPS 16u   /* one-shot without loop (plays to its table end and finishes) or reverse playback: the one-per-lane kernel's extended instantiation */
-#define SKC_FUTURE 64u  /* uses the envelope and its sample_start / sample_release lay AHEAD of the bank's clock when written: its stage
-                           is not monotone (the unsigned clock difference wraps to "sustain" until the clock catches up, synth.c:401),
-                           so "no envelope in motion" may not be latched while such a voice exists */
 #define SKC_FM_ODD 256u /* an SKC_FM voice that is anything but: even index, frequency-modulated by the voice after it and by nothing else
                           -- the shape sk_render_fast2_kernel<FMP> renders with carrier and modulator in one lane */
 #define SKC_PAIR_AP 512u /* a pair-shaped carrier whose amplitude or pan is modulated (by the voice after it or by itself) */
@@ -123,20 +130,19 @@ int skred_amd_set_error(int code, const char *fmt, ...);
  * written.  phase_known: the host's voice_phase is the voice's current phase (an upload); 0 when only
  * parameters are being pushed and the phase lives on the device. */
 typedef struct {
-  uint16_t cls;         /* SKC_* (SKC_FUTURE as the HOST's envelope clocks say: only applied when those clocks travel) */
+  uint16_t cls;         /* SKC_* */
   int8_t mod_lane[4];   /* modulator lane inside the 64-voice group (fm, am, pan, cz) or -1 */
   uint32_t features;    /* SKB_* this voice needs */
-  uint64_t future_until;/* SKC_FUTURE: the later of the voice's two envelope clocks */
 } sk_voice_meta_t;
 
 int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int dst, int phase_known,
                   sk_plane_t ro[SKP_COUNT], sk_plane_t rw[SKS_COUNT], sk_voice_meta_t *meta);
-/* clock_travels: the voice's sample_start / sample_release were written too (upload, SKRED_DIRTY_ENV_CLOCK), so SKC_FUTURE
- * follows the host's values; otherwise the bit the voice had is kept.  params_travel: everything else of `meta` applies. */
-void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *meta, int params_travel, int clock_travels);
+/* params_travel: the parameter planes were written, so `meta` applies (a pure clock / state update leaves the classes alone) */
+void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *meta, int params_travel);
 void sk_queue_free(skred_bank_t *b);
 void sk_patterns_free(skred_bank_t *b);
-/* a control action reached the bank: what earlier launches reported about envelope activity no longer holds */
-static inline void sk_control_changed(skred_bank_t *b) { b->control_epoch++; b->env_quiet = 0; }
+/* a control action reached the bank: what earlier launches reported about envelope activity no longer holds (the voices it
+ * touched went on the motion list on the device: skred_update_kernels.hip) */
+static inline void sk_control_changed(skred_bank_t *b) { b->control_epoch++; b->env_quiet = 0; b->list_empty = 0; }
 
 #endif

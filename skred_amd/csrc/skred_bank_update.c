@@ -99,16 +99,6 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
       if (fm_only && !pair) c |= SKC_FM_ODD;
       if (fm_only && pair && (ao >= 0 || po >= 0)) c |= SKC_PAIR_AP;
     }
-    {
-      /* a note-on or note-off stamped AHEAD of the clock (a host scheduling a note by writing sample_start itself): until
-       * the clock catches up the reference reads the wrapped difference as a huge elapsed time (synth.c:401,422) */
-      const skred_envelope_t *e = &h->voice_amp_envelope[v];
-      const uint64_t now = b->g.synth_sample_count;
-      if (h->voice_use_amp_envelope[v] && (e->sample_start > now || e->sample_release > now)) {
-        c |= SKC_FUTURE;
-        meta->future_until = e->sample_start > e->sample_release ? e->sample_start : e->sample_release;
-      }
-    }
     meta->cls = c;
   }
   meta->features = features;
@@ -162,22 +152,18 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
 }
 
 /* what voice `dst` now means for kernel selection (counters instead of a scan: a bank has up to millions of voices) */
-void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m, int params_travel, int clock_travels) {
-  const uint16_t old = b->h_class[dst];
-  uint16_t now = params_travel ? (uint16_t)(m->cls & ~SKC_FUTURE) : (uint16_t)(old & ~SKC_FUTURE);
-  now |= clock_travels ? (m->cls & SKC_FUTURE) : (old & SKC_FUTURE);
+void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m, int params_travel) {
+  if (!params_travel) return;
+  const uint16_t old = b->h_class[dst], now = m->cls;
   if (old != now) {
     if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; if (old & SKC_STOPS) b->cnt_stops--; if (old & SKC_FM) b->cnt_fm--; if (old & SKC_FM_ODD) b->cnt_fm_odd--; if (old & SKC_PAIR_AP) b->cnt_pair_ap--; }
     if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; if (now & SKC_STOPS) b->cnt_stops++; if (now & SKC_FM) b->cnt_fm++; if (now & SKC_FM_ODD) b->cnt_fm_odd++; if (now & SKC_PAIR_AP) b->cnt_pair_ap++; }
     /* per-voice bits that are not kernel classes: counted whether or not the voice can sound, and recounted whenever the
      * voice is written again -- a routing that escaped its group stops blocking the bank once it is fixed */
     b->cnt_escapes += ((now & SKC_ESCAPES) != 0) - ((old & SKC_ESCAPES) != 0);
-    b->cnt_future += ((now & SKC_FUTURE) != 0) - ((old & SKC_FUTURE) != 0);
-    if (now & SKC_FUTURE) { if (m->future_until > b->future_horizon) b->future_horizon = m->future_until; }
     b->h_class[dst] = now;
     b->class_dirty = 1;
   }
-  if (!params_travel) return;
   for (int k = 0; k < 4; k++) {
     int8_t *slot = &b->h_mod[(size_t)k * b->n_padded + dst];
     if (*slot != m->mod_lane[k]) { *slot = m->mod_lane[k]; b->mod_dirty = 1; b->class_dirty = 1; }
@@ -192,7 +178,7 @@ typedef struct sk_queue_item {
   uint64_t when;
   int n;
   sk_update_t *rec;          /* device-format records */
-  sk_voice_meta_t *meta;     /* NULL unless the batch carries SKRED_DIRTY_PARAMS or SKRED_DIRTY_ENV_CLOCK */
+  sk_voice_meta_t *meta;     /* NULL unless the batch carries SKRED_DIRTY_PARAMS */
 } sk_queue_item_t;
 
 #define SK_STAMP_ONLY(d) (((d) & ~(uint32_t)(SKRED_STAMP_TRIGGER | SKRED_STAMP_RELEASE)) == 0)
@@ -233,7 +219,7 @@ static int build_batch(const skred_bank_t *b, const skred_voice_bank_t *h, const
   *meta_out = NULL;
   if ((dirty & ~(uint32_t)SKRED_DIRTY_VALID_MASK) || !dirty) return fail(SKRED_E_BAD_ARG, "update: dirty mask 0x%x", dirty);
   sk_update_t *rec = (sk_update_t *)calloc((size_t)n, sizeof(sk_update_t));
-  const int wants_meta = (dirty & (SKRED_DIRTY_PARAMS | SKRED_DIRTY_ENV_CLOCK)) != 0;
+  const int wants_meta = (dirty & SKRED_DIRTY_PARAMS) != 0;
   sk_voice_meta_t *meta = wants_meta ? (sk_voice_meta_t *)calloc((size_t)n, sizeof(sk_voice_meta_t)) : NULL;
   if (!rec || (wants_meta && !meta)) { free(rec); free(meta); return fail(SKRED_E_NO_MEM, "update staging"); }
   const int stamp_only = SK_STAMP_ONLY(dirty);        /* note-on / note-off stamps carry no values: nothing to pack */
@@ -285,6 +271,18 @@ static int staging_slot(skred_bank_t *b, size_t bytes, hipStream_t s, sk_upd_slo
   return SKRED_OK;
 }
 
+/* Where the scatter kernel reads a staged batch from.  A small batch -- the notes of one audio block -- is read straight out
+ * of the pinned host buffer (it is mapped into the device's address space): a copy engine transfer in front of a 5 us kernel
+ * cost the stream ~12 us each (the copy and the gap behind it), four times per block under note traffic.  A large batch goes
+ * through the copy engine into the slot's device twin: bandwidth matters there, not latency. */
+#define SK_UPD_ZERO_COPY_MAX (256 * 1024)
+static const void *sk_stage(sk_upd_slot_t *sl, size_t bytes, hipStream_t s) {
+  if (bytes <= SK_UPD_ZERO_COPY_MAX) return sl->h;
+  const hipError_t e = hipMemcpyAsync(sl->d, sl->h, bytes, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) { (void)fail(SKRED_E_NO_DEVICE, "update copy -> %s", hipGetErrorString(e)); return NULL; }
+  return sl->d;
+}
+
 /* push records to the device and scatter them; a voice named twice is applied in order (one launch per run
  * of distinct voices, found with a per-voice epoch mark: linear in the batch) */
 static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_meta_t *meta, int n, hipStream_t s) {
@@ -297,8 +295,9 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
     if (rc) return rc;
     int32_t *ids = (int32_t *)sl->h;
     for (int i = 0; i < n; i++) ids[i] = rec[i].voice;
-    HIP_TRY(hipMemcpyAsync(sl->d, sl->h, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    const hipError_t e = (hipError_t)sk_launch_stamp((const int32_t *)sl->d, n, dirty, b->d_ro, b->d_rw, b->g.synth_sample_count, s);
+    const void *src = sk_stage(sl, (size_t)n * sizeof(int32_t), s);
+    if (!src) return SKRED_E_NO_DEVICE;
+    const hipError_t e = (hipError_t)sk_launch_stamp((const int32_t *)src, n, dirty, b->d_ro, b->d_rw, b->g.synth_sample_count, b->d_mask[b->mask_p], s);
     HIP_TRY(hipEventRecord(sl->ev, s));
     if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "stamp launch -> %s", hipGetErrorString(e));
     sk_control_changed(b);
@@ -307,7 +306,8 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
   int rc = staging_slot(b, (size_t)n * sizeof(sk_update_t), s, &sl);
   if (rc) return rc;
   memcpy(sl->h, rec, (size_t)n * sizeof(sk_update_t));
-  HIP_TRY(hipMemcpyAsync(sl->d, sl->h, (size_t)n * sizeof(sk_update_t), hipMemcpyHostToDevice, s));
+  const sk_update_t *src = (const sk_update_t *)sk_stage(sl, (size_t)n * sizeof(sk_update_t), s);
+  if (!src) return SKRED_E_NO_DEVICE;
   if (!b->upd_mark) {
     b->upd_mark = (uint32_t *)calloc((size_t)b->n_voices, sizeof(uint32_t));
     if (!b->upd_mark) return fail(SKRED_E_NO_MEM, "update marks");
@@ -321,13 +321,13 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
       if (*m == b->upd_epoch) break;                    /* named before in this run: the next launch takes it */
       *m = b->upd_epoch;
     }
-    const hipError_t e = (hipError_t)sk_launch_update((const sk_update_t *)sl->d + start, end - start, b->d_ro, b->d_rw,
-                                                      b->g.synth_sample_count, s);
+    const hipError_t e = (hipError_t)sk_launch_update(src + start, end - start, b->d_ro, b->d_rw,
+                                                      b->g.synth_sample_count, b->d_mask[b->mask_p], s);
     if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "update launch -> %s", hipGetErrorString(e));
     start = end;
   }
   HIP_TRY(hipEventRecord(sl->ev, s));
-  if (meta) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i], (dirty & SKRED_DIRTY_PARAMS) != 0, (dirty & SKRED_DIRTY_ENV_CLOCK) != 0);
+  if (meta && (dirty & SKRED_DIRTY_PARAMS)) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i], 1);
   sk_control_changed(b);
   return SKRED_OK;
 }

@@ -127,13 +127,25 @@ typedef struct {
   const float *tables;     /* HBM pool */
   float *partial;          /* [n_workgroups][num_frames][2] pre-master partial sums */
   float *stems;            /* [num_frames][n_voices][2] or NULL */
-  int32_t *group_flag;     /* [n_groups*2]: how many voices of this 128-voice wave slice have an envelope in motion and are
-                              left to sk_render_env2_kernel (fast2 -> env2 hand-over, voice by voice);
-                              [n_groups*2] (one more): ticket of the last launch that handed any voice over */
-  uint64_t *move_mask;     /* [n_groups*2][2]: which lanes (voices slice*128 + c*64 + lane, c = 0 / 1) those are */
+  int32_t *group_flag;     /* [n_groups*2]: voices of each 128-voice wave slice on the motion list (written by sk_collect_scan_kernel) */
+  const uint64_t *mask_cur;/* [n_groups*4]: THE MOTION LIST as a bit per voice (voice v: word v >> 6, bit v & 63): voices whose
+                              envelope may be in motion during this block (attack / decay / release, a note-on ahead of the clock,
+                              a smoother still settling).  sk_render_fast2_kernel sits these voices out, sk_render_env2_kernel
+                              renders them -- beside it, on a second stream.  Carried from block to block on the device:
+                              sk_update_kernel / sk_stamp_kernel set the bit of every voice they touch, sk_classify_kernel
+                              rebuilds it after uploads and clock changes, and sk_render_env2_kernel carries its voices
+                              over into mask_next until they have come to rest.  Read-only during a block. */
+  uint64_t *mask_next;     /* the list of the NEXT block: zeroed by sk_collect_scan_kernel, survivors OR-ed in by sk_render_env2_kernel */
   int32_t *env_off;        /* [n_groups*2 + 1]: exclusive prefix sums of the counts, [n_groups*2] = their total
-                              (sk_scan_moving_kernel, between the two render kernels) */
-  int32_t *env_list;       /* [n_groups*SK_GROUP]: the handed-over voices in ascending order (sk_expand_moving_kernel) */
+                              (sk_collect_scan_kernel, ahead of sk_render_env2_kernel on its stream) */
+  int32_t *env_list;       /* [n_groups*SK_GROUP]: the listed voices in ascending order (sk_collect_expand_kernel) */
+  uint32_t *moved;         /* [n_rows] one-voice family: the ticket of the last launch in which workgroup (row) i saw an envelope move */
+  unsigned long long *report; /* [2] in pinned HOST memory, written by the block's final arriver (one writer, one 8-byte store each):
+                              (launch_ticket << 32) | what the launch found -- one-voice family: 1 when an envelope moved; two-per-lane
+                              family: [0] the length of the motion list it rendered, [1] the violation counter.  The host polls the
+                              words: no copy, no event */
+  uint32_t *violations;    /* [1] sticky: voices sk_render_fast2_kernel found with an envelope in motion that were NOT on the list
+                              (unreachable by construction; the host rebuilds the list when it ever reads non-zero) */
   uint64_t count0;         /* synth_sample_count before the first frame */
   uint64_t rng0;           /* noise LCG state before the first frame */
   int32_t n_voices;        /* real voices (stems indexing) */
@@ -145,10 +157,17 @@ typedef struct {
   uint32_t features;       /* SKB_* */
   uint32_t fast_mode;      /* SKM_* : which specialised kernel the host picked */
   uint32_t launch_ticket;  /* this launch's number (see group_flag) */
-  uint32_t skip_env2;      /* host knows no group can be deferred: sk_render_env2_kernel is not launched */
-  int32_t env_workers;     /* sk_render_env2_kernel: workgroups that take passes = what the device holds at once (the grid
-                              still has n_rows of them: the others only hand their row to the mix-down).  A grid of more
-                              rendering workgroups than fit runs in rounds, the last one mostly empty. */
+  uint32_t skip_env2;      /* two-per-lane family: the motion list is EMPTY (a structural fact: the last list the device built was
+                              empty and nothing was added since), the masks are not read and sk_render_env2_kernel is not
+                              launched.  One-voice family: a launch reported that no envelope moved (picks the lean
+                              instantiation; both render everything, so this one is a pure speed hint) */
+  /* ---- the envelope kernel beside the steady kernel (two-per-lane family): its own rows, its own arrival ticket; its last
+   * arriver adds the rows that were used into env_sum and then arrives at the block's final ticket like one more slab ---- */
+  int32_t env_beside;      /* this block has an envelope kernel: the final ticket expects one more arrival, the final sum adds env_sum */
+  int32_t n_env_rows;      /* workgroups of sk_render_env2_kernel (each strides over the list's 512-voice passes) */
+  float *env_rows;         /* [n_env_rows][num_frames][2] */
+  float *env_sum;          /* [num_frames][2] */
+  uint32_t *env_ticket;    /* [1] */
   /* ---- the block's mix-down, inside the last render kernel of the block (skred_kernel_common.hpp: sk_finish_block) ----
    * Every workgroup leaves its partial-mix row in `partial`; with `finish` set the workgroup that arrives LAST at a
    * ticket adds the rows up in a fixed order (slab by slab when there are many), writes the pre-master sum and, in

@@ -159,7 +159,62 @@ __device__ __forceinline__ V sk_add_rows(const V *__restrict__ rows, size_t ncol
   return acc;
 }
 
-// Called by EVERY workgroup of the block's last row-writing kernel, after its last store into a.partial (renderers:
+// The block's last step, run by whichever workgroup arrived last at the final ticket: the rows (or the slab sums) added up in
+// index order, plus -- when an envelope kernel ran beside this one -- its sum; then the pre-master sum and / or the frames.
+template <typename V>
+__device__ __forceinline__ void sk_final_cols(const sk_render_args_t &a, int tid, int nthreads) {
+  constexpr int PER = sizeof(V) / sizeof(float2);             // (L,R) columns per V
+  const size_t ncolv = (size_t)a.num_frames / PER;
+  const bool two_level = a.n_rows > SK_FINISH_FLAT_MAX;
+  const int n_last = two_level ? SK_FINISH_SLABS : a.n_rows;
+  const V *rows = reinterpret_cast<const V *>(two_level ? a.slab_rows : a.partial);
+  for (int c = tid; c < (int)ncolv; c += nthreads) {
+    V s = sk_add_rows<V>(rows, ncolv, c, 0, n_last, 1);
+    if (a.env_beside) sk_acc<V>(s, reinterpret_cast<const V *>(a.env_sum)[c]);
+    const float2 *h = reinterpret_cast<const float2 *>(&s);
+    if (a.sum_out) reinterpret_cast<V *>(a.sum_out)[c] = s;
+    if (a.mix_out) {                                          // synth.c:621-624
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const size_t f = (size_t)c * PER + k;
+        const float vg = a.gains[f];
+        a.mix_out[f * a.num_channels + 0] = h[k].x * vg;
+        a.mix_out[f * a.num_channels + 1] = h[k].y * vg;
+      }
+    }
+  }
+  // what this launch found, straight into the host's pinned words (skred_bank.c: poll_reports)
+  if (a.report) {
+    uint32_t w0 = 0, w1 = 0;
+    if (a.fast_mode & SKM_TWO_PER_LANE) {
+      w0 = a.env_beside ? (uint32_t)__hip_atomic_load(a.env_off + a.n_groups * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      w1 = __hip_atomic_load(a.violations, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      // one-voice family: did any workgroup see an envelope move (sk_note_moved: one word per row, written through)
+      int any = 0;
+      for (int i = tid; i < a.n_rows; i += nthreads)
+        any |= __hip_atomic_load(a.moved + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.launch_ticket;
+      w0 = __syncthreads_or(any) ? 1u : 0u;
+    }
+    if (tid == 0) {
+      const unsigned long long t = (unsigned long long)a.launch_ticket << 32;
+      __hip_atomic_store(a.report + 1, t | w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(a.report, t | w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+// one-voice family, RAMPK instantiation: this workgroup saw an envelope in motion in this launch (one word per row, written
+// through: the block's final arriver, possibly on another XCD, collects them for the host's report)
+__device__ __forceinline__ void sk_note_moved(const sk_render_args_t &a, int bid) {
+  __hip_atomic_store(a.moved + bid, a.launch_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// arrivals the final ticket waits for: the rows (or slabs), the gain workgroup, the envelope kernel's sum
+__device__ __forceinline__ uint32_t sk_final_arrivals(const sk_render_args_t &a) {
+  const int n_last = a.n_rows > SK_FINISH_FLAT_MAX ? SK_FINISH_SLABS : a.n_rows;
+  return (uint32_t)n_last + (a.wg_shift ? 1u : 0u) + (a.env_beside ? 1u : 0u);
+}
+
+// Called by EVERY workgroup of the block's steady (or only) render kernel, after its last store into a.partial (renderers:
 // bid = their row; the gain workgroup: bid < 0).  `published`: the row's final values already left as write-through
 // stores (sk_row_store in the completing pass); otherwise it is copied in place that way here.
 // `flag_lds`: one LDS word the workgroup no longer needs.
@@ -168,7 +223,6 @@ __device__ __forceinline__ void sk_finish_cols(const sk_render_args_t &a, int bi
   constexpr int PER = sizeof(V) / sizeof(float2);             // (L,R) columns per V
   const size_t ncolv = (size_t)a.num_frames / PER;
   const bool two_level = a.n_rows > SK_FINISH_FLAT_MAX;
-  const int n_last = two_level ? SK_FINISH_SLABS : a.n_rows;  // rows the last arriver adds
   V *rows = reinterpret_cast<V *>(a.partial);
   if (bid < 0) {
     if (tid == 0) {                                           // the master gain of every frame, serially as the reference does
@@ -199,32 +253,46 @@ __device__ __forceinline__ void sk_finish_cols(const sk_render_args_t &a, int bi
       }
     }
   }
-  const uint32_t arrivals = (uint32_t)n_last + (a.wg_shift ? 1u : 0u);
-  if (!sk_arrive_last(a.tickets + SK_FINISH_SLABS, arrivals, tid, flag_lds)) return;
-  if (two_level) rows = reinterpret_cast<V *>(a.slab_rows);
-  for (int c = tid; c < (int)ncolv; c += nthreads) {
-    const V s = sk_add_rows<V>(rows, ncolv, c, 0, n_last, 1);
-    const float2 *h = reinterpret_cast<const float2 *>(&s);
-    if (a.sum_out) reinterpret_cast<V *>(a.sum_out)[c] = s;
-    if (a.mix_out) {                                          // synth.c:621-624
-#pragma unroll
-      for (int k = 0; k < PER; ++k) {
-        const size_t f = (size_t)c * PER + k;
-        const float vg = a.gains[f];
-        a.mix_out[f * a.num_channels + 0] = h[k].x * vg;
-        a.mix_out[f * a.num_channels + 1] = h[k].y * vg;
-      }
-    }
-  }
+  if (!sk_arrive_last(a.tickets + SK_FINISH_SLABS, sk_final_arrivals(a), tid, flag_lds)) return;
+  sk_final_cols<V>(a, tid, nthreads);
+}
+
+// two columns per load when the rows (num_frames * 8 bytes each) and sum_out keep 16-byte alignment
+__device__ __forceinline__ bool sk_finish_wide(const sk_render_args_t &a) {
+  return (a.num_frames & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.sum_out) & 15) == 0);
 }
 
 __device__ __forceinline__ void sk_finish_block(const sk_render_args_t &a, int bid, int tid, int nthreads, int *flag_lds,
                                                 bool published = false) {
-  // two columns per load when the rows (num_frames * 8 bytes each) and sum_out keep 16-byte alignment
-  if ((a.num_frames & 1) == 0 && ((reinterpret_cast<uintptr_t>(a.sum_out) & 15) == 0))
-    sk_finish_cols<float4>(a, bid, tid, nthreads, flag_lds, published);
-  else
-    sk_finish_cols<float2>(a, bid, tid, nthreads, flag_lds, published);
+  if (sk_finish_wide(a)) sk_finish_cols<float4>(a, bid, tid, nthreads, flag_lds, published);
+  else sk_finish_cols<float2>(a, bid, tid, nthreads, flag_lds, published);
+}
+
+// The same for the envelope kernel that runs BESIDE the steady kernel (its own stream): every one of its n_env_rows
+// workgroups arrives at the kernel's own ticket -- the first `n_used` of them rendered something and have published a row
+// of a.env_rows --, the last arriver adds those rows into a.env_sum (zeros when the list was empty) and then arrives at the
+// block's final ticket like one more slab.  Whichever workgroup of either kernel is last there finishes the block.
+template <typename V>
+__device__ __forceinline__ void sk_finish_env_cols(const sk_render_args_t &a, int n_used, int tid, int nthreads, int *flag_lds) {
+  constexpr int PER = sizeof(V) / sizeof(float2);
+  const size_t ncolv = (size_t)a.num_frames / PER;
+  if (!sk_arrive_last(a.env_ticket, (uint32_t)a.n_env_rows, tid, flag_lds)) return;
+  float2 *dst = reinterpret_cast<float2 *>(a.env_sum);
+  for (int c = tid; c < (int)ncolv; c += nthreads) {
+    V s;
+    if (n_used > 0) s = sk_add_rows<V>(reinterpret_cast<const V *>(a.env_rows), ncolv, c, 0, n_used, 1);
+    else { float2 *z = reinterpret_cast<float2 *>(&s); for (int k = 0; k < PER; ++k) z[k] = make_float2(0.0f, 0.0f); }
+    const float2 *h = reinterpret_cast<const float2 *>(&s);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) sk_store_through(&dst[(size_t)c * PER + k], h[k]);
+  }
+  if (!sk_arrive_last(a.tickets + SK_FINISH_SLABS, sk_final_arrivals(a), tid, flag_lds)) return;
+  sk_final_cols<V>(a, tid, nthreads);
+}
+__device__ __forceinline__ void sk_finish_env(const sk_render_args_t &a, int n_used, int tid, int nthreads, int *flag_lds) {
+  if (sk_finish_wide(a) && (reinterpret_cast<uintptr_t>(a.env_sum) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.env_rows) & 15) == 0)
+    sk_finish_env_cols<float4>(a, n_used, tid, nthreads, flag_lds);
+  else sk_finish_env_cols<float2>(a, n_used, tid, nthreads, flag_lds);
 }
 
 // ---------------------------------------------------------------- small exact helpers
@@ -242,6 +310,51 @@ __device__ __forceinline__ float crush(float v, int bits) {
   const int levels = (1 << bits) - 1;
   const int q = (int)((double)(v * (float)levels) + 0.5);
   return (float)q * (1.0f / (float)levels);
+}
+
+// ---------------------------------------------------------------- is a voice's gain at rest?
+//
+// Which branch of amp_envelope_step (synth.c:398-431) a voice takes at envelope clocks (t, tr):
+// 0 inactive, 1 attack, 2 decay, 3 sustain (held), 4 release, 5 release finished (is_active -> 0).
+// With both clocks behind the bank's the code is monotone in time (note-off only arrives between launches), so a voice
+// whose code is the same on the first and the last frame of a span keeps it for the whole span, and codes 0 / 3 / 5
+// (constant level) are absorbing.
+__device__ __forceinline__ int sk_env_stage_code(bool active, bool released, float t, float tr, float att, float attdec, float rel) {
+  if (!active) return 0;
+  if (t < att) return 1;
+  if (t < attdec) return 2;
+  if (!released) return 3;
+  return (tr < rel) ? 4 : 5;
+}
+
+// The ONE definition of "this voice may be in motion" that the motion list of the two-per-lane family is built from
+// (sk_classify_kernel after uploads and clock changes, sk_render_env2_kernel when it decides which of its voices stay on
+// the list, sk_render_fast2_kernel as a cross-check of the voices it was NOT told to sit out).  `first_now`: the clock of
+// the first frame that would be rendered (synth.c:521 pre-increments: count + 1).
+//   moving    the envelope is in attack / decay / release on that frame, or the note-on lies AHEAD of the clock: until the
+//             clock reaches sample_start the reference reads the wrapped difference as a huge elapsed time (synth.c:401), i.e.
+//             "sustain", and then starts the attack by itself -- the one way a constant level ends without a control action
+//   settling  constant level, but the one-pole amp smoother (synth.c:588-593) still moves: g + k*(gain - g) != g
+//   neither   at rest: constant level for every later block until a control action reaches the voice (stages 0 / 3 / 5 are
+//             absorbing, and every control action puts the voice back on the list)
+struct sk_motion_t {
+  int code;          // stage on the first frame
+  bool moving, settling;
+  float gain_const;  // amp * (level * velocity) of a constant stage (synth.c:582,588); 0-level for the moving ones
+};
+__device__ __forceinline__ sk_motion_t sk_env_motion(uint64_t first_now, bool dead, bool active, uint64_t t_start, uint64_t t_release,
+                                                     float att, float attdec, float rel, float sus, float amp, float vel, float k, float sgain) {
+  sk_motion_t m;
+  const bool released = t_release != 0;                        // synth.c:417
+  const uint64_t d_on = first_now - t_start, d_off = first_now - t_release;
+  m.code = sk_env_stage_code(active, released, (float)d_on, (float)d_off, att, attdec, rel);
+  const bool ahead = active && (int64_t)(t_start - first_now) > 0;
+  m.moving = !dead && (ahead || !(m.code == 0 || m.code == 3 || m.code == 5));
+  const float level = m.code == 3 ? sus : 0.0f;
+  m.gain_const = amp * (level * vel);
+  const float nxt = sgain + k * (m.gain_const - sgain);
+  m.settling = !dead && !m.moving && __float_as_uint(nxt) != __float_as_uint(sgain);
+  return m;
 }
 
 // ---------------------------------------------------------------- per-voice registers

@@ -4,7 +4,7 @@
  *
  *   skred_render_generic.hip  sk_launch_render (dispatcher), sk_launch_render_mod
  *   skred_render_fast.hip     sk_launch_render_fast
- *   skred_render_fast2.hip    sk_launch_render_fast2
+ *   skred_render_fast2.hip    sk_launch_render_fast2, sk_launch_env_fast2, sk_env2_grid, sk_launch_classify
  *   skred_mix_kernels.hip     sk_launch_master, sk_launch_master_apply
  *   skred_update_kernels.hip  sk_launch_update
  *   skred_rec_kernels.hip     sk_launch_rec_minmax, sk_rec_partial_floats, sk_launch_rec_convert
@@ -35,6 +35,13 @@ int sk_launch_render_mod(const sk_render_args_t *args, int n_workgroups, const i
 /* the two specialised families (called by sk_launch_render only) */
 int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+/* the two-per-lane family's motion list (skred_render_fast2.hip): the list collected from args->mask_cur and rendered by
+ * sk_render_env2_kernel on `stream` -- the block's SECOND stream, beside sk_launch_render_fast2 -- with args->n_env_rows
+ * workgroups (sk_env2_grid: what the device holds at once); sk_launch_classify rebuilds `mask` from the planes */
+int sk_launch_collect(const sk_render_args_t *args, hipStream_t stream);      /* mask_cur -> group_flag (counts), env_off, env_list; mask_next zeroed */
+int sk_launch_env_fast2(const sk_render_args_t *args, hipStream_t stream);
+int sk_env2_grid(const sk_render_args_t *args);
+int sk_launch_classify(const sk_render_args_t *args, uint64_t *mask, hipStream_t stream);
 
 int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels, float target, float k,
                      float *gain_state, hipStream_t stream);
@@ -42,13 +49,14 @@ int sk_launch_master(const float *sum, float *out, int num_frames, int num_chann
 int sk_launch_master_apply(const float *sum, const float *gains, float *out, int num_frames, int num_channels,
                            const float *gain_pending, float *gain_state, hipStream_t stream);
 
-/* scatter n voice updates into the planes; `now` = synth_sample_count for the STAMP bits */
+/* scatter n voice updates into the planes; `now` = synth_sample_count for the STAMP bits; every touched voice goes on the
+ * motion list (`mask`: a bit per voice, skred_device_layout.h: mask_cur) */
 int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[SKP_COUNT], sk_plane_t *const rw[SKS_COUNT],
-                     uint64_t now, hipStream_t stream);
+                     uint64_t now, uint64_t *mask, hipStream_t stream);
 
 /* note-on / note-off stamps only: a list of voice ids */
 int sk_launch_stamp(const int32_t *d_ids, int n, uint32_t dirty, sk_plane_t *const ro[SKP_COUNT], sk_plane_t *const rw[SKS_COUNT],
-                    uint64_t now, hipStream_t stream);
+                    uint64_t now, uint64_t *mask, hipStream_t stream);
 
 /* stem recorder (skred_recorder.c): min/max partials of rec[n_floats]; selected voices -> int16 pairs */
 int sk_rec_partial_floats(void);

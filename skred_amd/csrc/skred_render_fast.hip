@@ -949,7 +949,12 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         // bank, and their waves must come back to the steady blocks
         const bool idle = r.use_env && !(r.rw & SKR_ENV_ACTIVE);
         if (idle && !dead) r.gain_sustain = r.amp * (0.0f * r.vel);
-        steady = __all(dead || !r.use_env || idle || (!released && !(tf_first < r.attdec)));
+        // A note-on AHEAD of the clock (a host that schedules a note by writing sample_start itself): until the clock gets there
+        // the reference reads the wrapped difference as a huge elapsed time, i.e. "sustain", and then the attack starts by itself
+        // (synth.c:401) -- the one way a constant level ends without a control action.  Such a lane is never steady, and `exact`
+        // is false for it (d_on wrapped), so its wave walks the chunk on integer clocks: the reference's own arithmetic.
+        const bool ahead = r.use_env && !idle && (int64_t)(t_start - (base + 1)) > 0;
+        steady = __all(dead || !r.use_env || idle || (!released && !(tf_first < r.attdec) && !ahead));
         if (RAMPK) moved = moved || !steady;
         // envelopes in motion: can the chunk's 8-frame blocks keep the straight-line form (fast_env_span2)?
         if (RAMPK && !steady && exact && tame && !stems_on && cn >= 8 && (!STOPS || (!any_fm && !stop_near))) {
@@ -1083,7 +1088,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     // "an envelope moved in this launch": what the host's choice between the two instantiations rests on
     // (only the RAMPK instantiation reports: while the lean one runs, envelopes can start moving through a control action
     // only, and every control action sends the host back to RAMPK by itself)
-    if (RAMPK && moved && lane == 0) a.group_flag[a.n_groups * 2] = (int32_t)a.launch_ticket;
+    if (RAMPK && moved && lane == 0) sk_note_moved(a, bid);
     // store the recurrences; skipped voices keep their state and get voice_sample = 0 (synth.c:532,538)
     if (!dead) {
       uint4 s0, s1;

@@ -21,11 +21,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
                                8-frame block costs them 30 %); 0: always the DPP butterfly */
 #endif
 
-// Two kernels share this machinery.  sk_render_fast2_kernel renders the 512-voice groups in which every
-// voice holds a CONSTANT envelope level for the whole launch (sustain, inactive, finished release, or no
-// envelope at all): its loop has no envelope code and a small register footprint.  Groups with any voice
-// in attack / decay / release are only flagged by it and rendered right afterwards by
-// sk_render_env2_kernel, which carries the envelope machinery (and its registers) alone.
+// Two kernels share this machinery.  sk_render_fast2_kernel renders the voices that hold a CONSTANT envelope level
+// for the whole launch (sustain, inactive, finished release, or no envelope at all): its loop has no envelope code and
+// a small register footprint.  The voices that may be in motion -- the MOTION LIST, a bit per voice carried on the
+// device from block to block (skred_device_layout.h: mask_cur) -- sit that kernel out and are rendered by
+// sk_render_env2_kernel, which carries the envelope machinery (and its registers) alone and runs BESIDE it on a second
+// stream: its own rows, its own ticket, and the block's final ticket shared (skred_kernel_common.hpp: sk_finish_env).
+// No voice is ever sat out without that kernel being launched in the same block: both read the same, read-only list.
 // This source is compiled twice (Makefile): as skred_render_fast2.o with the plain instantiations and the launcher
 // sk_launch_render_fast2, and -- with -DSK_FAST2_FMP_TU=1 / =2 -- as skred_render_fm2.o / skred_render_fm2ap.o with the
 // FMP (two-operator FM; ... with amplitude / pan modulation) instantiations and sk_launch_render_fm2 / _fm2ap, so that the two halves of the template matrix compile side by side.
@@ -83,19 +85,8 @@ __device__ __forceinline__ float fast2_fetch(const char *lds_tab, const char *__
   return a + frac * (b - a);
 }
 
-// Which branch of amp_envelope_step (synth.c:398-431) a voice takes at envelope clocks (t, tr):
-// 0 inactive, 1 attack, 2 decay, 3 sustain (held), 4 release, 5 release finished (is_active -> 0).
-// The code is monotone in time within a launch (note-off only arrives between launches), so a voice
-// whose code is the same on the first and the last frame of a span keeps it for the whole span, and
-// codes 0 / 3 / 5 (constant level) are absorbing.
-__device__ __forceinline__ int env_stage_code(bool active, bool released, float t, float tr, float att,
-                                              float attdec, float rel) {
-  if (!active) return 0;
-  if (t < att) return 1;
-  if (t < attdec) return 2;
-  if (!released) return 3;
-  return (tr < rel) ? 4 : 5;
-}
+// (env_stage_code: skred_kernel_common.hpp: sk_env_stage_code)
+#define env_stage_code sk_env_stage_code
 
 // Per-lane envelope constants for a span of frames whose first / last frame have clocks (t1,tr1) / (tN,trN)
 // and whose preceding frame has (t0,tr0).  Constant lanes get gain_const; moving lanes get the "ramp" form
@@ -547,7 +538,7 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
     const float *w_ = reinterpret_cast<const float *>(wsum);                    \
     float s_ = w_[0 * 2 * SK_CHUNK + tid];                                      \
     _Pragma("unroll") for (int w2_ = 1; w2_ < NW; ++w2_) s_ += w_[w2_ * 2 * SK_CHUNK + tid]; \
-    sk_row_store(a.partial + part_base + (size_t)c0 * 2 + tid, s_, !(ACCUM_), publish);   \
+    sk_row_store(row_ptr + (size_t)c0 * 2 + tid, s_, !(ACCUM_), publish);   \
   }                                                                             \
   wsum = (wsum == wsum0) ? wsum0 + NW * SK_CHUNK : wsum0;
 
@@ -685,7 +676,7 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
 }
 
 // NW (a constexpr in scope): wavefronts per workgroup = 128-voice slices per workgroup pass
-#define SK_FAST2_PROLOGUE_(WORKS)                                                                      \
+#define SK_FAST2_PROLOGUE_(WORKS, ROWS, GAIN_WG)                                                      \
   extern __shared__ float lds[];                                                                     \
   float2 *const wsum0 = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));        \
   float2 *wsum = wsum0;                      /* [2][NW][SK_CHUNK]: see SK_FAST2_FLUSH */              \
@@ -697,9 +688,9 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
   /* global-table banks: the same LDS holds the wave's table windows instead (2 voices x SK_WIN x 64 lanes) */ \
   float *win = reinterpret_cast<float *>(wsum0 + 2 * NW * SK_CHUNK) + wave * (2 * SK_WIN * 64);      \
   (void)xp; (void)xq; (void)win;                                                                     \
-  const int bid = (int)blockIdx.x - a.wg_shift;   /* row of the partial mix; -1: the gain workgroup */ \
-  if (bid < 0) { sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds)); return; }      \
-  const int n_flags = a.n_groups * 2;      /* one hand-over flag per 128-voice wave slice; [n_flags] = the ticket slot */ \
+  const int bid = (int)blockIdx.x - ((GAIN_WG) ? a.wg_shift : 0);   /* row of the partial mix; -1: the gain workgroup */ \
+  if ((GAIN_WG) && bid < 0) { sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds)); return; } \
+  const int n_flags = a.n_groups * 2;      /* 128-voice wave slices; env_off[n_flags] = the length of the motion list */ \
   if (TAB_LDS && (WORKS)) {                 /* (a workgroup without a pass needs no tables) */           \
     const int n4 = a.lds_table_floats >> 2;                                                          \
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);                                 \
@@ -707,10 +698,9 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
     for (int i = tid; i < n4; i += NW * 64) dst4[i] = src4[i];                                       \
     __syncthreads();                                                                                 \
   }                                                                                                  \
-  const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;                                   \
-  const int n_groups2 = a.n_groups >> 1;   /* 512-voice groups: one pass of sk_render_env2_kernel */ \
+  float *const row_ptr = (ROWS) + (size_t)bid * (size_t)a.num_frames * 2;   /* this workgroup's row */ \
   const int n_pass = (a.n_groups * SK_GROUP) / (NW * 128);   /* workgroup passes over the (padded) bank */
-#define SK_FAST2_PROLOGUE() SK_FAST2_PROLOGUE_(true)
+#define SK_FAST2_PROLOGUE() SK_FAST2_PROLOGUE_(true, a.partial, true)
 
 #ifndef SK_FAST2_MIN_WAVES
 #define SK_FAST2_MIN_WAVES 4     /* <= 128 VGPRs */
@@ -721,10 +711,7 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
 // 16 waves, 4 per SIMD -- share a CU's LDS with ONE copy of the tables each (four per SIMD needs <= 40 KB per
 // 256-thread workgroup otherwise, and tables + tiles take ~46 KB); global-table banks keep 4 (their table windows
 // scale with the wave count).
-#ifndef SK_FAST2_MAX_SETTLING
-#define SK_FAST2_MAX_SETTLING 16   /* voices per 128-voice slice whose smoother alone still moves: up to this many are handed over */
-#endif
-/* store what this kernel rendered: not the voices handed over (lane masks m0 / m1) */
+/* store what this kernel rendered: not the voices on the motion list (lane masks m0 / m1) */
 #define SK_FAST2_STORE_MINE()                                                                        \
   {                                                                                                  \
     const bool skip_[2] = {(bool)((m0 >> lane) & 1), (bool)((m1 >> lane) & 1)};                      \
@@ -738,7 +725,7 @@ template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED, int FMP =
 __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
   constexpr int NW = Fast2Shape<TAB_LDS>::NW;
   SK_FAST2_PROLOGUE()
-  (void)n_groups2;
+  (void)n_flags;
   bool first_pass = true;
   bool row_published = false;
   for (int g = bid; g < n_pass; g += a.n_rows) {
@@ -751,62 +738,55 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     const int slice = g * NW + wave;
     const int vidx[2] = {FMP ? slice * 128 + 2 * lane : slice * 128 + lane, FMP ? slice * 128 + 2 * lane + 1 : slice * 128 + 64 + lane};
     const bool absent[2] = {false, false};
-    uint64_t m0 = 0, m1 = 0;                          // the lanes whose voice 0 / 1 is handed over (wave-uniform masks)
+    uint64_t m0 = 0, m1 = 0;                          // the lanes whose voice 0 / 1 is on the motion list (wave-uniform masks)
     const bool tame = fast2_load<FILTER, ENV, MIXED, FMP>(a, vidx, absent, lane, r, e, dead, silent, released, t_start, t_release, tame_m);
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
     bool wave_ok = true;
     if (ENV) {
-      // constant envelope level on the first frame of the launch <=> for the whole launch (absorbing codes)
-      bool moving[2], settling[2];
+      // The motion list: voices whose envelope may be in motion sit this launch out here -- pan gains at zero, exact zeros
+      // into the mix, nothing stored -- and are rendered by sk_render_env2_kernel, which reads the same bits (collected into
+      // full waves) on the other stream.  (Notes start and end all the time in a live bank: almost every 128-voice slice
+      // holds a few such voices.)  a.skip_env2: the list is empty, nobody runs beside this kernel.
+      if (!a.skip_env2) {
+        const int su = __builtin_amdgcn_readfirstlane(slice);
+        const uint64_t w0 = a.mask_cur[2 * su], w1 = a.mask_cur[2 * su + 1];     // voices slice*128 + 0..63 / + 64..127
+        if (FMP) {                                    // the lane's pair (2 lane, 2 lane + 1) travels together
+          const uint64_t w = lane < 32 ? w0 : w1;
+          m0 = m1 = __ballot(((w >> ((2 * lane) & 63)) & 3ull) != 0);
+        } else {
+          m0 = w0; m1 = w1;
+        }
+      }
+      // every voice that is NOT on the list holds a constant level for the whole launch: the stage on its first frame (stages
+      // 0 / 3 / 5 are absorbing; a voice leaves them only through a control action, and those put it on the list)
+      bool stray = false;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const uint64_t d_on = a.count0 + 1 - t_start[c], d_off = a.count0 + 1 - t_release[c];
-        const int code = env_stage_code((r.rw[c] & SKR_ENV_ACTIVE) != 0, released[c], (float)d_on, (float)d_off,
-                                        e.att[c], e.attdec[c], e.rel[c]);
-        moving[c] = !(dead[c] || code == 0 || code == 3 || code == 5);
-        const float level = code == 3 ? e.susv[c] : 0.0f;
-        r.gain_const[c] = e.ampv[c] * (level * e.velv[c]);                       // synth.c:582,588
-        if (!dead[c] && code == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;                   // synth.c:429
-        const float nxt = r.sgain[c] + r.k[c] * (r.gain_const[c] - r.sgain[c]);
-        settling[c] = !dead[c] && !moving[c] && __float_as_uint(nxt) != __float_as_uint(r.sgain[c]);
+        const sk_motion_t mo = sk_env_motion(a.count0 + 1, dead[c], (r.rw[c] & SKR_ENV_ACTIVE) != 0, t_start[c], t_release[c], e.att[c],
+                                             e.attdec[c], e.rel[c], e.susv[c], e.ampv[c], e.velv[c], r.k[c], r.sgain[c]);
+        r.gain_const[c] = mo.gain_const;                                         // synth.c:582,588
+        if (!dead[c] && mo.code == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;                // synth.c:429
+        stray = stray || (mo.moving && !(((c ? m1 : m0) >> lane) & 1));
       }
-      // a voice that has just reached its constant level still moves its amp smoother for a few hundred frames, and ONE
-      // such lane keeps its whole wave off the stalled-smoother blocks: a few of them go with the moving voices until they
-      // rest (many of them -- a bank right after its upload -- stay: the wave then runs its smoothers for all lanes anyway)
-      // (never in a launch that runs WITHOUT the envelope kernel: "no envelope moves" may have been reported by the one-voice
-      // kernel, which does not look at smoothers -- a settling voice then simply stays here, in a wave that runs its smoothers)
-      if (!a.skip_env2 && __popcll(__ballot(settling[0])) + __popcll(__ballot(settling[1])) <= SK_FAST2_MAX_SETTLING) {
-        moving[0] = moving[0] || settling[0];
-        moving[1] = moving[1] || settling[1];
+      {   // cross-check of the list (unreachable by construction: see DESIGN "The motion list"): counted, the host rebuilds the list
+        const uint64_t sb = __ballot(stray);
+        if (sb != 0 && lane == 0) atomicAdd(a.violations, (uint32_t)__popcll(sb));
       }
-      // hand-over per VOICE: a voice with its envelope in motion is left to sk_render_env2_kernel (which collects such
-      // voices from the whole bank into full waves) and sits out this launch here with its pan gains at zero -- exact
-      // zeros into the mix, nothing stored.  (Notes start and end all the time in a live bank: almost every 128-voice slice holds a few such voices,
-      // and a slice handed over whole makes the envelope kernel render the ~90 % of its lanes that are merely held.)
-      if (FMP) moving[0] = moving[1] = moving[0] || moving[1];   // carrier and modulator stay together
-      m0 = __ballot(moving[0]); m1 = __ballot(moving[1]);
-      const int n_moving = __popcll(m0) + __popcll(m1);
-      if (lane == 0) {
-        a.group_flag[slice] = n_moving;
-        a.move_mask[2 * slice] = m0;
-        a.move_mask[2 * slice + 1] = m1;
-        if (n_moving) a.group_flag[n_flags] = (int32_t)a.launch_ticket;         // "this launch handed something over"
-      }
-      if (n_moving) {                                 // (wave-uniform: the steady state pays for none of this)
+      if ((m0 | m1) != 0) {                           // (wave-uniform: the steady state pays for none of this)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-          if (moving[c]) {     // (two numbers, not fast2_make_inert's twenty-five: the kernel sits at its register budget)
+          if (((c ? m1 : m0) >> lane) & 1) {   // (two numbers, not fast2_make_inert's twenty-five: the kernel sits at its register budget)
             r.pan_lr[c] = (v2f){0.0f, 0.0f};           // it walks its oscillator for nothing and adds exact zeros
             r.k[c] = 0.0f;                             // its smoother counts as stalled (fast2_smoother_stalled is a wave vote)
             if (FMP == 2) r.am_on = r.pm_on = false;   // (and its pan stays at zero)
           }
-        wave_ok = __any((!dead[0] && !moving[0]) || (!dead[1] && !moving[1]));   // (nothing left to render: zeros to the chunk sums)
+        wave_ok = __any((!dead[0] && !((m0 >> lane) & 1)) || (!dead[1] && !((m1 >> lane) & 1)));   // (nothing left to render: zeros to the chunk sums)
       }
       if (!__syncthreads_or(wave_ok ? 1 : 0)) {       // nothing of this pass is rendered here
 #pragma unroll
         for (int c = 0; c < 2; ++c)                   // (really dead voices still get voice_sample = 0, synth.c:532,538 --
-          if (dead[c] && !(((c ? m1 : m0) >> lane) & 1))   //  unless they travel with a handed-over pair: its carrier reads it)
+          if (dead[c] && !(((c ? m1 : m0) >> lane) & 1))   //  unless they are on the list: the envelope kernel does it, and a listed pair's carrier reads it)
             reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][vidx[c]])[2] = 0u;
         continue;
       }
@@ -816,7 +796,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
       if (wave_ok) {
         SK_FAST2_CHUNK(0)
       } else if (lane < cn) {
-        wsum[wave * SK_CHUNK + lane] = make_float2(0.0f, 0.0f);             // a deferred wave adds nothing to the chunk
+        wsum[wave * SK_CHUNK + lane] = make_float2(0.0f, 0.0f);             // a wave of listed voices adds nothing to the chunk
       }
       SK_FAST2_FLUSH(!first_pass)
     }
@@ -824,32 +804,34 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     first_pass = false;
     row_published = publish;
   }
-  if (first_pass) {   // every group of this workgroup was deferred: its partial-mix row must still exist
-    for (int i = tid; i < 2 * a.num_frames; i += NW * 64) a.partial[part_base + i] = 0.0f;
+  if (first_pass) {   // every pass of this workgroup was skipped: its partial-mix row must still exist
+    for (int i = tid; i < 2 * a.num_frames; i += NW * 64) row_ptr[i] = 0.0f;
   }
-  // (row_published is false when the completing pass was skipped as a whole -- every wave deferred: the row is then
+  // (row_published is false when the completing pass was skipped as a whole -- every voice on the list: the row is then
   // copied out by sk_finish_block)
   if (a.finish) sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds), row_published);
 }
 
-// The voices with envelopes in motion (handed over by sk_render_fast2_kernel, which ran just before on the stream), 128
-// list entries per wave.
+// The voices on the motion list, 128 list entries per wave, on a stream of its own beside sk_render_fast2_kernel (which
+// sits exactly these voices out).  Rows, ticket and sum are this kernel's own (sk_finish_env).
 #ifndef SK_ENV2_MIN_WAVES
 #define SK_ENV2_MIN_WAVES 3      /* the envelope machinery wants ~170 VGPRs: 3 waves per SIMD measured best (2: no spills, 4: 220 B of scratch) */
 #endif
 template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED, int FMP = 0>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
   constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
-  SK_FAST2_PROLOGUE_((int)blockIdx.x - a.wg_shift < (a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows) &&
-                     (int)blockIdx.x - a.wg_shift < (a.env_off[a.n_groups * 2] + NW * 128 - 1) / (NW * 128))
-  (void)n_pass; (void)n_groups2;
-  // the voices sk_render_fast2_kernel left to this kernel, in ascending order (sk_scan_moving_kernel +
-  // sk_expand_moving_kernel): every workgroup pass takes 512 of them, so the launch costs what those voices cost
+  // the listed voices in ascending order (sk_collect_scan_kernel + sk_collect_expand_kernel, just before on this stream):
+  // every workgroup pass takes 512 of them, so the launch costs what those voices cost; the grid is what the device holds at
+  // once (a grid of more rendering workgroups than fit runs in rounds, the last one mostly empty) and strides over the passes
+  SK_FAST2_PROLOGUE_((int)blockIdx.x < (a.env_off[a.n_groups * 2] + NW * 128 - 1) / (NW * 128), a.env_rows, false)
+  (void)n_pass;
   const int n_mine = a.env_off[n_flags];
-  constexpr bool publish = false;   // (a workgroup of this kernel may have no pass at all: sk_finish_block copies every row out)
-  const int n_workers = a.env_workers > 0 && a.env_workers < a.n_rows ? a.env_workers : a.n_rows;
+  const int n_workers = a.n_env_rows;
   const int n_env_pass = (n_mine + NW * 128 - 1) / (NW * 128);
-  for (int g = bid < n_workers ? bid : n_env_pass; g < n_env_pass; g += n_workers) {
+  const int n_used = min(n_workers, n_env_pass);         // workgroups that render (and publish a row)
+  bool first_pass = true;
+  for (int g = bid; g < n_env_pass; g += n_workers) {
+    const bool publish = g + n_workers >= n_env_pass;    // the pass that completes this workgroup's row
     const int p0 = g * (NW * 128) + wave * 128;          // this wave's first list entry
     const bool mine = p0 < n_mine;
     Fast2Regs r;
@@ -890,6 +872,9 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
           cb_trf[c] = released[c] ? (float)d_off : 0.0f;
           fast2_env_span(r, e, c, dead[c], released[c], (float)(d_on + 1), (float)(d_off + 1),
                          (float)(d_on + (uint64_t)cn), (float)(d_off + (uint64_t)cn), cb_tf[c], cb_trf[c], st, same);
+          // a note-on AHEAD of the clock: the wrapped difference reads as "sustain" until the clock gets there, then the attack
+          // starts by itself (synth.c:401) -- not a constant level, and not a chunk for float clocks (ex is false: d_on wrapped)
+          if (!dead[c] && (r.rw[c] & SKR_ENV_ACTIVE) && (int64_t)(t_start[c] - (base + 1)) > 0) st = false;
         }
         exact = __all(ex);
         steady = __all(st);
@@ -969,22 +954,43 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
         }
       }
       }   // mine
-      SK_FAST2_FLUSH(true)
+      SK_FAST2_FLUSH(!first_pass)
     }
-    if (mine) fast2_store<MIXED>(a, r, dead, vidx, absent);
+    first_pass = false;
+    if (mine) {
+      fast2_store<MIXED>(a, r, dead, vidx, absent);
+      // Who stays on the list?  A voice whose envelope is still in motion on the next block's first frame, whose note-on is
+      // still ahead of the clock, or whose amp smoother has not come to rest (sk_env_motion: the list's one definition).
+      bool keep[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const sk_motion_t mo = sk_env_motion(a.count0 + (uint64_t)a.num_frames + 1, dead[c], (r.rw[c] & SKR_ENV_ACTIVE) != 0, t_start[c],
+                                             t_release[c], e.att[c], e.attdec[c], e.rel[c], e.susv[c], e.ampv[c], e.velv[c], r.k[c], r.sgain[c]);
+        keep[c] = !absent[c] && (mo.moving || mo.settling);
+      }
+      if (FMP) keep[0] = keep[1] = (keep[0] || keep[1]);        // carrier and modulator stay together
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        if (keep[c] && !absent[c]) atomicOr(reinterpret_cast<unsigned long long *>(a.mask_next) + (vidx[c] >> 6), 1ull << (vidx[c] & 63));
+    }
   }
-  if (a.finish) sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds));
+  sk_finish_env(a, n_used, tid, NW * 64, reinterpret_cast<int *>(lds));
 }
 
-// ---------------------------------------------------------------- launcher (C linkage)
+// ---------------------------------------------------------------- the motion list: collect, classify (plain TU only)
 
-// counts[n] (voices handed over per 128-voice slice) -> off[n] exclusive prefix sums, off[n] = their total.  One
-// workgroup, tiles of 8192 counts staged through LDS (coalesced loads in flight together -- a thread walking its
+#ifndef SK_FAST2_FMP_TU
+// mask[2 n] (a bit per voice; a 128-voice wave slice = two words) -> counts[n] (listed voices per slice), off[n] exclusive
+// prefix sums, off[n] = their total; and the NEXT block's mask zeroed (sk_render_env2_kernel, next on this stream, ORs its
+// survivors in).  pairs: two-operator FM banks list whole (2i, 2i+1) pairs -- either bit lists both voices.
+// One workgroup, tiles of 8192 slices staged through LDS (coalesced loads in flight together -- a thread walking its
 // contiguous share in global memory pays one memory latency per element): every thread sums its 32 contiguous counts, the
 // 256 sums are scanned across lanes (shuffles inside each wavefront, four wave totals through LDS), every thread writes its
 // prefixes back into the tile, and the tile leaves coalesced.
 #define SK_SCAN_TILE 8192
-SK_FAST2_TU_LOCAL __global__ __launch_bounds__(256) void sk_scan_moving_kernel(const int32_t *__restrict__ counts, int n, int32_t *__restrict__ off) {
+__device__ __forceinline__ uint64_t sk_pair_bits(uint64_t w) { return (w | (w >> 1)) & 0x5555555555555555ull; }   // bit 2i: pair i listed
+__global__ __launch_bounds__(256) void sk_collect_scan_kernel(const uint64_t *__restrict__ mask, uint64_t *__restrict__ mask_next, int n,
+                                                              int pairs, int32_t *__restrict__ counts, int32_t *__restrict__ off) {
   __shared__ int tile[SK_SCAN_TILE + SK_SCAN_TILE / 32];   // element k lives at k + k/32: a thread's 32 counts stay contiguous, the
                                                            // threads' shares start in different banks
 #define SK_SCAN_AT(k) ((k) + ((k) >> 5))
@@ -994,7 +1000,16 @@ SK_FAST2_TU_LOCAL __global__ __launch_bounds__(256) void sk_scan_moving_kernel(c
   for (int t0 = 0; t0 < n; t0 += SK_SCAN_TILE) {
     const int m = min(SK_SCAN_TILE, n - t0);
 #pragma unroll 8
-    for (int k = t; k < SK_SCAN_TILE; k += 256) tile[SK_SCAN_AT(k)] = k < m ? counts[t0 + k] : 0;
+    for (int k = t; k < SK_SCAN_TILE; k += 256) {
+      int cnt = 0;
+      if (k < m) {
+        const ulonglong2 w = reinterpret_cast<const ulonglong2 *>(mask)[t0 + k];
+        cnt = pairs ? 2 * (__popcll(sk_pair_bits(w.x)) + __popcll(sk_pair_bits(w.y))) : __popcll(w.x) + __popcll(w.y);
+        counts[t0 + k] = cnt;
+        reinterpret_cast<ulonglong2 *>(mask_next)[t0 + k] = make_ulonglong2(0ull, 0ull);
+      }
+      tile[SK_SCAN_AT(k)] = cnt;
+    }
     __syncthreads();
     int c = 0;
 #pragma unroll
@@ -1023,88 +1038,110 @@ SK_FAST2_TU_LOCAL __global__ __launch_bounds__(256) void sk_scan_moving_kernel(c
 }
 #undef SK_SCAN_AT
 
-// One wavefront per slice: its handed-over voices (two lane masks) go to list[off[slice] ...] in ascending voice order.
-// pairs: the slice's lanes hold voices (2 lane, 2 lane + 1) and both masks are the same (two-operator FM banks).
-SK_FAST2_TU_LOCAL __global__ __launch_bounds__(256) void sk_expand_moving_kernel(const int32_t *__restrict__ counts, const uint64_t *__restrict__ mask,
+// One wavefront per slice: its listed voices go to list[off[slice] ...] in ascending voice order.
+__global__ __launch_bounds__(256) void sk_collect_expand_kernel(const int32_t *__restrict__ counts, const uint64_t *__restrict__ mask,
                                                                 const int32_t *__restrict__ off, int n, int32_t *__restrict__ list, int pairs) {
   const int lane = threadIdx.x & 63, slice = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
   if (slice >= n || counts[slice] == 0) return;
   const uint64_t m0 = mask[2 * slice], m1 = mask[2 * slice + 1];
-  const uint64_t below = ((uint64_t)1 << lane) - 1;
   const int o = off[slice];
-  if (pairs) {
-    if ((m0 >> lane) & 1) {
-      const int at = o + 2 * __popcll(m0 & below);
-      list[at] = slice * 128 + 2 * lane;
-      list[at + 1] = slice * 128 + 2 * lane + 1;
+  if (pairs) {                                         // lane L: the pair (2L, 2L+1) of the slice
+    const uint64_t p0 = sk_pair_bits(m0), p1 = sk_pair_bits(m1);
+    const uint64_t p = lane < 32 ? p0 : p1;
+    const int sh = (2 * lane) & 63;
+    if ((p >> sh) & 1) {
+      const int rank = (lane < 32 ? 0 : __popcll(p0)) + __popcll(p & (((uint64_t)1 << sh) - 1));
+      list[o + 2 * rank] = slice * 128 + 2 * lane;
+      list[o + 2 * rank + 1] = slice * 128 + 2 * lane + 1;
     }
     return;
   }
+  const uint64_t below = ((uint64_t)1 << lane) - 1;
   if ((m0 >> lane) & 1) list[o + __popcll(m0 & below)] = slice * 128 + lane;
   if ((m1 >> lane) & 1) list[o + __popcll(m0) + __popcll(m1 & below)] = slice * 128 + 64 + lane;
 }
 
-// sk_render_fast2_kernel renders the constant-envelope slices and flags the others; when the bank has
-// envelopes at all, sk_render_env2_kernel follows on the same stream and renders the flagged groups.
+// The list from scratch (after uploads, clock changes, or a stretch on another kernel family): one wavefront per 128-voice
+// slice, two voices per lane, sk_env_motion on the block's first frame.  A voice whose envelope rests but whose smoother
+// still settles is listed only while its slice holds at most SK_FAST2_MAX_SETTLING of them -- a few such lanes would keep
+// their whole wave of the steady kernel off the stalled-smoother blocks; many of them (a bank right after its upload) make
+// that wave run its smoothers anyway, and listing them all would send the whole bank through the envelope kernel.
+#ifndef SK_FAST2_MAX_SETTLING
+#define SK_FAST2_MAX_SETTLING 16
+#endif
+__global__ __launch_bounds__(256) void sk_classify_kernel(const sk_render_args_t a, uint64_t *__restrict__ mask) {
+  const int lane = threadIdx.x & 63, slice = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+  if (slice >= a.n_groups * 2) return;
+  bool mv[2], st[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int v = slice * 128 + c * 64 + lane;
+    const uint4 osc = *reinterpret_cast<const uint4 *>(&a.ro[SKP_OSC][v]);
+    const uint4 tab = *reinterpret_cast<const uint4 *>(&a.ro[SKP_TAB][v]);
+    const uint4 gn = *reinterpret_cast<const uint4 *>(&a.ro[SKP_GAIN][v]);
+    const uint4 et = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_T][v]);
+    const uint4 es = *reinterpret_cast<const uint4 *>(&a.ro[SKP_ENV_S][v]);
+    const uint4 s0 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_OSC][v]);
+    const uint4 s1 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_FILT][v]);
+    const uint32_t flags = tab.z;
+    const float amp = __uint_as_float(osc.w);
+    const bool dead = (s1.w & SKR_FINISHED) || amp == 0.0f || (flags & SKF_INERT);
+    float att = __uint_as_float(et.x), dec = __uint_as_float(et.y), sus = __uint_as_float(et.z), rel = __uint_as_float(et.w);
+    float vel = __uint_as_float(gn.x);
+    uint64_t t_start = ((uint64_t)es.y << 32) | es.x, t_release = ((uint64_t)es.w << 32) | es.z;
+    bool active = (s1.w & SKR_ENV_ACTIVE) != 0;
+    if (!(flags & SKF_USE_ENV)) {            // no envelope: a note held at level 1 with velocity 1 (fast2_load does the same)
+      att = dec = rel = 0.0f; sus = 1.0f; vel = 1.0f; t_start = a.count0; t_release = 0; active = true;
+    }
+    const sk_motion_t mo = sk_env_motion(a.count0 + 1, dead, active, t_start, t_release, att, att + dec, rel, sus, amp, vel,
+                                         __uint_as_float(gn.y), __uint_as_float(s0.y));
+    mv[c] = mo.moving;
+    st[c] = mo.settling;
+  }
+  if (__popcll(__ballot(st[0])) + __popcll(__ballot(st[1])) <= SK_FAST2_MAX_SETTLING) { mv[0] = mv[0] || st[0]; mv[1] = mv[1] || st[1]; }
+  const uint64_t m0 = __ballot(mv[0]), m1 = __ballot(mv[1]);
+  if (lane == 0) { mask[2 * slice] = m0; mask[2 * slice + 1] = m1; }
+}
+
+extern "C" int sk_launch_classify(const sk_render_args_t *args, uint64_t *mask, hipStream_t stream) {
+  hipLaunchKernelGGL(sk_classify_kernel, dim3((unsigned)((args->n_groups * 2 + 3) / 4)), dim3(256), 0, stream, *args, mask);
+  return (int)hipGetLastError();
+}
+#endif   // !SK_FAST2_FMP_TU
+
+// ---------------------------------------------------------------- launchers (C linkage)
+
+// sk_launch_render_fast2: the steady kernel (args->skip_env2: alone; otherwise the host has put sk_launch_render_env2 on
+// its second stream first -- skred_bank.c: render_block).  sk_launch_render_env2: collect + the envelope kernel.
 #if defined(SK_FAST2_FMP_TU) && SK_FAST2_FMP_TU == 2
 #define SK_FAST2_LAUNCHER sk_launch_render_fm2ap
+#define SK_ENV2_LAUNCHER sk_launch_env_fm2ap
 #elif defined(SK_FAST2_FMP_TU)
 #define SK_FAST2_LAUNCHER sk_launch_render_fm2
+#define SK_ENV2_LAUNCHER sk_launch_env_fm2
 #else
 #define SK_FAST2_LAUNCHER sk_launch_render_fast2
+#define SK_ENV2_LAUNCHER sk_launch_env_fast2
 extern "C" int sk_launch_render_fm2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 extern "C" int sk_launch_render_fm2ap(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+extern "C" int sk_launch_env_fm2(const sk_render_args_t *args, hipStream_t stream);
+extern "C" int sk_launch_env_fm2ap(const sk_render_args_t *args, hipStream_t stream);
 #endif
-extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
-                                 hipStream_t stream) {
-  const bool tab_lds = args->lds_table_floats > 0;
-#ifndef SK_FAST2_FMP_TU
-  if ((args->fast_mode & SKM_FM_PAIR) && tab_lds)
-    return (args->fast_mode & SKM_PAIR_AP) ? sk_launch_render_fm2ap(args, n_workgroups, lds_bytes, stream)
-                                           : sk_launch_render_fm2(args, n_workgroups, lds_bytes, stream);
-#endif
-  (void)lds_bytes;
+
+static inline size_t sk_fast2_lds(const sk_render_args_t *args, int nw) {
   // LDS: [tables] + wsum[2][NW][SK_CHUNK] + per wave the transposition tile and row sums (LDS-table banks) or the table
-  // windows (global-table banks).  n_workgroups = partial rows = passes of sk_render_fast2_kernel; the env2 kernel
-  // (4 waves per workgroup) walks its 512-voice groups with the same grid and adds into the same rows.
+  // windows (global-table banks)
+  const bool tab_lds = args->lds_table_floats > 0;
   const size_t tab_bytes = (size_t)(tab_lds ? args->lds_table_floats : 0) * sizeof(float);
   const size_t per_wave = tab_lds ? (size_t)(8 * 65 + 64) * sizeof(float2) : (size_t)(2 * SK_WIN * 64) * sizeof(float);
-  const int nw = tab_lds ? Fast2Shape<true>::NW : Fast2Shape<false>::NW;
-  const size_t lds_fast2 = tab_bytes + (size_t)nw * (2 * SK_CHUNK * sizeof(float2) + per_wave);
-  const size_t lds_env2 = tab_bytes + (size_t)4 * (2 * SK_CHUNK * sizeof(float2) + per_wave);
-  dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block((unsigned)nw * 64), block_env(SK_GROUP);
-  // the block's mix-down (sk_finish_block) belongs to the LAST kernel that writes rows: sk_render_env2_kernel when it
-  // runs (it adds into the rows sk_render_fast2_kernel left), else sk_render_fast2_kernel itself
-  sk_render_args_t first = *args, second = *args;
-  {   /* workgroups of sk_render_env2_kernel the device holds at once: 3 per CU by registers (SK_ENV2_MIN_WAVES), fewer by LDS */
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-    int per_cu = (int)((size_t)160 * 1024 / (lds_env2 ? lds_env2 : 1));
-    if (per_cu > SK_ENV2_MIN_WAVES) per_cu = SK_ENV2_MIN_WAVES;
-    if (per_cu < 1) per_cu = 1;
-    second.env_workers = cus > 0 ? cus * per_cu - 1 : 0;   /* (the gain workgroup holds a slot too) */
-  }
-  const bool env_follows = (args->fast_mode & SKM_ENV_ALL) && !args->skip_env2;
-  if (env_follows) { first.finish = 0; first.wg_shift = 0; }
-  dim3 grid_first((unsigned)(n_workgroups + first.wg_shift));
-  const bool mixed = (args->fast_mode & SKM_MIXED) != 0;     // filter / envelope on some voices only: per-lane flags
-  const bool fmp = (args->fast_mode & SKM_FM_PAIR) != 0 && tab_lds;
-  const int key = (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
-                  ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
-#define SK_FAST2_COLLECT()                                                                              \
-  hipLaunchKernelGGL(sk_scan_moving_kernel, dim3(1), dim3(256), 0, stream, args->group_flag, args->n_groups * 2, args->env_off); \
-  hipLaunchKernelGGL(sk_expand_moving_kernel, dim3((unsigned)((args->n_groups * 2 + 3) / 4)), dim3(256), 0, stream,          \
-                     args->group_flag, args->move_mask, args->env_off, args->n_groups * 2, args->env_list, fmp ? 1 : 0);
-#define SK_FAST2_LAUNCH(T, F, E, I, M, P)                                                               \
-  {                                                                                                     \
-    hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, M, P>), grid_first, block, lds_fast2, stream, first); \
-    if (E && !args->skip_env2) {                                                                        \
-      SK_FAST2_COLLECT()                                                                                \
-      hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, M, P>), grid, block_env, lds_env2, stream, second); \
-    }                                                                                                   \
-  }
+  return tab_bytes + (size_t)nw * (2 * SK_CHUNK * sizeof(float2) + per_wave);
+}
+static inline int sk_fast2_key(const sk_render_args_t *args) {
+  return (args->lds_table_floats > 0 ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
+         ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
+}
 /* (two-operator FM banks: LDS-table banks only -- T is a constant there, which keeps the instantiations at 24 more; they live
-   in the other translation unit) */
+   in the other translation units) */
 #ifdef SK_FAST2_FMP_TU
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
@@ -1117,18 +1154,84 @@ extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups,
     else SK_FAST2_LAUNCH(T, F, E, I, false, 0)                                                          \
     break;
 #endif
-  switch (key) {
-    SK_FAST2_CASE(0, false, false, false, 0) SK_FAST2_CASE(1, false, false, false, 1)
-    SK_FAST2_CASE(2, false, false, true, 0)  SK_FAST2_CASE(3, false, false, true, 1)
-    SK_FAST2_CASE(4, false, true, false, 0)  SK_FAST2_CASE(5, false, true, false, 1)
-    SK_FAST2_CASE(6, false, true, true, 0)   SK_FAST2_CASE(7, false, true, true, 1)
-    SK_FAST2_CASE(8, true, false, false, 0)  SK_FAST2_CASE(9, true, false, false, 1)
-    SK_FAST2_CASE(10, true, false, true, 0)  SK_FAST2_CASE(11, true, false, true, 1)
-    SK_FAST2_CASE(12, true, true, false, 0)  SK_FAST2_CASE(13, true, true, false, 1)
-    SK_FAST2_CASE(14, true, true, true, 0)   SK_FAST2_CASE(15, true, true, true, 1)
+#define SK_FAST2_SWITCH()                                                                               \
+  switch (key) {                                                                                        \
+    SK_FAST2_CASE(0, false, false, false, 0) SK_FAST2_CASE(1, false, false, false, 1)                   \
+    SK_FAST2_CASE(2, false, false, true, 0)  SK_FAST2_CASE(3, false, false, true, 1)                    \
+    SK_FAST2_CASE(4, false, true, false, 0)  SK_FAST2_CASE(5, false, true, false, 1)                    \
+    SK_FAST2_CASE(6, false, true, true, 0)   SK_FAST2_CASE(7, false, true, true, 1)                     \
+    SK_FAST2_CASE(8, true, false, false, 0)  SK_FAST2_CASE(9, true, false, false, 1)                    \
+    SK_FAST2_CASE(10, true, false, true, 0)  SK_FAST2_CASE(11, true, false, true, 1)                    \
+    SK_FAST2_CASE(12, true, true, false, 0)  SK_FAST2_CASE(13, true, true, false, 1)                    \
+    SK_FAST2_CASE(14, true, true, true, 0)   SK_FAST2_CASE(15, true, true, true, 1)                     \
   }
-#undef SK_FAST2_CASE
+
+extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
+                                 hipStream_t stream) {
+  const bool tab_lds = args->lds_table_floats > 0;
+#ifndef SK_FAST2_FMP_TU
+  if ((args->fast_mode & SKM_FM_PAIR) && tab_lds)
+    return (args->fast_mode & SKM_PAIR_AP) ? sk_launch_render_fm2ap(args, n_workgroups, lds_bytes, stream)
+                                           : sk_launch_render_fm2(args, n_workgroups, lds_bytes, stream);
+#endif
+  (void)lds_bytes;
+  const int nw = tab_lds ? Fast2Shape<true>::NW : Fast2Shape<false>::NW;
+  const size_t lds_fast2 = sk_fast2_lds(args, nw);
+  dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block((unsigned)nw * 64);
+  const bool mixed = (args->fast_mode & SKM_MIXED) != 0;     // filter / envelope on some voices only: per-lane flags
+  const int key = sk_fast2_key(args);
+#define SK_FAST2_LAUNCH(T, F, E, I, M, P) { hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, M, P>), grid, block, lds_fast2, stream, *args); }
+  SK_FAST2_SWITCH()
 #undef SK_FAST2_LAUNCH
-#undef SK_FAST2_COLLECT
   return (int)hipGetLastError();
 }
+
+// the envelope kernel's workgroups the device holds at once: 3 per CU by registers (SK_ENV2_MIN_WAVES), fewer by LDS
+extern "C" int sk_env2_grid(const sk_render_args_t *args);
+#ifndef SK_FAST2_FMP_TU
+extern "C" int sk_env2_grid(const sk_render_args_t *args) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  const size_t lds_env2 = sk_fast2_lds(args, 4);
+  int per_cu = (int)((size_t)160 * 1024 / (lds_env2 ? lds_env2 : 1));
+  if (per_cu > SK_ENV2_MIN_WAVES) per_cu = SK_ENV2_MIN_WAVES;
+  if (per_cu < 1) per_cu = 1;
+  int n = (cus > 0 ? cus : 64) * per_cu;
+  const int most = (args->n_groups * SK_GROUP + 511) / 512;       // passes when every voice is listed
+  if (n > most) n = most;
+  return n < 1 ? 1 : n;
+}
+#endif
+
+#ifndef SK_FAST2_FMP_TU
+// collect the list (this block's mask -> counts, offsets, voices; the next block's mask zeroed): on the block's own stream,
+// ahead of both render kernels (an idle machine runs it in ~18 us; beside a full one it took 130)
+extern "C" int sk_launch_collect(const sk_render_args_t *args, hipStream_t stream) {
+  const bool fmp = (args->fast_mode & SKM_FM_PAIR) != 0 && args->lds_table_floats > 0;
+  hipLaunchKernelGGL(sk_collect_scan_kernel, dim3(1), dim3(256), 0, stream, args->mask_cur, args->mask_next, args->n_groups * 2, fmp ? 1 : 0,
+                     args->group_flag, args->env_off);
+  hipLaunchKernelGGL(sk_collect_expand_kernel, dim3((unsigned)((args->n_groups * 2 + 3) / 4)), dim3(256), 0, stream,
+                     args->group_flag, args->mask_cur, args->env_off, args->n_groups * 2, args->env_list, fmp ? 1 : 0);
+  return (int)hipGetLastError();
+}
+#endif
+
+// render the list: on the SECOND stream of the block, beside the steady kernel; args->n_env_rows workgroups (sk_env2_grid)
+extern "C" int SK_ENV2_LAUNCHER(const sk_render_args_t *args, hipStream_t stream) {
+  const bool tab_lds = args->lds_table_floats > 0;
+#ifndef SK_FAST2_FMP_TU
+  if ((args->fast_mode & SKM_FM_PAIR) != 0 && tab_lds)
+    return (args->fast_mode & SKM_PAIR_AP) ? sk_launch_env_fm2ap(args, stream) : sk_launch_env_fm2(args, stream);
+#endif
+  const size_t lds_env2 = sk_fast2_lds(args, 4);
+  dim3 grid((unsigned)args->n_env_rows), block_env(SK_GROUP);
+  const bool mixed = (args->fast_mode & SKM_MIXED) != 0;
+  const int key = sk_fast2_key(args) | 2;                    // (the envelope kernel exists for enveloped banks only)
+  (void)tab_lds;
+#define SK_FAST2_LAUNCH(T, F, E, I, M, P) { if (E) hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, M, P>), grid, block_env, lds_env2, stream, *args); }
+  SK_FAST2_SWITCH()
+#undef SK_FAST2_LAUNCH
+  return (int)hipGetLastError();
+}
+#undef SK_FAST2_CASE
+#undef SK_FAST2_SWITCH

@@ -14,12 +14,20 @@ struct sk_plane_ptrs_t {
   sk_plane_t *rw[SKS_COUNT];
 };
 
+// Every voice a control action touches goes on the motion list of the two-per-lane render family (a bit per voice, carried on
+// the device: skred_device_layout.h, mask_cur): whatever the action did to its envelope, the envelope kernel renders it in the
+// next block and keeps it until it is at rest again.  The render kernels therefore never have to be TOLD that a note started.
+__device__ __forceinline__ void sk_list_voice(uint64_t *mask, int v) {
+  atomicOr(reinterpret_cast<unsigned long long *>(mask) + (v >> 6), 1ull << (v & 63));
+}
+
 __global__ __launch_bounds__(64) void sk_update_kernel(const sk_update_t *__restrict__ u, int n, sk_plane_ptrs_t p,
-                                                      uint64_t now) {
+                                                      uint64_t now, uint64_t *mask) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   const sk_update_t r = u[i];
   const int v = r.voice;
+  sk_list_voice(mask, v);
   const uint32_t d = r.dirty;
   if (d & SKU_PARAMS) {
 #pragma unroll
@@ -55,10 +63,11 @@ __global__ __launch_bounds__(64) void sk_update_kernel(const sk_update_t *__rest
 
 // note-ons / note-offs only: a list of voice ids, the clock, which stamp
 __global__ __launch_bounds__(256) void sk_stamp_kernel(const int32_t *__restrict__ ids, int n, uint32_t dirty, sk_plane_ptrs_t p,
-                                                       uint64_t now) {
+                                                       uint64_t now, uint64_t *mask) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int v = ids[i];
+  sk_list_voice(mask, v);
   uint32_t *rwflags = reinterpret_cast<uint32_t *>(&p.rw[SKS_FILT][v]) + 3;
   uint4 es = *reinterpret_cast<const uint4 *>(&p.ro[SKP_ENV_S][v]);
   uint32_t f = *rwflags;
@@ -74,21 +83,21 @@ __global__ __launch_bounds__(256) void sk_stamp_kernel(const int32_t *__restrict
 }
 
 extern "C" int sk_launch_stamp(const int32_t *d_ids, int n, uint32_t dirty, sk_plane_t *const ro[SKP_COUNT],
-                               sk_plane_t *const rw[SKS_COUNT], uint64_t now, hipStream_t stream) {
+                               sk_plane_t *const rw[SKS_COUNT], uint64_t now, uint64_t *mask, hipStream_t stream) {
   if (n <= 0) return 0;
   sk_plane_ptrs_t p;
   for (int k = 0; k < SKP_COUNT; ++k) p.ro[k] = ro[k];
   for (int k = 0; k < SKS_COUNT; ++k) p.rw[k] = rw[k];
-  hipLaunchKernelGGL(sk_stamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ids, n, dirty, p, now);
+  hipLaunchKernelGGL(sk_stamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ids, n, dirty, p, now, mask);
   return (int)hipGetLastError();
 }
 
 extern "C" int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[SKP_COUNT],
-                                sk_plane_t *const rw[SKS_COUNT], uint64_t now, hipStream_t stream) {
+                                sk_plane_t *const rw[SKS_COUNT], uint64_t now, uint64_t *mask, hipStream_t stream) {
   if (n <= 0) return 0;
   sk_plane_ptrs_t p;
   for (int k = 0; k < SKP_COUNT; ++k) p.ro[k] = ro[k];
   for (int k = 0; k < SKS_COUNT; ++k) p.rw[k] = rw[k];
-  hipLaunchKernelGGL(sk_update_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_updates, n, p, now);
+  hipLaunchKernelGGL(sk_update_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_updates, n, p, now, mask);
   return (int)hipGetLastError();
 }

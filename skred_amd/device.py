@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "skred_bank_set_globals", "skred_bank_get_globals",
     "skred_bank_render", "skred_bank_master", "skred_bank_render_mix", "skred_bank_render_host",
     "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
-    "skred_bank_set_option", "skred_bank_last_kernel", "skred_bank_env_latch_misses",
+    "skred_bank_set_option", "skred_bank_last_kernel", "skred_bank_list_violations",
     "skred_bank_update", "skred_bank_defer", "skred_bank_run_queue", "skred_bank_queue_pending",
     "skred_shard_partition", "skred_shard_cut_ok", "skred_shard_create", "skred_shard_create_custom", "skred_shard_destroy",
     "skred_shard_bank", "skred_shard_range", "skred_shard_upload", "skred_shard_set_ops", "skred_shard_rccl_unique_id",
@@ -85,8 +85,8 @@ def load() -> C.CDLL:
     L.skred_bank_last_render_ms.restype = C.c_float
     L.skred_bank_set_option.argtypes = [vp, i32, i32]
     L.skred_bank_last_kernel.argtypes = [vp]
-    L.skred_bank_env_latch_misses.argtypes = [vp]
-    L.skred_bank_env_latch_misses.restype = C.c_uint
+    L.skred_bank_list_violations.argtypes = [vp]
+    L.skred_bank_list_violations.restype = C.c_uint
     L.skred_bank_timing_reset.argtypes = [vp]
     L.skred_bank_timing_reset.restype = None
     L.skred_bank_timing_summary.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]
@@ -255,9 +255,9 @@ class DeviceBank:
         """0 = generic kernel, 1 = specialised fast kernel (SKRED_KERNEL_*)."""
         return int(self.L.skred_bank_last_kernel(self.h))
 
-    def env_latch_misses(self) -> int:
-        """Launches that skipped the envelope kernel although a slice needed it (self-check; must be 0)."""
-        return int(self.L.skred_bank_env_latch_misses(self.h))
+    def list_violations(self) -> int:
+        """Voices the steady two-per-lane kernel found in motion without being on the motion list (cross-check; 0 by construction)."""
+        return int(self.L.skred_bank_list_violations(self.h))
 
     def last_render_ms(self) -> float:
         return float(self.L.skred_bank_last_render_ms(self.h))

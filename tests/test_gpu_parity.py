@@ -907,52 +907,122 @@ def test_envelope_ramps_segment_by_segment(dev, recipe, interp, fast2):
         db.download(host)
         bad = host.rw_equal(ref_host)
         assert not bad, f"segment {k} ({frames} frames): state differs from the oracle: {bad}"
-    assert db.env_latch_misses() == 0
+    assert db.list_violations() == 0
     db.close()
     act = ref_host["voice_amp_envelope"]["is_active"]
     assert int((act == 0).sum()) > n // 2                    # the releases did run out
     assert rel_rms(np.concatenate(mixes), np.concatenate(ref_mixes)) <= 1e-5
 
 
-def test_note_on_ahead_of_the_clock_is_not_lost_by_the_envelope_latch(dev):
-    """A host that schedules a note by writing sample_start AHEAD of the clock: the reference reads the wrapped clock
-    difference as a huge elapsed time (sustain) until the clock catches up, then the attack starts (synth.c:401) -- the
-    one way an envelope changes stage on its own in mid-launch.  The specialised kernels decide the stage per launch or per
-    chunk, and the two-per-lane path stops launching sk_render_env2_kernel once a launch deferred no slice, so a bank
-    with such voices is rendered by the generic kernel (integer clocks, every frame) until the clock has passed them, and
-    goes back to the specialised ones afterwards.  Against the oracle, block by block, through the attacks' start."""
-    n = 6000
+def _late_note_bank(n):
+    """C2 recipe, everyone long in sustain, every 97th voice with its note-on scheduled 5-9 blocks AHEAD of the clock."""
     bank, tables, g = banks.bank_c2(n)
     e = bank["voice_amp_envelope"]
     now0 = g.synth_sample_count
-    e["sample_start"][:] = np.uint64(now0 - 20000)            # everyone long in sustain ...
+    e["sample_start"][:] = np.uint64(now0 - 20000)
     e["sample_release"][:] = 0
     e["is_active"][:] = 1
     late = np.arange(17, n, 97)
-    e["sample_start"][late] = (now0 + 2500 + (late % 7) * 300).astype(np.uint64)     # ... but these start 5-9 blocks from now
+    e["sample_start"][late] = (now0 + 2500 + (late % 7) * 300).astype(np.uint64)
+    return bank, tables, g, late
+
+
+@pytest.mark.parametrize("two_per_lane", [True, False])
+def test_note_on_ahead_of_the_clock(dev, two_per_lane):
+    """A host that schedules a note by writing sample_start AHEAD of the clock: the reference reads the wrapped clock
+    difference as a huge elapsed time (sustain) until the clock catches up, then the attack starts (synth.c:401) -- the
+    one way an envelope leaves a constant level without a control action.  Both specialised families render that themselves
+    (round 3; the bank used to go to the generic kernel meanwhile): the one-voice kernel walks such a wave's chunks on integer
+    clocks, and on the two-per-lane path such a voice stays on the device's motion list -- rendered by the envelope kernel --
+    until its note has started and come to rest.  Against the oracle, block by block, through the attacks' start."""
+    import torch
+    n = 6000
+    bank, tables, g, _ = _late_note_bank(n)
     db = dev.DeviceBank(n)
     db.set_tables(tables)
     host = bank.copy()
     db.upload(host)
     db.set_globals(g)
-    db.fast2_min_voices(0)
+    db.fast2_min_voices(0 if two_per_lane else 1 << 30)
     ref_host, ref_g = bank.copy(), g.copy()
-    import torch
     out = torch.zeros(512, 2, device="cuda")
     kernels = []
     for k in range(14):
-        db.render_mix(512, out.data_ptr(), 2, 0, 0)           # asynchronous blocks: the way the latch gets its answers
+        db.render_mix(512, out.data_ptr(), 2, 0, 0)           # asynchronous blocks: the way the host gets its reports
         kernels.append(db.last_kernel())
         torch.cuda.synchronize()
         r = cpuref.render(ref_host, ref_g, tables, 512, 0)
         ref_mix = cpuref.master(ref_g, r["sum64"].astype(np.float32))
         assert rel_rms(out.cpu().numpy(), ref_mix) <= 1e-5, f"block {k}"
     db.download(host)
-    assert db.env_latch_misses() == 0
+    assert db.list_violations() == 0
     db.close()
     assert not host.rw_equal(ref_host), host.rw_equal(ref_host)
-    # the latest note-on is at now0 + 2500 + 6*300 = block 8: generic up to there, two per lane from the next block on
-    assert kernels[:9] == [0] * 9 and kernels[9:] == [3] * 5, kernels
+    assert kernels == [3 if two_per_lane else 1] * 14, kernels
+
+
+@pytest.mark.parametrize("two_per_lane", [True, False])
+def test_pending_note_on_rescheduled_and_bank_reused(dev, two_per_lane):
+    """Two call orders that a host-side "is any note-on pending" bookkeeping got wrong (round 2's advisor findings; the
+    bookkeeping is gone, the kernels look at the clocks themselves).  (1) A pending note-on is moved to a LATER clock with
+    SKRED_DIRTY_ENV_CLOCK while it is pending, and some are moved again after the first ones have started.  (2) The bank is
+    re-used for a new session: a second upload with note-ons scheduled ahead of a clock that set_globals() then RESETS to 0,
+    i.e. behind the device's old clock.  Oracle, block by block; one update travels on a stream of its own."""
+    import torch
+    n = 6000
+    bank, tables, g, late = _late_note_bank(n)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    host = bank.copy()
+    db.upload(host)
+    db.set_globals(g)
+    db.fast2_min_voices(0 if two_per_lane else 1 << 30)
+    ref_host, ref_g = bank.copy(), g.copy()
+    out = torch.zeros(512, 2, device="cuda")
+    other = torch.cuda.Stream()
+
+    def block(tag):
+        db.render_mix(512, out.data_ptr(), 2, 0, 0)
+        torch.cuda.synchronize()
+        r = cpuref.render(ref_host, ref_g, tables, 512, 0)
+        ref_mix = cpuref.master(ref_g, r["sum64"].astype(np.float32))
+        assert rel_rms(out.cpu().numpy(), ref_mix) <= 1e-5, tag
+
+    for k in range(3):
+        block(f"a{k}")
+    # (1) every second pending note-on moves 6 blocks further out -- through a stream of its own, finished before the next block
+    moved = late[::2]
+    for hb in (host, ref_host):
+        hb["voice_amp_envelope"]["sample_start"][moved] += np.uint64(6 * 512)
+    db.update(host, moved, dev.DIRTY_ENV_CLOCK, stream=other.cuda_stream)
+    other.synchronize()
+    for k in range(8):
+        block(f"b{k}")
+    again = moved[::3]                                          # ... and a few of those once more, after the others have started
+    for hb in (host, ref_host):
+        hb["voice_amp_envelope"]["sample_start"][again] += np.uint64(5 * 512 + 77)
+    db.update(host, again, dev.DIRTY_ENV_CLOCK)
+    for k in range(12):
+        block(f"c{k}")
+    got = host.copy()
+    db.download(got)
+    assert not got.rw_equal(ref_host), got.rw_equal(ref_host)
+    # (2) a new session on the same bank: upload first, then the clock goes back to 0
+    bank2, _, g2, _ = _late_note_bank(n)
+    e2 = bank2["voice_amp_envelope"]
+    e2["sample_start"][:] = 0
+    late2 = np.arange(5, n, 61)
+    e2["sample_start"][late2] = (700 + (late2 % 5) * 400).astype(np.uint64)
+    g2.synth_sample_count = 0
+    host, ref_host, ref_g = bank2.copy(), bank2.copy(), g2.copy()
+    db.upload(host)
+    db.set_globals(g2)
+    for k in range(9):
+        block(f"d{k}")
+    db.download(host)
+    assert db.list_violations() == 0
+    db.close()
+    assert not host.rw_equal(ref_host), host.rw_equal(ref_host)
 
 
 @pytest.mark.parametrize("interp,fast2", [(0, True), (1, True), (0, False), (1, False)])

@@ -41,5 +41,5 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(100): db.render_mix(F, out.data_ptr(), 2, 0, 0)
 torch.cuda.synchronize()
-print(f"steady               ms/block {(time.perf_counter() - t0) / 100 * 1e3:.4f}  env latch misses {db.env_latch_misses()}")
+print(f"steady               ms/block {(time.perf_counter() - t0) / 100 * 1e3:.4f}  list violations {db.list_violations()}")
 db.close()

@@ -124,9 +124,54 @@ def pmc_entry(workload):
         return None
 
 
+EVENT_PAIR_MS = 0.0        # what an EMPTY hipEvent pair on the render stream reads (calibrated once per run: main())
+ISSUE_PEAK = None          # tools/issue_rate on this box: VALU instructions a SIMD issues per second (main())
+
+
+def issue_peak():
+    """tools/issue_rate (built by __graft_entry__.build() from tools/issue_rate.hip) on THIS box: the rate at which a SIMD with
+    four resident waves issues plain fp32 VALU instructions (v_add_f32, independent chains), and packed ones.  None when the
+    binary is absent."""
+    exe = os.path.join(ROOT, "tools", "issue_rate")
+    if not os.path.exists(exe):
+        return None
+    import subprocess
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=60).stdout
+        for line in out.splitlines():
+            if line.startswith("PEAK "):
+                f = line.split()
+                return {"plain_per_simd": float(f[2]), "packed_per_simd": float(f[4]), "simds": int(f[6]), "clock_mhz": float(f[8]),
+                        "source": "tools/issue_rate.hip on this box: v_add_f32 / v_pk_add_f32, four independent chains, 4 waves per SIMD"}
+    except Exception:
+        pass
+    return None
+
+
+def valu_roofline(workload, voices, frames, k_mean):
+    """Second roofline of the line: the resource that actually binds the LDS-table banks.  achieved = VALU (wave) instructions
+    per launch, from the committed rocprofv3 PMC pass of this workload (SQ_INSTS_VALU, profiles/pmc_traffic.json), / this run's
+    kernel time; peak = SIMDs x the plain-fp32 issue rate tools/issue_rate measures on this box.  A packed instruction
+    (v_pk_*_f32: two voices' worth) occupies the VALU about 1.6x as long as a plain one, so a kernel that is half packed
+    cannot reach 1.0; `valu_busy_fraction` is the PMC's own SQ_ACTIVE_INST_VALU / cycles figure for the same pass."""
+    pm = pmc_entry(workload)
+    if not pm or not pm.get("valu_insts_per_launch") or pm.get("frames_per_launch") != frames or pm.get("voices") != voices or not ISSUE_PEAK:
+        return None
+    insts = pm["valu_insts_per_launch"]
+    peak = ISSUE_PEAK["plain_per_simd"] * ISSUE_PEAK["simds"]
+    ach = insts / (k_mean * 1e-3)
+    return {"bound": "valu", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": ach / peak,
+            "valu_insts_per_launch": insts, "valu_insts_per_voice_sample": insts / (voices * frames),
+            "valu_busy_fraction_pmc": pm.get("valu_busy_fraction"), "packed_issue_per_simd": ISSUE_PEAK["packed_per_simd"],
+            "peak_source": ISSUE_PEAK["source"], "insts_source": pm.get("valu_source", pm.get("source", ""))}
+
+
 def roofline(workload, voices, frames, gather_bytes, k_mean, k_min, k_cnt, kernel):
     B = gather_bytes + (STATE_READ + STATE_WRITE) / frames       # algorithmic bytes / voice-sample, SURVEY §8(d)
     launch_bytes = B * voices * frames
+    k_raw = k_mean
+    k_mean = max(k_mean - EVENT_PAIR_MS, 1e-6)                   # the event pair's own share of the bracket (calibrated per run)
+    k_min = max(k_min - EVENT_PAIR_MS, 1e-6)
     achieved = launch_bytes / (k_mean * 1e-3)
     pm = pmc_entry(workload)
     traffic = pm["hbm_bytes_per_launch"] if pm and pm.get("frames_per_launch") == frames and pm.get("voices") == voices else None
@@ -136,6 +181,7 @@ def roofline(workload, voices, frames, gather_bytes, k_mean, k_min, k_cnt, kerne
            "traffic_frac": None if traffic is None else traffic / (k_mean * 1e-3) / HBM_PEAK,
            "kernel": kernel, "frames_per_launch": frames,
            "kernel_ms_mean": k_mean, "kernel_ms_min": k_min, "launches_timed": k_cnt,
+           "kernel_ms_mean_raw": k_raw, "event_pair_ms": EVENT_PAIR_MS,
            "algorithmic_bytes_per_voice_sample": B, "algorithmic_bytes_per_launch": launch_bytes,
            "kernel_voice_samples_per_s": voices * frames / (k_mean * 1e-3)}
     if traffic is not None and pm.get("l2_read_requests_per_launch") and pm.get("l2_request_peak_per_s"):
@@ -167,6 +213,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="N = 1: only the main line (no other workloads / block lengths / legs)")
     ap.add_argument("--no-low-latency", action="store_true", help="(older name of --no-extra)")
     ap.add_argument("--no-fixed-point", action="store_true", help="skip the fixed-point leg")
+    ap.add_argument("--no-event-calibration", action="store_true", help="report bracketed kernel times as read (no empty-pair correction)")
     ap.add_argument("--no-recipe-warmup", action="store_true",
                     help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
     ap.add_argument("--time-every", type=int, default=0,
@@ -213,6 +260,20 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     every = a.time_every if a.time_every > 0 else min(8, max(1, a.steps // 10))
+
+    # what an empty event pair on the render stream reads: taken out of every bracketed kernel time (the pair's own
+    # few microseconds made kernel_ms_mean exceed ms_per_step on the small banks)
+    global EVENT_PAIR_MS, ISSUE_PEAK
+    if not a.no_event_calibration:
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        x = torch.zeros(1 << 20, device=dev)
+        for _ in range(3):
+            x.add_(1.0)                                   # (the stream is busy, as it is around a bracketed launch)
+            for e0, e1 in pairs:
+                e0.record(); e1.record()
+            torch.cuda.synchronize()
+        EVENT_PAIR_MS = float(np.median([e0.elapsed_time(e1) for e0, e1 in pairs]))
+    ISSUE_PEAK = issue_peak() if rank == 0 else None
 
     def fence():
         torch.cuda.synchronize()
@@ -367,6 +428,7 @@ def main():
     db, bank, tables, g, out = keep
     value = bank_voices * F * a.steps / dt
     rl.pop("value"); rl.pop("ms_per_step"); rl.pop("realtime_factor_48k"); rl.pop("voices")
+    vr = valu_roofline(a.workload, bank_voices, F, rl["kernel_ms_mean"])
     rl["note"] = ("LUTs are LDS-resident and the recurrences live in registers, so compulsory HBM traffic is one state sweep per "
                   "launch: at F=512 the kernel is bound by fp32 VALU issue (profiles/), not by HBM; the HBM fraction grows as F "
                   "shrinks (low_latency).  PCM banks (c4) gather from an L2-resident pool: see c4.l2_requests")
@@ -382,7 +444,20 @@ def main():
                    "seed": "0x5EED", "recipe_warmup_frames": warm[0], "spinup_blocks": warm[1]},
         "realtime_factor_48k": value / (bank_voices * 48000.0), "output_finite": finite, "roofline": rl,
     }
+    if vr:
+        res["roofline_valu"] = vr
     if not a.no_extra:
+        # ---- the same bank with LINEAR interpolation (north_star's lookup mode; the reference truncates): two LDS taps
+        if not interp:
+            def block_lin(frames):
+                db.render_mix(frames, out.data_ptr(), 2, 0, 1, stream)
+            dtl, kml, knl, kcl = timed(block_lin, db, F, a.steps, a.warmup, every)
+            rlin = roofline(a.workload, bank_voices, F, gather_bytes, kml, knl, kcl, KERNELS.get(db.last_kernel(), "?"))
+            rlin.pop("traffic", None); rlin.pop("traffic_rate", None); rlin.pop("traffic_frac", None)   # (the PMC pass was the truncating run)
+            rlin["value"] = bank_voices * F * a.steps / dtl
+            rlin["ms_per_step"] = dtl / a.steps * 1e3
+            rlin["interp"] = "linear"
+            res[a.workload + "_linear"] = rlin
         # ---- other block lengths on the same bank (state keeps running): F = 64 (1.33 ms callbacks: the per-launch state
         # sweep dominates and the kernel approaches the HBM roofline) and F = 4800 (100 ms blocks), SURVEY §8(d)
         for key, fr, steps, warmup, te in (("low_latency", 64, max(50, a.steps), 20, min(8, max(1, max(50, a.steps) // 10))),
@@ -467,9 +542,26 @@ def main():
             reps_w.sort()
             r["envelopes_in_motion"] = {"ms_per_step": reps_w[1] * 1e3, "value": r["voices"] * 512 / reps_w[1], "unit": "voice-samples/s",
                                         "blocks_timed": n_blocks_w, "repetitions": 3}
+            if not WORKLOADS[wl][2]:                      # ... and with linear interpolation (north_star's lookup mode)
+                db_w.upload(bank_w)
+                db_w.set_globals(g_w)
+
+                def block_wl(fr, _db=db_w, _o=out_w):
+                    _db.render_mix(fr, _o.data_ptr(), 2, 0, 1, stream)
+                recipe_warmup(block_wl, 512)
+                dtl, kml, knl, kcl = timed(block_wl, db_w, 512, steps_w, 20, min(8, max(1, steps_w // 10)))
+                rlin = roofline(wl, r["voices"], 512, WORKLOADS[wl][3], kml, knl, kcl, KERNELS.get(db_w.last_kernel(), "?"))
+                rlin.pop("traffic", None); rlin.pop("traffic_rate", None); rlin.pop("traffic_frac", None)
+                rlin["value"] = r["voices"] * 512 * steps_w / dtl
+                rlin["ms_per_step"] = dtl / steps_w * 1e3
+                rlin["interp"] = "linear"
+                res[wl + "_linear"] = rlin
             db_w.close()
             r["workload"] = DESCR[wl]
             r["output_finite"] = fin
+            vr_w = valu_roofline(wl, r["voices"], 512, r["kernel_ms_mean"])
+            if vr_w:
+                r["roofline_valu"] = vr_w
             res[wl] = r
 
     # ---- the fixed-point LUT path (include/skred_amd_fxpt.h; integer mix, exact)

@@ -1102,6 +1102,75 @@ def test_two_per_lane_kernel_full_size_c3(dev):
     assert rel_rms(mix, ref_mix) <= 1e-5
 
 
+def test_headline_block_at_full_size(dev):
+    """The exact block bench.py's headline times: BASELINE config 3 (2^20 voices), the recipe's 5 632 warm-up frames rendered
+    in 512-frame blocks (envelopes in motion: the envelope kernel beside the steady one, then the list runs empty), then ONE
+    512-frame all-sustain block on the steady two-per-lane kernel alone -- per-voice state of all 2^20 voices bit for bit and
+    the block's mix against the oracle (16 threads, parity flags)."""
+    import torch
+    n, F = 1 << 20, 512
+    bank, tables, g = banks.bank_c2(n)
+    ref_bank, ref_g = bank.copy(), g.copy()
+    threads = min(16, os.cpu_count() or 1)
+    warm = cpuref.render_mt(ref_bank, ref_g, tables, 11 * F, threads, 0, fast=False)
+    cpuref.master(ref_g, warm.astype(np.float32))              # (the master gain's recurrence runs through the warm-up too)
+    ref_sum = cpuref.render_mt(ref_bank, ref_g, tables, F, threads, 0, fast=False)
+    ref_mix = cpuref.master(ref_g, ref_sum.astype(np.float32))
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    out = torch.zeros(F, 2, device="cuda")
+    for _ in range(11):
+        db.render_mix(F, out.data_ptr(), 2, 0, 0)
+    torch.cuda.synchronize()
+    db.render_mix(F, out.data_ptr(), 2, 0, 0)
+    torch.cuda.synchronize()
+    assert db.last_kernel() == 3
+    got = bank.copy()
+    db.download(got)
+    assert db.list_violations() == 0
+    db.close()
+    assert not got.rw_equal(ref_bank), got.rw_equal(ref_bank)
+    assert rel_rms(out.cpu().numpy(), ref_mix) <= 1e-5
+
+
+def test_bank_at_the_size_ceiling(dev):
+    """SKRED_MAX_VOICES (2^24; include/skred_amd.h): a bank of exactly the documented ceiling renders, and -- voices being
+    independent -- every one of its 16 copies of a 2^20-voice bank ends in the state that bank ends in alone, bit for bit, with
+    16 x its pre-master sum (1e-5).  64 frames from the recipe's first frame: steady kernel, envelope kernel beside it, and the
+    motion list at 2^24 voices (index widths: the class of round 2's overflow)."""
+    import torch
+    n1, copies, F = 1 << 20, 16, 64
+    one, tables, g = banks.bank_c2(n1)
+    part1 = torch.zeros(F, 2, device="cuda")
+    db1 = dev.DeviceBank(n1)
+    db1.set_tables(tables)
+    db1.upload(one)
+    db1.set_globals(g)
+    db1.render(F, part1.data_ptr())
+    torch.cuda.synchronize()
+    end1 = one.copy()
+    db1.download(end1)
+    db1.close()
+    db = dev.DeviceBank(n1 * copies)
+    db.set_tables(tables)
+    for k in range(copies):
+        db.upload(one, 0, k * n1, n1)
+    db.set_globals(g)
+    part = torch.zeros(F, 2, device="cuda")
+    db.render(F, part.data_ptr())
+    torch.cuda.synchronize()
+    assert db.last_kernel() == 3
+    for k in (0, 7, copies - 1):
+        got = one.copy()
+        db.download(got, k * n1, 0, n1)
+        assert not got.rw_equal(end1), (k, got.rw_equal(end1))
+    assert db.list_violations() == 0
+    db.close()
+    assert rel_rms(part.cpu().numpy(), copies * part1.cpu().numpy().astype(np.float64)) <= 1e-5
+
+
 def test_two_operator_fm_full_size(dev):
     """A 2^20-voice two-operator FM bank of C2 voices (the bank tools/measure_banks.py times) on the kernel that keeps
     carrier and modulator in one lane, from the recipe's first frame (envelopes in motion: pairs are handed to the envelope

@@ -47,6 +47,11 @@ def main():
         e = {"frames_per_launch": 512, "voices": voices, "hbm_bytes_per_launch": summ["hbm_bytes_per_launch"]["total"],
              "algorithmic_bytes_per_launch": summ["hbm_bytes_per_launch"]["algorithmic_bytes_per_launch"],
              "source": f"profiles/{prefix}_{w}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled)"}
+        valu = summ["counters_mean_per_dispatch"].get("SQ_INSTS_VALU")
+        if valu:      # bench.py: roofline_valu (wave-level VALU instructions per launch; VALU-busy fraction of the same pass)
+            e["valu_insts_per_launch"] = valu
+            e["valu_busy_fraction"] = summ.get("valu_busy_fraction")
+            e["valu_source"] = f"profiles/{prefix}_{w}_pmc_summary.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, own pass)"
         if w == "c4":
             req = summ["counters_mean_per_dispatch"].get("TCP_TCC_READ_REQ_sum")
             if req:

@@ -36,9 +36,12 @@ int main() {
   (void)hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0);
   printf("reported shader clock: %d MHz\n", clk_khz / 1000);
   const char *names[] = {"v_add_f32, one dependent chain", "v_add_f32, four independent chains", "v_pk_add_f32, one dependent chain", "v_pk_add_f32, four independent chains"};
+  int cus = 256;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+  double per_simd[4] = {0, 0, 0, 0};                 // instructions per second and SIMD with 4 waves resident, per mode
   for (int m = 0; m < 4; ++m) {
     for (int wps = 1; wps <= 4; wps *= 2) {          // waves per SIMD: blocks of 4 waves, 256 CUs
-      const int blocks = 256 * wps;
+      const int blocks = cus * wps;
       float best = 1e9f;
       for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
@@ -56,7 +59,10 @@ int main() {
       const double n_inst = (double)iters * 64.0;
       const double cyc = best * 1e-3 * (clk_khz * 1e3) / n_inst;
       printf("%-40s %d wave(s)/SIMD: %.3f ms  -> %.2f cycles per instruction per wave (%.2f per SIMD)\n", names[m], wps, best, cyc, cyc / wps);
+      if (wps == 4) per_simd[m] = n_inst * wps / (best * 1e-3);
     }
   }
+  // what bench.py prices the kernels' VALU instruction rate against (independent chains: what a SIMD with four waves can issue)
+  printf("PEAK plain %.6e packed %.6e simds %d clock_mhz %d\n", per_simd[1], per_simd[3], cus * 4, clk_khz / 1000);
   return 0;
 }

@@ -213,6 +213,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="N = 1: only the main line (no other workloads / block lengths / legs)")
     ap.add_argument("--no-low-latency", action="store_true", help="(older name of --no-extra)")
     ap.add_argument("--no-fixed-point", action="store_true", help="skip the fixed-point leg")
+    ap.add_argument("--no-scaling-proxy", action="store_true", help="skip the strong_scaling_proxy leg (shard blocks of 2^17 .. 2^19 voices)")
     ap.add_argument("--no-event-calibration", action="store_true", help="report bracketed kernel times as read (no empty-pair correction)")
     ap.add_argument("--no-recipe-warmup", action="store_true",
                     help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
@@ -224,6 +225,11 @@ def main():
                          "needs ~25 ms of work before clocks and caches settle (20 steps right after first touch time ~10 %% slow)")
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="with one process: run the N > 1 code path (the shard's RCCL reduce, with one rank) on a single-GPU box")
+    ap.add_argument("--serial-collective", action="store_true",
+                    help="N > 1: render -> reduce -> master one after the other (skred_shard_render_mix); default: both forms are "
+                         "calibrated on 40 untimed blocks and the faster one is timed")
+    ap.add_argument("--pipelined-collective", action="store_true",
+                    help="N > 1: the collective of block k beside the render of block k + 1 (skred_shard_render_mix_pipelined)")
     ap.add_argument("--fast2-min-voices", type=int, default=-1,
                     help="override the bank size from which the two-voices-per-lane kernel is used (-1: library default)")
     a = ap.parse_args()
@@ -348,17 +354,38 @@ def main():
             sh.init_rccl(ids[0])
             if a.rehearse_dist and world == 1:
                 sh.set_reduce(None, always_reduce=True)
-        out = torch.zeros(F, 2, device=dev, dtype=torch.float32)
+        outs = [torch.zeros(F, 2, device=dev, dtype=torch.float32) for _ in range(2)]
+        out = outs[0]
+        kblk = [0]
 
         def block(frames):
-            sh.render_mix(frames, out.data_ptr(), 2, interp, stream)
+            # the pipelined form: the collective of block k runs beside the render of block k + 1 (two output buffers in turn)
+            if a.serial_collective:
+                sh.render_mix(frames, out.data_ptr(), 2, interp, stream)
+            else:
+                sh.render_mix_pipelined(frames, outs[kblk[0] & 1].data_ptr(), 2, interp, stream)
+                kblk[0] += 1
         warm = 0 if a.no_recipe_warmup else recipe_warmup(block, F)
         spun = spinup(block, F)
         fence()
+        calib = None
+        if not a.serial_collective and not a.pipelined_collective:
+            # which form of the block is faster HERE (it depends on what the collective costs on this node): 40 untimed blocks each
+            calib = {}
+            for form in ("serial", "pipelined"):
+                a.serial_collective = form == "serial"
+                dtc, _, _, _ = timed(block, sh.bank, F, 40, 8, 0)
+                calib[form + "_ms"] = dtc / 40 * 1e3
+            a.serial_collective = calib["serial_ms"] <= calib["pipelined_ms"]
         dt, k_mean, k_min, k_cnt = timed(block, sh.bank, F, a.steps, a.warmup, every)
-        finite = bool(torch.isfinite(out).all().item()) if rank == 0 else True
+        form_used = "serial" if a.serial_collective else "pipelined"
+        if calib is not None:
+            a.serial_collective = False
+        sh.flush(stream)
+        torch.cuda.synchronize()
+        finite = bool(all(torch.isfinite(o).all().item() for o in outs)) if rank == 0 else True
         res = {"dt": dt, "k": (k_mean, k_min, k_cnt), "kernel": KERNELS.get(sh.bank.last_kernel(), "?"), "finite": finite,
-               "warm": warm, "spun": spun, "n_local": sh.n_local}
+               "warm": warm, "spun": spun, "n_local": sh.n_local, "form": form_used, "calib": calib}
         sh.close()
         return res
 
@@ -379,7 +406,10 @@ def main():
                            "voices_total": total, "voices_per_gpu": m["n_local"], "frames_per_launch": F, "sample_rate": 48000,
                            "interp": "linear" if interp else "truncate",
                            "parallelism": f"voices block-partitioned over {world} GPU(s); one RCCL reduce(sum) of float[F][2] per launch "
-                                          "(skred_shard_render_mix: render + mix-down on every GPU -> ncclReduce -> master volume on rank 0)",
+                                          + ("(skred_shard_render_mix: render + mix-down on every GPU -> ncclReduce -> master volume on rank 0)" if m["form"] == "serial" else
+                                             "(skred_shard_render_mix_pipelined: render + mix-down on every GPU; ncclReduce + master volume of block k on a "
+                                             "second stream beside the render of block k + 1)"),
+                           "collective_form": m["form"], "collective_form_calibration": m["calib"],
                            "seed": "0x5EED", "recipe_warmup_frames": m["warm"], "spinup_blocks": m["spun"]},
                 "realtime_factor_48k": value / (total * 48000.0), "output_finite": m["finite"], "roofline": rl,
             }
@@ -563,6 +593,58 @@ def main():
             if vr_w:
                 r["roofline_valu"] = vr_w
             res[wl] = r
+
+    # ---- strong scaling, as far as ONE GPU can show it: the block of the shard BASELINE config 3 leaves each of 8 / 4 / 2 GPUs
+    # (2^17 / 2^18 / 2^19 voices), as a fused single-GPU block, through the N > 1 sequence with a one-rank RCCL reduce, and through
+    # the pipelined form of that sequence.  What an N-GPU run adds to these numbers is the collective's own latency (serial form) or
+    # nothing until it exceeds the render (pipelined form).
+    if not a.no_extra and a.workload == "c3" and not a.no_scaling_proxy:
+        proxy = {"what": "per-GPU shard of BASELINE config 3 on this ONE GPU: ms per 512-frame block.  fused: render + mix-down + master in one "
+                         "launch; serial / pipelined: the N > 1 sequence skred_shard_render_mix(_pipelined) -- sum-only render, master kernel, "
+                         "and for the pipelined form the two-stream event chain -- without a collective; rccl_1rank_*: the same with the "
+                         "library's own RCCL communicator of ONE rank in the sequence (a one-rank ncclReduce launches nothing on the stream it "
+                         "was first used on, but costs ~70 us of stream time on the pipelined form's second stream: not what an 8-rank reduce "
+                         "does; the 8-GPU run itself calibrates both forms and times the faster one)", "shards": {}}
+        steps_p = max(100, a.steps)
+        for gpus, n_sh in ((8, 1 << 17), (4, 1 << 18), (2, 1 << 19)):
+            ent = {"voices": n_sh}
+            try:
+                whole, tables_p, g_p = banks.RECIPES["c2"](n_sh)
+                for form in ("fused", "serial", "pipelined", "rccl_1rank_serial", "rccl_1rank_pipelined"):
+                    sh = Shard(n_sh, 0, 1, local)
+                    sh.bank.set_tables(tables_p)
+                    sh.upload(whole)
+                    sh.bank.set_globals(g_p)
+                    o2 = [torch.zeros(512, 2, device=dev, dtype=torch.float32) for _ in range(2)]
+                    kk = [0]
+                    if form.startswith("rccl"):
+                        sh.init_rccl(Shard.rccl_unique_id())
+                        sh.set_reduce(None, always_reduce=True)
+
+                    def blk(frames, _sh=sh, _o=o2, _kk=kk, _form=form):
+                        if _form == "fused":
+                            _sh.bank.render_mix(frames, _o[0].data_ptr(), 2, 0, 0, stream)
+                        elif _form.endswith("serial"):
+                            _sh.render_mix(frames, _o[0].data_ptr(), 2, 0, stream)
+                        else:
+                            _sh.render_mix_pipelined(frames, _o[_kk[0] & 1].data_ptr(), 2, 0, stream)
+                            _kk[0] += 1
+                    recipe_warmup(blk, 512)
+                    spinup(blk, 512)
+                    dtp, _, _, _ = timed(blk, sh.bank, 512, steps_p, 20, 0)
+                    ent[form + "_ms"] = dtp / steps_p * 1e3
+                    sh.close()
+                del whole
+            except Exception as ex:       # (a box without RCCL: the fused number stands alone)
+                ent["error"] = repr(ex)[:200]
+            proxy["shards"][f"1/{gpus}"] = ent
+        one = res["ms_per_step"]
+        for key, ent in proxy["shards"].items():
+            gpus = int(key.split("/")[1])
+            for form in ("serial", "pipelined"):
+                if form + "_ms" in ent:
+                    ent[form + "_speedup_if_collective_were_free"] = one / ent[form + "_ms"]
+        res["strong_scaling_proxy"] = proxy
 
     # ---- the fixed-point LUT path (include/skred_amd_fxpt.h; integer mix, exact)
     if not a.no_extra and not a.no_fixed_point and a.workload != "c4":

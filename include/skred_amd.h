@@ -361,6 +361,14 @@ int  skred_shard_init_rccl(skred_shard_t *shard, const void *unique_id128);
  * Asynchronous on `stream` with the bank-backed steps. */
 int  skred_shard_render_mix(skred_shard_t *shard, int num_frames, int interp, float *partial, float *out, int num_channels, void *stream);
 
+/* The same block with the collective of block k overlapped with the render of block k + 1 (two partial buffers, the
+ * collective and the root's master stage on a stream of the shard's own, chained by events): throughput is bounded by
+ * max(render, reduce + master) instead of their sum.  `out` of call k is complete on `stream` once call k + 1 -- or
+ * skred_shard_flush -- has returned (one block of latency): alternate between two output buffers.  Same samples as
+ * skred_shard_render_mix, bit for bit.  Custom steps (host memory) run synchronously, in order. */
+int  skred_shard_render_mix_pipelined(skred_shard_t *shard, int num_frames, int interp, float *out, int num_channels, void *stream);
+int  skred_shard_flush(skred_shard_t *shard, void *stream);
+
 /* Timing of the most recent skred_bank_render() on its stream, via hipEvents
  * recorded around the render kernel itself (ms; <0 if unavailable). Synchronises. */
 float skred_bank_last_render_ms(skred_bank_t *bank);

@@ -127,6 +127,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   b->fast2_min_voices = SK_FAST2_MIN_VOICES;
   b->fm2_min_voices = SK_FM2_MIN_VOICES;
   b->timing_every = 1;
+  b->pp_parity = -1;
   b->n_padded = b->n_groups * SK_GROUP;
   b->class_dirty = 1;
   b->mod_dirty = 1;
@@ -484,12 +485,14 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   /* rows of the partial mix, the slab sums of the two-level mix-down, the per-frame master gains, and (when the envelope kernel
    * runs beside) its rows and its sum: one allocation */
   const size_t row = (size_t)num_frames * 2;
-  const size_t gains_at = ((size_t)n_wg + SK_FINISH_SLABS) * row;
-  const size_t env_at = (gains_at + (size_t)num_frames + 3) & ~(size_t)3;          /* 16-byte aligned */
+  const size_t gains_at = ((size_t)n_wg + SK_FINISH_SLABS) * row;                  /* (two rows of gains: the pipelined sum-only form alternates) */
+  const size_t env_at = (gains_at + 2 * (size_t)num_frames + 3) & ~(size_t)3;      /* 16-byte aligned */
+  if (env_at + ((size_t)n_env + 1) * row > b->partial_cap && b->pp_parity >= 0) HIP_TRY(hipDeviceSynchronize());   /* (a master stage of the pipelined form may still read the old rows) */
   if ((rc = grow(&b->d_partial, &b->partial_cap, env_at + ((size_t)n_env + 1) * row))) return rc;
+  const int pp = b->pp_parity >= 0 && !d_out;      /* pipelined sum-only form: skred_shard_render_mix_pipelined */
   a.partial = b->d_partial;
   a.slab_rows = b->d_partial + (size_t)n_wg * row;
-  a.gains = b->d_partial + gains_at;
+  a.gains = b->d_partial + gains_at + (pp && b->pp_parity ? (size_t)num_frames : 0);
   a.env_rows = b->d_partial + env_at;
   a.env_sum = a.env_rows + (size_t)n_env * row;
   a.env_ticket = b->d_tickets + SK_FINISH_SLABS + 1;
@@ -507,8 +510,10 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   a.mix_out = d_out;
   a.num_channels = num_channels;
   a.gain_state = b->d_gain_state;
-  a.gain_commit = d_out ? b->d_gain_state : b->d_gain_state + 1;
-  b->gains_frames = d_out ? 0 : num_frames;  /* gains for a block of this many frames are waiting for skred_bank_master */
+  /* (pipelined form: the NEXT block's render starts before this block's master stage has run, so the render commits the
+   * carried gain itself and the master stage, sk_bank_master_pp, only scales) */
+  a.gain_commit = (d_out || pp) ? b->d_gain_state : b->d_gain_state + 1;
+  b->gains_frames = (d_out || pp) ? 0 : num_frames;  /* gains for a block of this many frames are waiting for skred_bank_master */
   a.tickets = b->d_tickets;
   a.vol_target = b->g.volume_final;
   a.vol_k = b->g.volume_smoother_smoothing;
@@ -562,6 +567,27 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
 int skred_bank_render(skred_bank_t *b, int num_frames, int interp, float *d_partial, float *d_stems, void *stream) {
   if (!b || !d_partial || num_frames <= 0) return fail(SKRED_E_BAD_ARG, "render: bad arguments");
   return render_block(b, num_frames, interp, d_stems, d_partial, NULL, 0, (hipStream_t)stream);
+}
+
+/* The two halves of a block in the PIPELINED multi-GPU form (skred_shard.c: skred_shard_render_mix_pipelined): the render of block
+ * k + 1 runs while the collective and the master stage of block k are still under way on another stream, so the per-frame gains
+ * live in two alternating rows (`parity`) and the carried gain is committed by the render. */
+int sk_bank_render_sum_pp(skred_bank_t *b, int num_frames, int interp, float *d_sum, int parity, void *stream) {
+  if (!b || !d_sum || num_frames <= 0) return fail(SKRED_E_BAD_ARG, "render_sum_pp: bad arguments");
+  b->pp_parity = parity & 1;
+  const int rc = render_block(b, num_frames, interp, NULL, d_sum, NULL, 0, (hipStream_t)stream);
+  b->pp_parity = -1;
+  return rc;
+}
+
+int sk_bank_master_pp(skred_bank_t *b, const float *d_sum, int num_frames, int num_channels, float *d_out, int parity, void *stream) {
+  if (!b || !d_sum || !d_out || num_frames <= 0 || num_channels < 2 || !b->d_partial) return fail(SKRED_E_BAD_ARG, "master_pp: bad arguments");
+  HIP_TRY(hipSetDevice(b->device));
+  const float *gains = b->d_partial + b->gains_offset + ((parity & 1) ? (size_t)num_frames : 0);
+  /* (nothing to commit: slots 2 and 3 of the gain state are scratch) */
+  const hipError_t e = (hipError_t)sk_launch_master_apply(d_sum, gains, d_out, num_frames, num_channels, b->d_gain_state + 2, b->d_gain_state + 3, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "master launch -> %s", hipGetErrorString(e));
+  return SKRED_OK;
 }
 
 int skred_bank_render_mix(skred_bank_t *b, int num_frames, int interp, float *d_out, int num_channels,

@@ -41,6 +41,7 @@ struct skred_bank {
   uint32_t *d_tickets;        /* [SK_FINISH_SLABS + 1] arrival counters of the in-kernel mix-down */
   int timing_every;           /* SKRED_OPT_KERNEL_TIMING: bracket every n-th launch's render kernels with an event pair (0: none) */
   float *d_gain_state;        /* [0] master smoother gain carried between blocks; [1] the gain a sum-only render prepared for skred_bank_master */
+  int pp_parity;              /* >= 0 only inside sk_bank_render_sum_pp: which of the two gain rows the sum-only render fills */
   int gains_frames;           /* > 0: the latest skred_bank_render() left the master gains of a block of this many frames in d_partial */
   size_t gains_offset;        /* ... at this float offset */
   float *d_out, *d_stems;     /* scratch of skred_bank_render_host */
@@ -139,6 +140,9 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
                   sk_plane_t ro[SKP_COUNT], sk_plane_t rw[SKS_COUNT], sk_voice_meta_t *meta);
 /* params_travel: the parameter planes were written, so `meta` applies (a pure clock / state update leaves the classes alone) */
 void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *meta, int params_travel);
+/* the pipelined multi-GPU form's two halves of a block (skred_bank.c; used by skred_shard.c) */
+int sk_bank_render_sum_pp(skred_bank_t *b, int num_frames, int interp, float *d_sum, int parity, void *stream);
+int sk_bank_master_pp(skred_bank_t *b, const float *d_sum, int num_frames, int num_channels, float *d_out, int parity, void *stream);
 void sk_queue_free(skred_bank_t *b);
 void sk_patterns_free(skred_bank_t *b);
 /* a control action reached the bank: what earlier launches reported about envelope activity no longer holds (the voices it

@@ -33,6 +33,12 @@ struct skred_shard {
   int device;
   float *d_partial;                  /* [F][2] scratch when the caller passes none */
   size_t partial_cap;
+  /* pipelined form (skred_shard_render_mix_pipelined): two partial buffers, the collective's own stream, event chain */
+  float *pp_buf[2];                  /* device memory (bank-backed steps) or host memory (custom steps) */
+  size_t pp_cap;
+  unsigned pp_k;                     /* blocks issued */
+  hipStream_t pp_comm;
+  hipEvent_t pp_rendered[2], pp_done[2];
   /* library-owned RCCL communicator */
   void *rccl_lib;
   void *comm;
@@ -125,6 +131,12 @@ void skred_shard_destroy(skred_shard_t *s) {
   if (!s) return;
   if (s->comm && s->nccl_comm_destroy) (void)s->nccl_comm_destroy(s->comm);
   if (s->d_partial) { (void)hipSetDevice(s->device); (void)hipFree(s->d_partial); }
+  for (int i = 0; i < 2; i++) {
+    if (s->pp_buf[i]) { if (s->bank) (void)hipFree(s->pp_buf[i]); else free(s->pp_buf[i]); }
+    if (s->pp_rendered[i]) (void)hipEventDestroy(s->pp_rendered[i]);
+    if (s->pp_done[i]) (void)hipEventDestroy(s->pp_done[i]);
+  }
+  if (s->pp_comm) (void)hipStreamDestroy(s->pp_comm);
   if (s->bank) skred_bank_destroy(s->bank);
   /* the RCCL handle stays open: the process may hold other communicators on it */
   free(s);
@@ -237,4 +249,83 @@ int skred_shard_render_mix(skred_shard_t *s, int num_frames, int interp, float *
   }
   if (s->rank == s->root) rc = s->ops.master(s->ops.ctx, partial, num_frames, num_channels, out, stream);
   return rc;
+}
+
+/* ------------------------------------------------------------------ one block, pipelined */
+
+/* The same three steps with the collective of block k overlapped with the render of block k + 1: the render runs on `stream`
+ * into one of two partial buffers; reduce and master stage follow on the shard's own stream behind an event; `stream` only
+ * waits for them one call later.  Throughput is bounded by max(render, reduce + master) instead of their sum -- the block
+ * of a strong-scaling shard is short (2^17 voices: ~56 us) and the 8-rank reduce of 4 KiB is pure latency, so the sum is what
+ * kept 8 GPUs at ~3.3x one ("Mid-size banks").
+ *
+ * Contract: `out` of call k is complete on `stream` once call k + 1 (or skred_shard_flush) has returned -- one block of
+ * latency --, so consecutive calls must alternate between (at least) two output buffers.  Same samples as
+ * skred_shard_render_mix, bit for bit (tests/c_shard_smoke.c).  With custom steps (host memory, synchronous) the calls simply
+ * run in order: the CPU rehearsal exercises the buffer rotation, not the overlap. */
+static int pp_setup(skred_shard_t *s, size_t need) {
+  if (need <= s->pp_cap) return SKRED_OK;
+  for (int i = 0; i < 2; i++) {
+    if (s->bank) {
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipDeviceSynchronize());
+      if (s->pp_buf[i]) { (void)hipFree(s->pp_buf[i]); s->pp_buf[i] = NULL; }
+      HIP_TRY(hipMalloc((void **)&s->pp_buf[i], need * sizeof(float)));
+    } else {
+      free(s->pp_buf[i]);
+      s->pp_buf[i] = (float *)malloc(need * sizeof(float));
+      if (!s->pp_buf[i]) return fail(SKRED_E_NO_MEM, "pipelined partial buffers");
+    }
+  }
+  s->pp_cap = need;
+  if (s->bank && !s->pp_comm) {
+    HIP_TRY(hipStreamCreateWithFlags(&s->pp_comm, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      HIP_TRY(hipEventCreateWithFlags(&s->pp_rendered[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&s->pp_done[i], hipEventDisableTiming));
+    }
+  }
+  return SKRED_OK;
+}
+
+int skred_shard_render_mix_pipelined(skred_shard_t *s, int num_frames, int interp, float *out, int num_channels, void *stream) {
+  if (!s || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "shard_render_mix_pipelined: bad arguments");
+  if (s->rank == s->root && !out) return fail(SKRED_E_BAD_ARG, "shard_render_mix_pipelined: the root needs an output buffer");
+  int rc = pp_setup(s, (size_t)num_frames * 2);
+  if (rc) return rc;
+  const int p = (int)(s->pp_k & 1u);
+  const int collective = s->world > 1 || s->always_reduce;
+  if (collective && !s->ops.reduce) return fail(SKRED_E_BAD_ARG, "shard_render_mix_pipelined: a reduce step is required but none was given");
+  const int device_steps = s->bank && s->ops.render == bank_render && s->ops.master == bank_master;
+  if (!device_steps) {
+    /* custom steps: host memory, synchronous -- in order, through the rotating buffers */
+    if ((rc = s->ops.render(s->ops.ctx, num_frames, interp, s->pp_buf[p], stream))) return rc;
+    if (collective && (rc = s->ops.reduce(s->ops.reduce_ctx, s->pp_buf[p], (size_t)num_frames * 2, s->root, stream))) return rc;
+    if (s->rank == s->root) rc = s->ops.master(s->ops.ctx, s->pp_buf[p], num_frames, num_channels, out, stream);
+    s->pp_k++;
+    return rc;
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t main_s = (hipStream_t)stream;
+  /* (buffer p was last read by the collective of block k - 2: `main_s` waited for that at the end of call k - 1) */
+  if ((rc = sk_bank_render_sum_pp(s->bank, num_frames, interp, s->pp_buf[p], p, main_s))) return rc;
+  HIP_TRY(hipEventRecord(s->pp_rendered[p], main_s));
+  HIP_TRY(hipStreamWaitEvent(s->pp_comm, s->pp_rendered[p], 0));
+  if (collective && (rc = s->ops.reduce(s->ops.reduce_ctx, s->pp_buf[p], (size_t)num_frames * 2, s->root, s->pp_comm))) return rc;
+  if (s->rank == s->root && (rc = sk_bank_master_pp(s->bank, s->pp_buf[p], num_frames, num_channels, out, p, s->pp_comm))) return rc;
+  HIP_TRY(hipEventRecord(s->pp_done[p], s->pp_comm));
+  /* the block before this one is complete on `main_s` from here on (its collective ran beside this block's render) */
+  if (s->pp_k >= 1) HIP_TRY(hipStreamWaitEvent(main_s, s->pp_done[p ^ 1], 0));
+  s->pp_k++;
+  return SKRED_OK;
+}
+
+/* `stream` waits for everything the pipelined calls have issued: the last block's output is complete on it afterwards */
+int skred_shard_flush(skred_shard_t *s, void *stream) {
+  if (!s) return fail(SKRED_E_BAD_ARG, "shard_flush");
+  if (s->pp_k >= 1 && s->pp_comm) {
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, s->pp_done[(s->pp_k - 1) & 1u], 0));
+  }
+  return SKRED_OK;
 }

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "skred_bank_update", "skred_bank_defer", "skred_bank_run_queue", "skred_bank_queue_pending",
     "skred_shard_partition", "skred_shard_cut_ok", "skred_shard_create", "skred_shard_create_custom", "skred_shard_destroy",
     "skred_shard_bank", "skred_shard_range", "skred_shard_upload", "skred_shard_set_ops", "skred_shard_rccl_unique_id",
-    "skred_shard_init_rccl", "skred_shard_render_mix",
+    "skred_shard_init_rccl", "skred_shard_render_mix", "skred_shard_render_mix_pipelined", "skred_shard_flush",
     "skred_seq_create", "skred_seq_destroy", "skred_seq_tempo_set", "skred_seq_time_per_step", "skred_seq_step_set",
     "skred_seq_mute_set", "skred_seq_modulo_set", "skred_seq_state_set", "skred_seq_pattern_reset", "skred_seq_pointer",
     "skred_seq_counter", "skred_seq_tick",

@@ -47,6 +47,8 @@ def _lib():
         L.skred_shard_rccl_unique_id.argtypes = [vp]
         L.skred_shard_init_rccl.argtypes = [vp, vp]
         L.skred_shard_render_mix.argtypes = [vp, i32, i32, vp, vp, i32, vp]
+        L.skred_shard_render_mix_pipelined.argtypes = [vp, i32, i32, vp, i32, vp]
+        L.skred_shard_flush.argtypes = [vp, vp]
         L._shard_ready = True
     return L
 
@@ -117,6 +119,21 @@ class Shard:
         _check(self.L.skred_shard_render_mix(self.h, frames, interp, d_partial or None, d_out or None, channels, stream or None),
                "skred_shard_render_mix")
 
+    def render_mix_pipelined(self, frames: int, d_out: int, channels: int = 2, interp: int = 0, stream: int = 0):
+        """The collective of this block runs beside the render of the next one; `d_out` is complete on `stream` after the next
+        call or flush(): alternate between two output buffers."""
+        _check(self.L.skred_shard_render_mix_pipelined(self.h, frames, interp, d_out or None, channels, stream or None),
+               "skred_shard_render_mix_pipelined")
+
+    def flush(self, stream: int = 0):
+        _check(self.L.skred_shard_flush(self.h, stream or None), "skred_shard_flush")
+
+    def step_pipelined(self, out: np.ndarray, interp: int = 0) -> None:
+        """The same block through skred_shard_render_mix_pipelined (the library's own rotating partial buffers)."""
+        assert out.dtype == np.float32 and out.flags.c_contiguous
+        _check(self.L.skred_shard_render_mix_pipelined(self.h, out.shape[0], interp, out.ctypes.data, out.shape[1], None),
+               "skred_shard_render_mix_pipelined")
+
     def close(self):
         if getattr(self, "h", None):
             self.L.skred_shard_destroy(self.h)
@@ -172,6 +189,12 @@ class ShardedRender:
         assert partial.dtype == np.float32 and out.dtype == np.float32 and partial.flags.c_contiguous and out.flags.c_contiguous
         _check(self.L.skred_shard_render_mix(self.h, partial.shape[0], interp, partial.ctypes.data, out.ctypes.data,
                                              out.shape[1], None), "skred_shard_render_mix")
+
+    def step_pipelined(self, out: np.ndarray, interp: int = 0) -> None:
+        """The same block through skred_shard_render_mix_pipelined (the library's own rotating partial buffers)."""
+        assert out.dtype == np.float32 and out.flags.c_contiguous
+        _check(self.L.skred_shard_render_mix_pipelined(self.h, out.shape[0], interp, out.ctypes.data, out.shape[1], None),
+               "skred_shard_render_mix_pipelined")
 
     def close(self):
         if getattr(self, "h", None):

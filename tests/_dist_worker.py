@@ -19,6 +19,7 @@ from skred_amd.sharded import ShardedRender, modulation_components_ok, partition
 
 def main():
     out_path, n, frames, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    pipelined = len(sys.argv) > 5 and sys.argv[5] == "pipelined"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     full, tables, g = banks.bank_c2(n)
@@ -44,7 +45,10 @@ def main():
     out = np.zeros((frames, 2), np.float32)
     outs = []
     for _ in range(steps):
-        sh.step(partial, out)
+        if pipelined:                 # skred_shard_render_mix_pipelined: the library's own rotating partial buffers
+            sh.step_pipelined(out)
+        else:
+            sh.step(partial, out)
         if rank == 0:
             outs.append(out.copy())
     sh.close()

@@ -48,8 +48,8 @@ def test_cut_check_refuses_modulation_across_ranks():
     assert not modulation_components_ok(bank, 256, 512)
 
 
-@pytest.mark.parametrize("world,n", [(2, 2048), (3, 1000)])
-def test_sharded_matches_single_process(tmp_path, world, n):
+@pytest.mark.parametrize("world,n,form", [(2, 2048, "serial"), (3, 1000, "serial"), (2, 2048, "pipelined")])
+def test_sharded_matches_single_process(tmp_path, world, n, form):
     frames, steps = 256, 3
     out = str(tmp_path / "mix.npy")
     port = free_port()
@@ -58,7 +58,7 @@ def test_sharded_matches_single_process(tmp_path, world, n):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), out,
-                                       str(n), str(frames), str(steps)], env=env))
+                                       str(n), str(frames), str(steps), form], env=env))
     for p in procs:
         assert p.wait(timeout=240) == 0
     got = np.load(out)

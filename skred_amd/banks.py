@@ -149,6 +149,7 @@ def bank_c1(n: int = 4096, sample_rate: int = 48000, seed: int = SEED) -> Tuple[
     b = VoiceBank(n)
     freq = _common(b, u[0], u[1], u[2], sample_rate, g.synth_sample_count)
     table = sine_table(4096)
+    table = np.concatenate([table, table[:1]])     # guard sample: the table's first value once more behind it (SKF_GUARD)
     b["voice_table_offset"] = 0
     b["voice_table_size"] = 4096
     b["voice_loop_start_f"], b["voice_loop_end_f"] = 0.0, 4095.0   # wave_loop_end = size-1 (synth.c:1229), unused: loop off
@@ -166,13 +167,16 @@ def bank_c2(n: int = 65536, sample_rate: int = 48000, seed: int = SEED) -> Tuple
     u = lcg_uniform(5 * n, seed).reshape(5, n)
     b = VoiceBank(n)
     freq = _common(b, u[0], u[1], u[2], sample_rate, g.synth_sample_count)
-    # pool = all notamy float LUTs, in file order
+    # pool = all notamy float LUTs, in file order, each followed by a GUARD sample (its first value once more): a voice that
+    # loops over a whole table then finds the second tap of the linear lookup in the next float, whatever the index
+    # (include/skred_amd.h: skred_bank_set_tables_f32; skred_device_layout.h: SKF_GUARD) -- the samples are the same either way
     offs, pos, pool = {}, 0, []
     for nm in names:
         t = z["f32_" + nm]
         offs[nm] = pos
         pool.append(t)
-        pos += len(t)
+        pool.append(t[:1])
+        pos += len(t) + 1
     pool = np.concatenate(pool).astype(np.float32)
     fam = np.arange(n) % 3
     t_off = np.zeros(n, np.int64)

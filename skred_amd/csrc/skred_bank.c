@@ -148,6 +148,7 @@ void skred_bank_destroy(skred_bank_t *b) {
   hipSetDevice(b->device);
   if (b->d_planes) hipFree(b->d_planes);
   if (b->d_tables) hipFree(b->d_tables);
+  free(b->h_tables);
   if (b->d_partial) hipFree(b->d_partial);
   if (b->d_tickets) hipFree(b->d_tickets);
   if (b->d_gain_state) hipFree(b->d_gain_state);
@@ -192,6 +193,11 @@ int skred_bank_set_tables_f32(skred_bank_t *b, const float *pool, size_t n_float
   HIP_TRY(hipMalloc((void **)&b->d_tables, b->table_floats_padded * sizeof(float)));
   HIP_TRY(hipMemset(b->d_tables, 0, b->table_floats_padded * sizeof(float)));
   HIP_TRY(hipMemcpy(b->d_tables, pool, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  free(b->h_tables);
+  b->h_tables = (float *)malloc(n_floats * sizeof(float));
+  if (!b->h_tables) return fail(SKRED_E_NO_MEM, "set_tables: host copy of the pool");
+  memcpy(b->h_tables, pool, n_floats * sizeof(float));
+  b->tables_epoch++;                    /* voices packed against the old pool carry its guard flags: see render_block */
   return SKRED_OK;
 }
 
@@ -225,7 +231,7 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
                                    hipMemcpyHostToDevice);
   free(st);
   if (e != hipSuccess) { free(meta); HIP_TRY(e); }
-  if (dst_first == 0 && count == b->n_voices) b->features = 0;                /* whole bank replaced */
+  if (dst_first == 0 && count == b->n_voices) { b->features = 0; b->guard_epoch = b->tables_epoch; }   /* whole bank replaced */
   for (int i = 0; i < count; i++) sk_apply_meta(b, dst_first + i, &meta[i], 1);
   free(meta);
   sk_control_changed(b);
@@ -456,6 +462,11 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     a.fast_mode |= SKM_TWO_PER_LANE;
   else
     a.fast_mode &= ~(SKM_FM_PAIR | SKM_PAIR_AP);
+  /* linear lookup on a bank whose every real voice loops over its whole table with a guard sample behind it: the specialised
+   * kernels' instantiations without the fold test (two-operator FM banks keep the general form) */
+  if (interp == SKRED_INTERP_LINEAR && (a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_FM_PAIR) && !modulated && b->cnt_real > 0 &&
+      b->cnt_guard == b->cnt_real && b->guard_epoch == b->tables_epoch)
+    a.interp = 2;
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
   if (modulated) b->last_kernel = SKRED_KERNEL_MODULATED;

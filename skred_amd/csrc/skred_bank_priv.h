@@ -34,6 +34,7 @@ struct skred_bank {
   sk_plane_t *d_ro[SKP_COUNT];
   sk_plane_t *d_rw[SKS_COUNT];
   float *d_tables;
+  float *h_tables;            /* host copy of the pool (sk_pack_voice looks for guard samples: SKF_GUARD) */
   size_t table_floats;        /* real pool size       */
   size_t table_floats_padded; /* rounded up to 4      */
   float *d_partial;           /* [n_wg][F][2] workgroup rows, then [SK_FINISH_SLABS][F][2] slab sums, then [F] master gains */
@@ -69,6 +70,8 @@ struct skred_bank {
   int max_level;
   int class_dirty;
   int cnt_real, cnt_filter, cnt_env, cnt_exotic, cnt_stops, cnt_fm;   /* voices per SKC_* bit (kept incrementally) */
+  int cnt_guard;              /* real voices with SKC_GUARD */
+  uint32_t tables_epoch, guard_epoch;   /* pools set so far; the pool the whole bank was last packed against (guard flags are a property of the pool) */
   int cnt_pair_ap;            /* pair-shaped carriers whose amplitude or pan is modulated too (SKC_PAIR_AP) */
   int cnt_fm_odd;             /* SKC_FM voices that are not the even half of a (carrier, next voice) pair (SKC_FM_ODD) */
   int cnt_escapes;            /* voices naming a modulator outside their aligned 64-voice group (SKC_ESCAPES) */
@@ -114,6 +117,8 @@ struct skred_bank {
 #define SKC_FM_ODD 256u /* an SKC_FM voice that is anything but: even index, frequency-modulated by the voice after it and by nothing else
                           -- the shape sk_render_fast2_kernel<FMP> renders with carrier and modulator in one lane */
 #define SKC_PAIR_AP 512u /* a pair-shaped carrier whose amplitude or pan is modulated (by the voice after it or by itself) */
+#define SKC_GUARD 64u   /* loops over its whole table with a guard sample behind it (SKF_GUARD): when every real voice does, the
+                           linear lookup runs the instantiations without the fold test */
 #define SKC_ESCAPES 128u /* names a modulator outside its aligned 64-voice group: the bank cannot be rendered until that is fixed */
 
 

@@ -53,6 +53,11 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
   if (h->voice_smoother_enable[v]) flags |= SKF_SMOOTH;
   if (h->voice_disconnect[v]) flags |= SKF_MUTED;
   if (noise) { flags |= SKF_NOISE; features |= SKB_ANY_NOISE; }
+  /* a guard sample behind a table that is looped as a whole: the linear lookup's second tap never folds (SKF_GUARD) */
+  if (usable && !noise && !windowed && b->h_tables && (uint64_t)off + (uint64_t)size < b->table_floats &&
+      !(h->voice_one_shot[v] && !h->voice_loop_enabled[v]) &&     /* (a one-shot that plays to its end does not fold: its neighbour clamps) */
+      memcmp(&b->h_tables[off + size], &b->h_tables[off], sizeof(float)) == 0)
+    flags |= SKF_GUARD;
   const int has_mod = h->voice_freq_mod_osc[v] >= 0 || h->voice_amp_mod_osc[v] >= 0 ||
                       h->voice_pan_mod_osc[v] >= 0 || h->voice_cz_mode[v] != 0;
   /* Modulation the one-per-lane kernel can serve: FM / AM / pan by a HIGHER-indexed voice of the same aligned
@@ -79,6 +84,7 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
   {
     uint16_t c = 0;
     if (usable || noise) c |= SKC_REAL;
+    if (flags & SKF_GUARD) c |= SKC_GUARD;
     if (h->voice_filter_mode[v]) c |= SKC_FILTER;
     if (h->voice_use_amp_envelope[v]) c |= SKC_ENV;
     const int stops = h->voice_one_shot[v] && !h->voice_loop_enabled[v];
@@ -156,8 +162,8 @@ void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m, int param
   if (!params_travel) return;
   const uint16_t old = b->h_class[dst], now = m->cls;
   if (old != now) {
-    if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; if (old & SKC_STOPS) b->cnt_stops--; if (old & SKC_FM) b->cnt_fm--; if (old & SKC_FM_ODD) b->cnt_fm_odd--; if (old & SKC_PAIR_AP) b->cnt_pair_ap--; }
-    if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; if (now & SKC_STOPS) b->cnt_stops++; if (now & SKC_FM) b->cnt_fm++; if (now & SKC_FM_ODD) b->cnt_fm_odd++; if (now & SKC_PAIR_AP) b->cnt_pair_ap++; }
+    if (old & SKC_REAL) { b->cnt_real--; if (old & SKC_FILTER) b->cnt_filter--; if (old & SKC_ENV) b->cnt_env--; if (old & SKC_EXOTIC) b->cnt_exotic--; if (old & SKC_STOPS) b->cnt_stops--; if (old & SKC_FM) b->cnt_fm--; if (old & SKC_FM_ODD) b->cnt_fm_odd--; if (old & SKC_PAIR_AP) b->cnt_pair_ap--; if (old & SKC_GUARD) b->cnt_guard--; }
+    if (now & SKC_REAL) { b->cnt_real++; if (now & SKC_FILTER) b->cnt_filter++; if (now & SKC_ENV) b->cnt_env++; if (now & SKC_EXOTIC) b->cnt_exotic++; if (now & SKC_STOPS) b->cnt_stops++; if (now & SKC_FM) b->cnt_fm++; if (now & SKC_FM_ODD) b->cnt_fm_odd++; if (now & SKC_PAIR_AP) b->cnt_pair_ap++; if (now & SKC_GUARD) b->cnt_guard++; }
     /* per-voice bits that are not kernel classes: counted whether or not the voice can sound, and recounted whenever the
      * voice is written again -- a routing that escaped its group stops blocking the bank once it is fixed */
     b->cnt_escapes += ((now & SKC_ESCAPES) != 0) - ((old & SKC_ESCAPES) != 0);

@@ -53,6 +53,10 @@ enum {
 #define SKF_NOISE      (1u << 7)   /* voice_wave_table_index == WAVE_TABLE_NOISE_ALT   */
 #define SKF_INERT      (1u << 8)   /* padding voice, or a voice without a table: always skipped */
 #define SKF_HAS_MOD    (1u << 9)   /* names another voice as FM/AM/pan/CZ modulator, or uses CZ */
+#define SKF_GUARD      (1u << 10)  /* the voice loops over its WHOLE table (lo == 0, hi == table_size) and the pool holds a guard sample behind
+                                      the table, equal to its first one: the second tap of the linear lookup is always the next float, the
+                                      fold at the loop end (oracle/cpu_ref.c: table_fetch) needs no test.  A property of the caller's pool,
+                                      checked per voice when it is packed (skred_bank_update.c) */
 
 /* rwflags word of SKS_FILT */
 #define SKR_FINISHED   (1u << 0)   /* voice_finished                 */

@@ -70,6 +70,15 @@ __device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__r
   if (!NOCLAMP) idx = max(min(idx, r.tsize_m1), 0);          // clamp, synth.c:271-272
   const char *tab = TAB_LDS ? lds_tab : glb_tab;
   if (INTERP == 0) return *reinterpret_cast<const float *>(tab + (r.toff4 + (idx << 2)));
+  if (INTERP == 2 && NOCLAMP) {
+    // linear, and EVERY live voice of the bank loops over its whole table with a guard sample behind it (SKF_GUARD; the host
+    // picks this instantiation): the second tap is always the next float -- no fold test, no third gather; the fraction is
+    // v_fract_f32 (pos - floor(pos): the same exact difference as pos - (float)(int)pos for pos >= 0).  Same products, same
+    // sums as the form below and as oracle/cpu_ref.c: table_fetch.
+    const tap_pair_t pg = TAB_LDS ? *reinterpret_cast<const tap_pair_t *>(tab + (r.toff4 + (idx << 2)))
+                                  : load_tap_pair_global(tab + (r.toff4 + (idx << 2)));
+    return pg.a + __builtin_amdgcn_fractf(pos) * (pg.b - pg.a);
+  }
   // linear: oracle/cpu_ref.c:table_fetch.  Every voice of a fast bank wraps (no stopping one-shots).
   // Both taps come from ONE 8-byte gather (4-byte aligned pair) -- the neighbour is idx+1 except on
   // the last sample before the loop end, where a second (rare) gather fetches the loop start.
@@ -1121,13 +1130,15 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
   if (args->lds_table_floats == 0) lds_bytes += (size_t)4 * (8 * SK_XT) * sizeof(float);   // global-table banks: window AND tile
   dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block(SK_GROUP);
   const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
-                  ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
+                  ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp != 0 ? 1 : 0);
   const bool rampk = !args->skip_env2;   /* envelopes may be moving (skip_env2: a launch has reported that none did) */
+  const bool guard = args->interp == 2;  /* linear lookup, every live voice on a guarded whole-table loop (SKF_GUARD; the host counts) */
+#define SK_FAST_LAUNCH_(T, F, E, I, X)                                                                                      \
+  { if (E && rampk) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, E>), grid, block, lds_bytes, stream, *args);   \
+    else hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, false>), grid, block, lds_bytes, stream, *args); }
 #define SK_FAST_CASE(K, T, F, E, I)                                                                                        \
-  case K: if (E && rampk) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false, E>), grid, block, lds_bytes, stream, *args); \
-          else hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, false, false>), grid, block, lds_bytes, stream, *args); break;  \
-  case 16 + K: if (E && rampk) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, true, E>), grid, block, lds_bytes, stream, *args); \
-               else hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, true, false>), grid, block, lds_bytes, stream, *args); break;
+  case K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), false) else SK_FAST_LAUNCH_(T, F, E, I, false) break;      \
+  case 16 + K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), true) else SK_FAST_LAUNCH_(T, F, E, I, true) break;
   switch (key) {
     SK_FAST_CASE(0, false, false, false, 0) SK_FAST_CASE(1, false, false, false, 1)
     SK_FAST_CASE(2, false, false, true, 0)  SK_FAST_CASE(3, false, false, true, 1)
@@ -1139,5 +1150,6 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
     SK_FAST_CASE(14, true, true, true, 0)   SK_FAST_CASE(15, true, true, true, 1)
   }
 #undef SK_FAST_CASE
+#undef SK_FAST_LAUNCH_
   return (int)hipGetLastError();
 }

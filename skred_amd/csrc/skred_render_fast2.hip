@@ -72,6 +72,11 @@ __device__ __forceinline__ float fast2_fetch(const char *lds_tab, const char *__
   if (!NOCLAMP) idx = max(min(idx, tsize_m1), 0);
   const char *tab = TAB_LDS ? lds_tab : glb_tab;
   if (INTERP == 0) return *reinterpret_cast<const float *>(tab + (toff4 + (idx << 2)));
+  if (INTERP == 2 && NOCLAMP) {                                   // linear over guarded whole-table loops: see fast_fetch
+    const tap_pair_t pg = TAB_LDS ? *reinterpret_cast<const tap_pair_t *>(tab + (toff4 + (idx << 2)))
+                                  : load_tap_pair_global(tab + (toff4 + (idx << 2)));
+    return pg.a + __builtin_amdgcn_fractf(pos) * (pg.b - pg.a);
+  }
   const tap_pair_t pr = TAB_LDS ? *reinterpret_cast<const tap_pair_t *>(tab + (toff4 + (idx << 2)))   // see fast_fetch
                                 : load_tap_pair_global(tab + (toff4 + (idx << 2)));
   const float a = pr.a;
@@ -1138,10 +1143,12 @@ static inline size_t sk_fast2_lds(const sk_render_args_t *args, int nw) {
 }
 static inline int sk_fast2_key(const sk_render_args_t *args) {
   return (args->lds_table_floats > 0 ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
-         ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp == 1 ? 1 : 0);
+         ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp != 0 ? 1 : 0);
 }
 /* (two-operator FM banks: LDS-table banks only -- T is a constant there, which keeps the instantiations at 24 more; they live
    in the other translation units) */
+/* (I = 1: linear; with every live voice on a guarded whole-table loop -- args->interp == 2, SKF_GUARD -- the instantiation
+   without the fold test, INTERP == 2: plain translation unit only, two-operator FM banks keep the general form) */
 #ifdef SK_FAST2_FMP_TU
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
@@ -1150,7 +1157,8 @@ static inline int sk_fast2_key(const sk_render_args_t *args) {
 #else
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
-    if (mixed) SK_FAST2_LAUNCH(T, F, E, I, true, 0)                                                     \
+    if (I && args->interp == 2) { if (mixed) SK_FAST2_LAUNCH(T, F, E, (I ? 2 : 0), true, 0) else SK_FAST2_LAUNCH(T, F, E, (I ? 2 : 0), false, 0) } \
+    else if (mixed) SK_FAST2_LAUNCH(T, F, E, I, true, 0)                                                \
     else SK_FAST2_LAUNCH(T, F, E, I, false, 0)                                                          \
     break;
 #endif

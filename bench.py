@@ -656,15 +656,15 @@ def main():
         fdb.set_sample_count(fcount0)
         fmix = torch.zeros(F, 2, device=dev, dtype=torch.int64)
         for _ in range(12 + a.warmup):                      # 12 x 512 frames: the recipe's last note-on reaches sustain
-            fdb.render(F, fmix.data_ptr(), 1, 0, stream)
+            fdb.render_mix(F, fmix.data_ptr(), 1, 0, stream)
         fence()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            fdb.render(F, fmix.data_ptr(), 1, 0, stream)
+            fdb.render_mix(F, fmix.data_ptr(), 1, 0, stream)   # ONE launch per block: render + int64 mix-down + integer master stage
         fence()
         fdt = time.perf_counter() - t0
         res["fixed_point"] = {"value": bank_voices * F * a.steps / fdt, "unit": "voice-samples/s", "dtype": fxbank.DTYPE_NOTE,
-                              "frames_per_launch": F, "ms_per_step": fdt / a.steps * 1e3, "kernel": "sk_fx_render_kernel",
+                              "frames_per_launch": F, "ms_per_step": fdt / a.steps * 1e3, "kernel": "sk_fx_render_kernel", "launches_per_block": 1,
                               "kernel_ms_last": fdb.last_render_ms(), "mix_nonzero": bool((fmix != 0).any().item()),
                               "workload": fxbank.WORKLOAD_NOTE}
         fdb.close()

@@ -38,6 +38,13 @@
  *              y0  = clamp((acc + 2^29) >> 30, -2^29, 2^29 - 1)       round to nearest, saturating
  *              x2 = x1, x1 = x0, y2 = y1, y1 = y0
  *              s   = clamp(y0 >> 12, -32768, 32767)                   back to sample units: a resonant overshoot saturates
+ *   master   the image of the master-volume stage (synth.c:616-624: vg += k * (target - vg); out = sum * vg), after the mix:
+ *            g is Q31 held in int64, target in [0, 2^31), k_q15 in [0, 32768]; per frame
+ *              g   += ((target_q31 - g) * k_q15) >> 15
+ *              out  = (mix * (g >> 16)) >> 15                         per channel, int64 (|mix| < 2^38 for 2^20 voices: 53 bits)
+ *            defaults: target 0.025 (volume_user 1 x AMY_FACTOR), k 66/32768 (0.002), g 0 -- the float path's
+ *   stamps   note-on: sample_start = now, sample_release = 0, is_active = 1; note-off: if is_active, sample_release = now
+ *            (amp_envelope_trigger / _release, synth.c:383-395), now = the bank's synth_sample_count when the stamp runs
  */
 #ifndef SKRED_AMD_FXPT_H
 #define SKRED_AMD_FXPT_H
@@ -87,9 +94,32 @@ uint64_t skred_fxbank_get_sample_count(const skred_fxbank_t *fx);
 /* Render num_frames frames; d_mix = device int64[num_frames][2]; d_stems = device int32
  * [num_frames][n_voices][2] or NULL.  interp: 0 truncate, 1 linear.  Asynchronous on `stream`. */
 int  skred_fxbank_render(skred_fxbank_t *fx, int num_frames, int interp, int64_t *d_mix, int32_t *d_stems, void *stream);
+/* Render + mix-down + master stage in ONE launch (the render kernel's last-arriving workgroups add the rows up and apply the
+ * gain of each frame): d_out = device int64[num_frames][2], post-master. */
+int  skred_fxbank_render_mix(skred_fxbank_t *fx, int num_frames, int interp, int64_t *d_out, int32_t *d_stems, void *stream);
+/* The master stage alone, for a sum that travelled (multi-GPU: on the root, after the int64 reduce of the ranks'
+ * skred_fxbank_render outputs -- an exact sum, whatever the order): must follow a skred_fxbank_render of the same block on
+ * this bank, which walked the block's gains.  d_out may equal d_sum. */
+int  skred_fxbank_master(skred_fxbank_t *fx, const int64_t *d_sum, int num_frames, int64_t *d_out, void *stream);
+int  skred_fxbank_set_master(skred_fxbank_t *fx, int64_t target_q31, int32_t k_q15, int64_t gain_q31);   /* synchronous */
+int64_t skred_fxbank_get_master_gain(skred_fxbank_t *fx);                                                  /* synchronous; < 0: error */
+/* Note-ons / note-offs on device-resident voices (the float path's SKRED_STAMP_TRIGGER / _RELEASE), on `stream`. */
+enum { SKRED_FX_STAMP_TRIGGER = 1, SKRED_FX_STAMP_RELEASE = 2 };
+int  skred_fxbank_stamp(skred_fxbank_t *fx, const int32_t *voices, int n_voices, int which, void *stream);
 /* Same on host buffers (synchronous). */
 int  skred_fxbank_render_host(skred_fxbank_t *fx, int num_frames, int interp, int64_t *mix, int32_t *stems_or_null);
 float skred_fxbank_last_render_ms(skred_fxbank_t *fx);
+
+/* ---- the fixed-point bank sharded over the GPUs of one node (include/skred_amd.h: skred_shard_*) ----
+ * skred_fxshard_create() makes an skred_shard_t whose steps are this path's: every rank renders its block of the bank into an
+ * int64 pre-master sum, the one collective is ncclReduce(ncclSum, ncclInt64) -- an exact sum: the sharded render equals the
+ * unsharded one BIT FOR BIT for every number of ranks --, the root applies the master stage.  Drive it with
+ * skred_shard_render_mix (partial / out: int64[num_frames][2] behind the float pointers), skred_shard_init_rccl,
+ * skred_shard_set_ops, skred_shard_destroy. */
+struct skred_shard;
+int  skred_fxshard_create(int device, int rank, int world, int root, int total_voices, struct skred_shard **out);
+skred_fxbank_t *skred_fxshard_bank(struct skred_shard *shard);
+int  skred_fxshard_upload(struct skred_shard *shard, const skred_fxpt_bank_t *whole_bank);
 
 #ifdef __cplusplus
 }

@@ -113,3 +113,17 @@ int skred_cpuref_fx_render(skred_fxpt_bank_t *b, const int16_t *pool, uint64_t *
   *count = now;
   return SKRED_OK;
 }
+
+/* The master stage of the definition (include/skred_amd_fxpt.h: "master"): *gain_q31 is carried. */
+int skred_cpuref_fx_master(int64_t target_q31, int32_t k_q15, int64_t *gain_q31, const int64_t *mix, int num_frames, int64_t *out) {
+  if (!gain_q31 || !mix || !out || num_frames < 0) return SKRED_E_BAD_ARG;
+  int64_t g = *gain_q31;
+  for (int i = 0; i < num_frames; i++) {
+    g += ((target_q31 - g) * (int64_t)k_q15) >> 15;
+    const int64_t g15 = g >> 16;
+    out[2 * i] = (mix[2 * i] * g15) >> 15;
+    out[2 * i + 1] = (mix[2 * i + 1] * g15) >> 15;
+  }
+  *gain_q31 = g;
+  return SKRED_OK;
+}

@@ -119,3 +119,17 @@ def fx_render(bank, pool: np.ndarray, count: int, frames: int, interp: int = 0, 
     if rc != 0:
         raise RuntimeError(f"skred_cpuref_fx_render rc={rc}")
     return mix, stems, int(cnt.value)
+
+
+def fx_master(target_q31: int, k_q15: int, gain_q31: int, mix: np.ndarray):
+    """The fixed-point master stage (oracle/cpu_ref_fxpt.c: skred_cpuref_fx_master).  Returns (out int64 [F][2], new gain)."""
+    L = lib()
+    L.skred_cpuref_fx_master.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.c_int, C.c_void_p]
+    L.skred_cpuref_fx_master.restype = C.c_int
+    mix = np.ascontiguousarray(mix, np.int64)
+    out = np.zeros_like(mix)
+    g = C.c_int64(gain_q31)
+    rc = L.skred_cpuref_fx_master(target_q31, k_q15, C.byref(g), mix.ctypes.data, mix.shape[0], out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"skred_cpuref_fx_master rc={rc}")
+    return out, int(g.value)

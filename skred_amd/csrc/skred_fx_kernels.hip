@@ -8,6 +8,67 @@
 #include <stdint.h>
 
 #include "skred_fx_layout.h"
+#include "skred_kernel_common.hpp"   /* sk_arrive_last: the arrival tickets of the in-kernel mix-down */
+
+// ---------------------------------------------------------------- the block's mix-down + master stage (int64 rows)
+//
+// The float path's scheme (skred_kernel_common.hpp: sk_finish_block) on integer rows.  The master stage is DEFINED in
+// include/skred_amd_fxpt.h ("master"): g (Q31, int64) += ((target - g) * k_q15) >> 15 per frame, out = (mix * (g >> 16)) >> 15.
+typedef long long skx_i64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void skx_store_through(long long *p, long long v) {
+  __hip_atomic_store((sk_gu64 *)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// sum of n rows (step apart) for one (L,R) column, ascending, 8 loads in flight
+__device__ __forceinline__ skx_i64x2 skx_add_rows(const skx_i64x2 *rows, size_t ncol, int c, int first, int n, int step) {
+  skx_i64x2 acc = rows[(size_t)first * ncol + c];
+  int i = 1;
+  for (; i + 8 <= n; i += 8) {
+    skx_i64x2 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = rows[(size_t)(first + (i + k) * step) * ncol + c];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += t[k];
+  }
+  for (; i < n; ++i) acc += rows[(size_t)(first + i * step) * ncol + c];
+  return acc;
+}
+// every workgroup of the render kernel ends here (bid < 0: the gain workgroup); the row was published write-through
+__device__ __forceinline__ void skx_finish_block(const skx_args_t &a, int bid, int tid, int nthreads, int *flag_lds) {
+  const size_t ncol = (size_t)a.num_frames;
+  const bool two_level = a.n_rows > SKX_FINISH_FLAT_MAX;
+  const int n_last = two_level ? SKX_FINISH_SLABS : a.n_rows;
+  if (bid < 0) {
+    if (tid == 0) {                                       // the master gain of every frame: a serial recurrence
+      long long g = a.gain_state[0];
+      for (int i = 0; i < a.num_frames; ++i) {
+        g += ((a.master_target_q31 - g) * (long long)a.master_k_q15) >> 15;
+        __hip_atomic_store((sk_gu32 *)(a.gains + i), (uint32_t)(int32_t)(g >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      a.gain_commit[0] = g;
+    }
+  } else if (two_level) {
+    const int slab = bid % SKX_FINISH_SLABS;
+    const int members = (a.n_rows - slab + SKX_FINISH_SLABS - 1) / SKX_FINISH_SLABS;
+    if (!sk_arrive_last(a.tickets + slab, (uint32_t)members, tid, flag_lds)) return;
+    long long *dst = a.slab_rows + (size_t)slab * ncol * 2;
+    for (int c = tid; c < (int)ncol; c += nthreads) {
+      const skx_i64x2 s = skx_add_rows(reinterpret_cast<const skx_i64x2 *>(a.partial), ncol, c, slab, members, SKX_FINISH_SLABS);
+      skx_store_through(dst + 2 * c, s.x);
+      skx_store_through(dst + 2 * c + 1, s.y);
+    }
+  }
+  if (!sk_arrive_last(a.tickets + SKX_FINISH_SLABS, (uint32_t)n_last + 1u, tid, flag_lds)) return;
+  const skx_i64x2 *rows = reinterpret_cast<const skx_i64x2 *>(two_level ? a.slab_rows : a.partial);
+  for (int c = tid; c < (int)ncol; c += nthreads) {
+    const skx_i64x2 s = skx_add_rows(rows, ncol, c, 0, n_last, 1);
+    if (a.sum_out) { a.sum_out[2 * c] = s.x; a.sum_out[2 * c + 1] = s.y; }
+    if (a.mix_out) {
+      const long long g15 = (long long)a.gains[c];
+      a.mix_out[2 * c] = (s.x * g15) >> 15;
+      a.mix_out[2 * c + 1] = (s.y * g15) >> 15;
+    }
+  }
+}
 
 // integer wave sum of two values into lane 63 (the float kernels fold L/R first: skred_kernel_common.hpp)
 __device__ __forceinline__ void wave_isum2_to_lane63(int &l, int &r) {
@@ -148,6 +209,8 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
   int2 *xp = wsum + 4 * SKX_CHUNK + wave * SKX_TILE;
   int2 *xq = xp + 8 * 65;
   const bool lut_in_lds = a.lds_bytes_tables > 0;
+  const int bid = (int)blockIdx.x - 1;                 // row of the partial mix; -1: the gain workgroup
+  if (bid < 0) { skx_finish_block(a, bid, tid, SKX_GROUP, reinterpret_cast<int *>(lut_lds)); return; }
   if (lut_in_lds) {
     const int n4 = a.lds_bytes_tables >> 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
@@ -155,10 +218,11 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
     for (int i = tid; i < n4; i += SKX_GROUP) dst[i] = src[i];
     __syncthreads();
   }
-  const size_t part_base = (size_t)blockIdx.x * (size_t)a.num_frames * 2;
+  const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;
   bool first_pass = true;
 
-  for (int g = blockIdx.x; g < a.n_groups; g += gridDim.x) {
+  for (int g = bid; g < a.n_groups; g += a.n_rows) {
+    const bool publish = g + a.n_rows >= a.n_groups;   // the pass that completes this workgroup's row: its values leave write-through
     const int v = g * SKX_GROUP + tid;
     const uint4 p0 = *reinterpret_cast<const uint4 *>(&a.ro[SKX_OSC][v]);
     const uint4 p1 = *reinterpret_cast<const uint4 *>(&a.ro[SKX_GAIN][v]);
@@ -309,7 +373,8 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
         long long s = (long long)w[0 * 2 * SKX_CHUNK + tid] + w[1 * 2 * SKX_CHUNK + tid] +
                       w[2 * 2 * SKX_CHUNK + tid] + w[3 * 2 * SKX_CHUNK + tid];
         long long *p = a.partial + part_base + (size_t)c0 * 2 + tid;
-        if (first_pass) *p = s; else *p += s;
+        if (!first_pass) s += *p;
+        if (publish) skx_store_through(p, s); else *p = s;
       }
       __syncthreads();
     }
@@ -320,55 +385,55 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
     if (a.any_filter && filt) *reinterpret_cast<uint4 *>(&a.rw[1][v]) = make_uint4((uint32_t)x1, (uint32_t)x2, (uint32_t)y1, (uint32_t)y2);
     first_pass = false;
   }
+  skx_finish_block(a, bid, tid, SKX_GROUP, reinterpret_cast<int *>(lut_lds));
 }
 
-// partial[W][ncols] -> out[ncols] (int64, so any order of addition is exact).  Large W: stage 1 folds the rows into
-// SKX_RED_SLABS slabs (grid: column tiles x slabs, four row-strided slices per workgroup), stage 2 adds the slabs.
-#define SKX_RED_SLABS 32
-__global__ __launch_bounds__(256) void sk_fx_reduce_slabs_kernel(const long long *__restrict__ partial,
-                                                                 long long *__restrict__ tmp, int W, int ncols) {
-  __shared__ long long part[4][64];
-  const int c = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + c;
-  const int slabs = gridDim.y;
-  const int w0 = (int)((long long)W * blockIdx.y / slabs), w1 = (int)((long long)W * (blockIdx.y + 1) / slabs);
-  long long s = 0;
-  if (col < ncols)
-    for (int w = w0 + slice; w < w1; w += 4) s += partial[(size_t)w * ncols + col];
-  part[slice][c] = s;
-  __syncthreads();
-  if (slice == 0 && col < ncols)
-    tmp[(size_t)blockIdx.y * ncols + col] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+// The master stage as a kernel of its own (multi-GPU form: on the root, after the int64 reduce): the gains of the block were
+// walked by the render kernel's gain workgroup; scale, and commit the carried gain.
+__global__ __launch_bounds__(256) void sk_fx_master_apply_kernel(const long long *__restrict__ sum, const int32_t *__restrict__ gains,
+                                                                 long long *__restrict__ out, int num_frames,
+                                                                 const long long *gain_pending, long long *gain_state) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < num_frames) {
+    const long long g15 = (long long)gains[i];
+    out[2 * i] = (sum[2 * i] * g15) >> 15;
+    out[2 * i + 1] = (sum[2 * i + 1] * g15) >> 15;
+  }
+  if (i == 0) gain_state[0] = gain_pending[0];
+}
+extern "C" int skx_launch_master_apply(const long long *sum, const int32_t *gains, long long *out, int num_frames,
+                                       const long long *gain_pending, long long *gain_state, hipStream_t stream) {
+  hipLaunchKernelGGL(sk_fx_master_apply_kernel, dim3((unsigned)((num_frames + 255) / 256)), dim3(256), 0, stream, sum, gains, out, num_frames,
+                     gain_pending, gain_state);
+  return (int)hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void sk_fx_reduce_kernel(const long long *__restrict__ partial,
-                                                           long long *__restrict__ out, int W, int ncols) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= ncols) return;
-  long long s = 0;
-  for (int w = 0; w < W; ++w) s += partial[(size_t)w * ncols + col];
-  out[col] = s;
+// note-on / note-off stamps on device-resident voices (include/skred_amd_fxpt.h: skred_fxbank_stamp): the integer image of
+// amp_envelope_trigger / amp_envelope_release (synth.c:383-395)
+__global__ __launch_bounds__(256) void sk_fx_stamp_kernel(const int32_t *__restrict__ ids, int n, int which, skx_plane_t *time_plane,
+                                                          skx_plane_t *rw0, uint64_t now) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int v = ids[i];
+  uint4 t = *reinterpret_cast<const uint4 *>(&time_plane[v]);
+  uint32_t *flags = reinterpret_cast<uint32_t *>(&rw0[v]) + 3;
+  uint32_t f = *flags;
+  if (which & 1) { t.x = (uint32_t)now; t.y = (uint32_t)(now >> 32); t.z = 0; t.w = 0; f |= 1u; }     // trigger
+  if ((which & 2) && (f & 1u)) { t.z = (uint32_t)now; t.w = (uint32_t)(now >> 32); }                 // release, if active
+  *reinterpret_cast<uint4 *>(&time_plane[v]) = t;
+  *flags = f;
+}
+extern "C" int skx_launch_stamp(const int32_t *d_ids, int n, int which, skx_plane_t *time_plane, skx_plane_t *rw0, uint64_t now, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sk_fx_stamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ids, n, which, time_plane, rw0, now);
+  return (int)hipGetLastError();
 }
 
 extern "C" int skx_launch_render(const skx_args_t *args, int n_workgroups, hipStream_t stream) {
   const size_t lds = (size_t)args->lds_bytes_tables + (size_t)4 * SKX_CHUNK * sizeof(int2) + (size_t)4 * SKX_TILE * sizeof(int2);
-  dim3 grid((unsigned)n_workgroups), block(SKX_GROUP);
+  dim3 grid((unsigned)n_workgroups + 1u), block(SKX_GROUP);   /* + the gain workgroup */
   if (args->stems) hipLaunchKernelGGL((sk_fx_render_kernel<true>), grid, block, lds, stream, *args);
   else             hipLaunchKernelGGL((sk_fx_render_kernel<false>), grid, block, lds, stream, *args);
   return (int)hipGetLastError();
 }
 
-extern "C" int skx_reduce_tmp_elems(int ncols) { return SKX_RED_SLABS * ncols; }
-
-// tmp: skx_reduce_tmp_elems(ncols) int64 of scratch (used when W > 4 * SKX_RED_SLABS)
-extern "C" int skx_launch_reduce(const long long *partial, long long *tmp, long long *out, int W, int ncols, hipStream_t stream) {
-  const long long *rows = partial;
-  int n_rows = W;
-  if (W > 4 * SKX_RED_SLABS) {
-    hipLaunchKernelGGL(sk_fx_reduce_slabs_kernel, dim3((unsigned)((ncols + 63) / 64), SKX_RED_SLABS), dim3(256), 0, stream, partial, tmp, W, ncols);
-    rows = tmp;
-    n_rows = SKX_RED_SLABS;
-  }
-  hipLaunchKernelGGL(sk_fx_reduce_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, stream, rows, out, n_rows, ncols);
-  return (int)hipGetLastError();
-}

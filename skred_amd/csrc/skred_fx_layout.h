@@ -42,5 +42,22 @@ typedef struct {
   int32_t n_voices, n_groups, num_frames, interp;
   int32_t lds_bytes_tables;   /* bytes of the pool staged in LDS (multiple of 16), 0 = gather from L2/HBM */
   int32_t any_filter;         /* some voice of the bank runs the biquad (selects the block instantiation) */
+  /* ---- the block's mix-down and master stage inside the render kernel (the float path's scheme, skred_kernel_common.hpp:
+   * sk_finish_block, on int64 rows: every workgroup publishes its row write-through, the last arriver of a slab adds the slab,
+   * the last slab adds the slabs -- integer sums, any order is exact -- and applies the master gain of each frame, which
+   * workgroup 0 of the grid walked meanwhile) ---- */
+  int32_t n_rows;             /* rendering workgroups; the grid has one more (blockIdx 0: the gain workgroup) */
+  long long *slab_rows;       /* [SKX_FINISH_SLABS][num_frames][2] */
+  uint32_t *tickets;          /* [SKX_FINISH_SLABS + 1], zero between launches */
+  long long *sum_out;         /* [num_frames][2] pre-master sum (the operand of the multi-GPU reduce), or NULL */
+  long long *mix_out;         /* [num_frames][2] post-master output, or NULL */
+  int32_t *gains;             /* [num_frames] Q15 master gain per frame */
+  long long *gain_state;      /* [0] Q31 gain carried between blocks (read) */
+  long long *gain_commit;     /* where the gain after the last frame goes ([0] when this launch applies the stage; [1]: pending for skred_fxbank_master) */
+  long long master_target_q31;
+  int32_t master_k_q15;
 } skx_args_t;
+
+#define SKX_FINISH_SLABS 32
+#define SKX_FINISH_FLAT_MAX 64
 #endif

@@ -15,8 +15,9 @@
 #include "skred_fx_layout.h"
 
 int skx_launch_render(const skx_args_t *args, int n_workgroups, hipStream_t stream);
-int skx_launch_reduce(const long long *partial, long long *tmp, long long *out, int W, int ncols, hipStream_t stream);
-int skx_reduce_tmp_elems(int ncols);
+int skx_launch_master_apply(const long long *sum, const int32_t *gains, long long *out, int num_frames, const long long *gain_pending,
+                            long long *gain_state, hipStream_t stream);
+int skx_launch_stamp(const int32_t *d_ids, int n, int which, skx_plane_t *time_plane, skx_plane_t *rw0, uint64_t now, hipStream_t stream);
 int skred_amd_set_error(int code, const char *fmt, ...);   /* skred_bank.c */
 
 struct skred_fxbank {
@@ -26,8 +27,14 @@ struct skred_fxbank {
   int n_filter;                 /* voices with filter_mode != 0 (recounted on whole-bank uploads, grown otherwise) */
   int16_t *d_tables;
   size_t table_entries, table_bytes_padded;
-  long long *d_partial; size_t partial_cap;
-  long long *d_redtmp; size_t redtmp_cap;   /* stage-1 output of the partial-row reduction */
+  long long *d_partial; size_t partial_cap;  /* [n_wg][F][2] rows, [SKX_FINISH_SLABS][F][2] slab sums, then int32 gains[F] */
+  uint32_t *d_tickets;          /* [SKX_FINISH_SLABS + 1] arrival counters of the in-kernel mix-down */
+  long long *d_gain_state;      /* [0] Q31 master gain carried between blocks; [1] the gain a sum-only render prepared for skred_fxbank_master */
+  long long master_target_q31;  /* default: 0.025 (the float path's volume_final) in Q31 */
+  int32_t master_k_q15;         /* default: 0.002 in Q15 */
+  int gains_frames;             /* > 0: the latest sum-only render left the gains of a block of this many frames */
+  size_t gains_offset;          /* ... at this int64 offset into d_partial */
+  int32_t *d_ids; int32_t *h_ids; size_t ids_cap;   /* staging of skred_fxbank_stamp */
   long long *d_mix; size_t mix_cap;
   int32_t *d_stems; size_t stems_cap;
   uint64_t count;
@@ -72,6 +79,12 @@ int skred_fxbank_create(int device, int n_voices, skred_fxbank_t **out) {
   free(inert);
   HIP_TRY(e);
   HIP_TRY(hipEventCreate(&fx->ev0)); HIP_TRY(hipEventCreate(&fx->ev1));
+  HIP_TRY(hipMalloc((void **)&fx->d_tickets, (SKX_FINISH_SLABS + 1) * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(fx->d_tickets, 0, (SKX_FINISH_SLABS + 1) * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc((void **)&fx->d_gain_state, 4 * sizeof(long long)));
+  HIP_TRY(hipMemset(fx->d_gain_state, 0, 4 * sizeof(long long)));
+  fx->master_target_q31 = (long long)(0.025 * 2147483648.0);    /* volume_user 1 * AMY_FACTOR (synth.c:96-100) */
+  fx->master_k_q15 = 66;                                        /* 0.002 (synth.c:92) */
   *out = fx;
   return SKRED_OK;
 }
@@ -83,7 +96,10 @@ void skred_fxbank_destroy(skred_fxbank_t *fx) {
   for (int p = 0; p < SKX_RW_COUNT; p++) if (fx->d_rw[p]) hipFree(fx->d_rw[p]);
   if (fx->d_tables) hipFree(fx->d_tables);
   if (fx->d_partial) hipFree(fx->d_partial);
-  if (fx->d_redtmp) hipFree(fx->d_redtmp);
+  if (fx->d_tickets) hipFree(fx->d_tickets);
+  if (fx->d_gain_state) hipFree(fx->d_gain_state);
+  if (fx->d_ids) hipFree(fx->d_ids);
+  if (fx->h_ids) hipHostFree(fx->h_ids);
   if (fx->d_mix) hipFree(fx->d_mix);
   if (fx->d_stems) hipFree(fx->d_stems);
   if (fx->ev0) hipEventDestroy(fx->ev0);
@@ -202,15 +218,16 @@ int skred_fxbank_download(skred_fxbank_t *fx, skred_fxpt_bank_t *h, int src_firs
 int skred_fxbank_set_sample_count(skred_fxbank_t *fx, uint64_t c) { if (!fx) return SKRED_E_BAD_ARG; fx->count = c; return SKRED_OK; }
 uint64_t skred_fxbank_get_sample_count(const skred_fxbank_t *fx) { return fx ? fx->count : 0; }
 
-int skred_fxbank_render(skred_fxbank_t *fx, int num_frames, int interp, int64_t *d_mix, int32_t *d_stems, void *stream) {
-  if (!fx || !d_mix || num_frames <= 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx render: bad arguments");
+/* one block: the render kernel, whose last-arriving workgroups add the rows up into `d_sum` (pre-master, may be NULL) and / or,
+ * scaled by the master gain of each frame, into `d_out` */
+static int fx_block(skred_fxbank_t *fx, int num_frames, int interp, int64_t *d_sum, int64_t *d_out, int32_t *d_stems, hipStream_t s) {
   if (!fx->d_tables) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx render: no table pool set");
   HIP_TRY(hipSetDevice(fx->device));
-  hipStream_t s = (hipStream_t)stream;
   const int n_wg = fx->n_groups < SKX_MAX_WORKGROUPS ? fx->n_groups : SKX_MAX_WORKGROUPS;
-  int rc = grow_bytes((void **)&fx->d_partial, &fx->partial_cap, (size_t)n_wg * (size_t)num_frames * 2 * sizeof(long long));
+  const size_t row = (size_t)num_frames * 2;
+  const size_t gains_at = ((size_t)n_wg + SKX_FINISH_SLABS) * row;                   /* int64 units; the gains are int32 behind */
+  int rc = grow_bytes((void **)&fx->d_partial, &fx->partial_cap, gains_at * sizeof(long long) + (size_t)num_frames * sizeof(int32_t));
   if (rc) return rc;
-  if ((rc = grow_bytes((void **)&fx->d_redtmp, &fx->redtmp_cap, (size_t)skx_reduce_tmp_elems(2 * num_frames) * sizeof(long long)))) return rc;
   skx_args_t a;
   memset(&a, 0, sizeof(a));
   for (int p = 0; p < SKX_COUNT; p++) a.ro[p] = fx->d_ro[p];
@@ -220,14 +237,94 @@ int skred_fxbank_render(skred_fxbank_t *fx, int num_frames, int interp, int64_t 
   a.count0 = fx->count; a.n_voices = fx->n_voices; a.n_groups = fx->n_groups;
   a.num_frames = num_frames; a.interp = interp ? 1 : 0;
   a.lds_bytes_tables = fx->table_bytes_padded <= SKX_LDS_TABLE_MAX_BYTES ? (int32_t)fx->table_bytes_padded : 0;
+  a.n_rows = n_wg;
+  a.slab_rows = fx->d_partial + (size_t)n_wg * row;
+  a.gains = (int32_t *)(fx->d_partial + gains_at);
+  a.tickets = fx->d_tickets;
+  a.sum_out = (long long *)d_sum;
+  a.mix_out = (long long *)d_out;
+  a.gain_state = fx->d_gain_state;
+  a.gain_commit = d_out ? fx->d_gain_state : fx->d_gain_state + 1;
+  a.master_target_q31 = fx->master_target_q31;
+  a.master_k_q15 = fx->master_k_q15;
+  fx->gains_frames = d_out ? 0 : num_frames;
+  fx->gains_offset = gains_at;
   HIP_TRY(hipEventRecord(fx->ev0, s));
   hipError_t e = (hipError_t)skx_launch_render(&a, n_wg, s);
   if (e != hipSuccess) return skred_amd_set_error(SKRED_E_NO_DEVICE, "fx render launch -> %s", hipGetErrorString(e));
   HIP_TRY(hipEventRecord(fx->ev1, s));
   fx->timed = 1;
-  e = (hipError_t)skx_launch_reduce(fx->d_partial, fx->d_redtmp, (long long *)d_mix, n_wg, 2 * num_frames, s);
-  if (e != hipSuccess) return skred_amd_set_error(SKRED_E_NO_DEVICE, "fx reduce launch -> %s", hipGetErrorString(e));
   fx->count += (uint64_t)num_frames;
+  return SKRED_OK;
+}
+
+int skred_fxbank_render(skred_fxbank_t *fx, int num_frames, int interp, int64_t *d_mix, int32_t *d_stems, void *stream) {
+  if (!fx || !d_mix || num_frames <= 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx render: bad arguments");
+  return fx_block(fx, num_frames, interp, d_mix, NULL, d_stems, (hipStream_t)stream);
+}
+
+int skred_fxbank_render_mix(skred_fxbank_t *fx, int num_frames, int interp, int64_t *d_out, int32_t *d_stems, void *stream) {
+  if (!fx || !d_out || num_frames <= 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx render_mix: bad arguments");
+  return fx_block(fx, num_frames, interp, NULL, d_out, d_stems, (hipStream_t)stream);
+}
+
+int skred_fxbank_master(skred_fxbank_t *fx, const int64_t *d_sum, int num_frames, int64_t *d_out, void *stream) {
+  if (!fx || !d_sum || !d_out || num_frames <= 0) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx master: bad arguments");
+  if (fx->gains_frames != num_frames || !fx->d_partial)
+    return skred_amd_set_error(SKRED_E_BAD_ARG, "fx master: no skred_fxbank_render of %d frames precedes it (the render walks the block's gains)", num_frames);
+  HIP_TRY(hipSetDevice(fx->device));
+  const hipError_t e = (hipError_t)skx_launch_master_apply((const long long *)d_sum, (const int32_t *)(fx->d_partial + fx->gains_offset), (long long *)d_out,
+                                                           num_frames, fx->d_gain_state + 1, fx->d_gain_state, (hipStream_t)stream);
+  fx->gains_frames = 0;
+  if (e != hipSuccess) return skred_amd_set_error(SKRED_E_NO_DEVICE, "fx master launch -> %s", hipGetErrorString(e));
+  return SKRED_OK;
+}
+
+int skred_fxbank_set_master(skred_fxbank_t *fx, int64_t target_q31, int32_t k_q15, int64_t gain_q31) {
+  if (!fx || target_q31 < 0 || target_q31 > 0x7FFFFFFFll || k_q15 < 0 || k_q15 > 32768 || gain_q31 < 0 || gain_q31 > 0x7FFFFFFFll)
+    return skred_amd_set_error(SKRED_E_BAD_ARG, "fx set_master: target and gain are Q31 in [0, 2^31), k is Q15 in [0, 32768]");
+  HIP_TRY(hipSetDevice(fx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  fx->master_target_q31 = target_q31;
+  fx->master_k_q15 = k_q15;
+  fx->gains_frames = 0;
+  const long long g = gain_q31;
+  HIP_TRY(hipMemcpy(fx->d_gain_state, &g, sizeof(g), hipMemcpyHostToDevice));
+  return SKRED_OK;
+}
+
+int64_t skred_fxbank_get_master_gain(skred_fxbank_t *fx) {
+  if (!fx || hipSetDevice(fx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+  long long g = -1;
+  if (hipMemcpy(&g, fx->d_gain_state, sizeof(g), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return g;
+}
+
+/* note-ons / note-offs on device-resident voices, stamped with the bank's synth_sample_count when they run (the integer image of
+ * amp_envelope_trigger / amp_envelope_release, synth.c:383-395; the float path: SKRED_STAMP_TRIGGER / _RELEASE) */
+int skred_fxbank_stamp(skred_fxbank_t *fx, const int32_t *voices, int n, int which, void *stream) {
+  if (!fx || n < 0 || (n > 0 && !voices) || !(which & 3) || (which & ~3)) return skred_amd_set_error(SKRED_E_BAD_ARG, "fx stamp: bad arguments");
+  if (n == 0) return SKRED_OK;
+  for (int i = 0; i < n; i++)
+    if (voices[i] < 0 || voices[i] >= fx->n_voices) return skred_amd_set_error(SKRED_E_RANGE, "fx stamp: voice %d outside the bank", voices[i]);
+  HIP_TRY(hipSetDevice(fx->device));
+  const size_t bytes = (size_t)n * sizeof(int32_t);
+  if (bytes > fx->ids_cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (fx->d_ids) { (void)hipFree(fx->d_ids); fx->d_ids = NULL; }
+    if (fx->h_ids) { (void)hipHostFree(fx->h_ids); fx->h_ids = NULL; }
+    size_t cap = 4096;
+    while (cap < bytes) cap *= 2;
+    HIP_TRY(hipMalloc((void **)&fx->d_ids, cap));
+    HIP_TRY(hipHostMalloc((void **)&fx->h_ids, cap, hipHostMallocDefault));
+    fx->ids_cap = cap;
+  } else {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   /* (one staging buffer: the previous batch must have been read) */
+  }
+  memcpy(fx->h_ids, voices, bytes);
+  HIP_TRY(hipMemcpyAsync(fx->d_ids, fx->h_ids, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  const hipError_t e = (hipError_t)skx_launch_stamp(fx->d_ids, n, which, fx->d_ro[SKX_TIME], fx->d_rw[0], fx->count, (hipStream_t)stream);
+  if (e != hipSuccess) return skred_amd_set_error(SKRED_E_NO_DEVICE, "fx stamp launch -> %s", hipGetErrorString(e));
   return SKRED_OK;
 }
 

@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include "skred_bank_priv.h"
+#include "skred_amd_fxpt.h"
 
 struct skred_shard {
   int rank, world, root, total, lo, hi;
@@ -30,6 +31,8 @@ struct skred_shard {
   skred_shard_ops_t ops;
   /* bank-backed flavour */
   skred_bank_t *bank;
+  skred_fxbank_t *fxbank;            /* ... of the fixed-point path (skred_fxshard_create): int64 partials, an exact sum */
+  int elem_bytes;                    /* of one partial-mix element: 4 (float) or 8 (int64) */
   int device;
   float *d_partial;                  /* [F][2] scratch when the caller passes none */
   size_t partial_cap;
@@ -82,8 +85,8 @@ static int bank_master(void *ctx, const float *sum, int num_frames, int num_chan
 static int rccl_reduce(void *ctx, float *partial, size_t n_floats, int root, void *stream) {
   skred_shard_t *s = (skred_shard_t *)ctx;
   if (!s->comm) return fail(SKRED_E_BAD_ARG, "shard: %d ranks but no collective (skred_shard_init_rccl / skred_shard_set_ops)", s->world);
-  /* in place on the root; ncclFloat32 = 7, ncclSum = 0 (rccl.h) */
-  const int rc = s->nccl_reduce(partial, partial, n_floats, 7, 0, root, s->comm, stream);
+  /* in place on the root; ncclFloat32 = 7, ncclInt64 = 4, ncclSum = 0 (rccl.h) */
+  const int rc = s->nccl_reduce(partial, partial, n_floats, s->elem_bytes == 8 ? 4 : 7, 0, root, s->comm, stream);
   if (rc != 0) return fail(SKRED_E_NO_DEVICE, "ncclReduce -> %s", s->nccl_error_string ? s->nccl_error_string(rc) : "error");
   return SKRED_OK;
 }
@@ -98,6 +101,7 @@ static int shard_new(int rank, int world, int root, int total_voices, skred_shar
   skred_shard_t *s = (skred_shard_t *)calloc(1, sizeof(*s));
   if (!s) return fail(SKRED_E_NO_MEM, "calloc");
   s->rank = rank; s->world = world; s->root = root; s->total = total_voices;
+  s->elem_bytes = (int)sizeof(float);
   (void)skred_shard_partition(total_voices, world, rank, &s->lo, &s->hi);
   *out = s;
   return SKRED_OK;
@@ -116,6 +120,45 @@ int skred_shard_create(int device, int rank, int world, int root, int total_voic
   s->ops.reduce_ctx = s;
   s->ops.reduce = rccl_reduce;       /* fails loudly until a communicator exists; never called with one rank */
   return SKRED_OK;
+}
+
+/* ------------------------------------------------------------------ the fixed-point path, sharded the same way
+ *
+ * Every rank renders its block of an skred_fxpt_bank_t into an int64 pre-master sum; the reduce is ncclSum on int64 -- an EXACT
+ * sum, so the sharded render equals the unsharded one bit for bit whatever the number of ranks --; the root applies the integer
+ * master stage (include/skred_amd_fxpt.h).  Same skred_shard_t, same skred_shard_render_mix / _init_rccl / _set_ops:
+ * `partial` and `out` are int64[num_frames][2] there (passed through the float pointers of the float path's signature). */
+static int fx_render_step(void *ctx, int num_frames, int interp, float *partial, void *stream) {
+  return skred_fxbank_render(((skred_shard_t *)ctx)->fxbank, num_frames, interp, (int64_t *)partial, NULL, stream);
+}
+static int fx_master_step(void *ctx, const float *sum, int num_frames, int num_channels, float *out, void *stream) {
+  (void)num_channels;
+  return skred_fxbank_master(((skred_shard_t *)ctx)->fxbank, (const int64_t *)sum, num_frames, (int64_t *)out, stream);
+}
+
+int skred_fxshard_create(int device, int rank, int world, int root, int total_voices, skred_shard_t **out) {
+  int rc = shard_new(rank, world, root, total_voices, out);
+  if (rc) return rc;
+  skred_shard_t *s = *out;
+  s->device = device;
+  s->elem_bytes = (int)sizeof(int64_t);
+  rc = skred_fxbank_create(device, s->hi - s->lo, &s->fxbank);
+  if (rc) { free(s); *out = NULL; return rc; }
+  s->ops.ctx = s;
+  s->ops.render = fx_render_step;
+  s->ops.master = fx_master_step;
+  s->ops.reduce_ctx = s;
+  s->ops.reduce = rccl_reduce;
+  return SKRED_OK;
+}
+
+skred_fxbank_t *skred_fxshard_bank(skred_shard_t *s) { return s ? s->fxbank : NULL; }
+
+/* this rank's block of the WHOLE fixed-point bank (voices of that path are independent: every cut is legal) */
+int skred_fxshard_upload(skred_shard_t *s, const skred_fxpt_bank_t *whole) {
+  if (!s || !whole || !s->fxbank) return fail(SKRED_E_BAD_ARG, "fxshard_upload: bad arguments");
+  if (whole->n_voices != s->total) return fail(SKRED_E_RANGE, "fxshard_upload: the bank has %d voices, the shard was made for %d", whole->n_voices, s->total);
+  return skred_fxbank_upload(s->fxbank, whole, s->lo, 0, s->hi - s->lo);
 }
 
 int skred_shard_create_custom(int rank, int world, int root, int total_voices, const skred_shard_ops_t *ops, skred_shard_t **out) {
@@ -138,6 +181,7 @@ void skred_shard_destroy(skred_shard_t *s) {
   }
   if (s->pp_comm) (void)hipStreamDestroy(s->pp_comm);
   if (s->bank) skred_bank_destroy(s->bank);
+  if (s->fxbank) skred_fxbank_destroy(s->fxbank);
   /* the RCCL handle stays open: the process may hold other communicators on it */
   free(s);
 }
@@ -204,7 +248,7 @@ int skred_shard_rccl_unique_id(void *out128) {
 /* every rank calls this with the id rank 0 obtained from skred_shard_rccl_unique_id (how the 128 bytes travel is the
  * host program's business: a file, a socket, MPI, torch.distributed) */
 int skred_shard_init_rccl(skred_shard_t *s, const void *unique_id128) {
-  if (!s || !unique_id128 || !s->bank) return fail(SKRED_E_BAD_ARG, "shard_init_rccl: bad arguments");
+  if (!s || !unique_id128 || (!s->bank && !s->fxbank)) return fail(SKRED_E_BAD_ARG, "shard_init_rccl: bad arguments");
   if (s->comm) return SKRED_OK;
   s->rccl_lib = rccl_open();
   if (!s->rccl_lib) return fail(SKRED_E_NO_DEVICE, "librccl.so not found: %s", dlerror());
@@ -230,12 +274,12 @@ int skred_shard_render_mix(skred_shard_t *s, int num_frames, int interp, float *
   if (!s || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "shard_render_mix: bad arguments");
   if (s->rank == s->root && !out) return fail(SKRED_E_BAD_ARG, "shard_render_mix: the root needs an output buffer");
   if (!partial) {
-    if (!s->bank) return fail(SKRED_E_BAD_ARG, "shard_render_mix: custom steps need a partial buffer");
+    if (!s->bank && !s->fxbank) return fail(SKRED_E_BAD_ARG, "shard_render_mix: custom steps need a partial buffer");
     const size_t need = (size_t)num_frames * 2;
     if (need > s->partial_cap) {
       HIP_TRY(hipSetDevice(s->device));
       if (s->d_partial) { (void)hipFree(s->d_partial); s->d_partial = NULL; s->partial_cap = 0; }
-      HIP_TRY(hipMalloc((void **)&s->d_partial, need * sizeof(float)));
+      HIP_TRY(hipMalloc((void **)&s->d_partial, need * (size_t)s->elem_bytes));
       s->partial_cap = need;
     }
     partial = s->d_partial;
@@ -290,6 +334,7 @@ static int pp_setup(skred_shard_t *s, size_t need) {
 
 int skred_shard_render_mix_pipelined(skred_shard_t *s, int num_frames, int interp, float *out, int num_channels, void *stream) {
   if (!s || num_frames <= 0 || num_channels < 2) return fail(SKRED_E_BAD_ARG, "shard_render_mix_pipelined: bad arguments");
+  if (s->fxbank) return fail(SKRED_E_UNSUPPORTED, "shard_render_mix_pipelined: the fixed-point shard has the serial form only");
   if (s->rank == s->root && !out) return fail(SKRED_E_BAD_ARG, "shard_render_mix_pipelined: the root needs an output buffer");
   int rc = pp_setup(s, (size_t)num_frames * 2);
   if (rc) return rc;

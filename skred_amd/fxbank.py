@@ -31,7 +31,12 @@ FX_RW = [f[0] for f in FX_FIELDS if f[2]]
 FX_ABI_SYMBOLS = ["skred_fxbank_create", "skred_fxbank_destroy", "skred_fxbank_set_tables_i16",
                   "skred_fxbank_upload", "skred_fxbank_download", "skred_fxbank_set_sample_count",
                   "skred_fxbank_get_sample_count", "skred_fxbank_render", "skred_fxbank_render_host",
-                  "skred_fxbank_last_render_ms"]
+                  "skred_fxbank_last_render_ms", "skred_fxbank_render_mix", "skred_fxbank_master", "skred_fxbank_set_master",
+                  "skred_fxbank_get_master_gain", "skred_fxbank_stamp",
+                  "skred_fxshard_create", "skred_fxshard_bank", "skred_fxshard_upload"]
+FX_STAMP_TRIGGER, FX_STAMP_RELEASE = 1, 2
+MASTER_TARGET_Q31 = int(0.025 * 2147483648.0)     # the library's default: volume_user 1 x AMY_FACTOR
+MASTER_K_Q15 = 66                                 # 0.002
 
 
 class FxBankC(C.Structure):
@@ -93,6 +98,16 @@ def _bind(L):
     L.skred_fxbank_render_host.argtypes = [vp, i32, i32, vp, vp]
     L.skred_fxbank_last_render_ms.argtypes = [vp]
     L.skred_fxbank_last_render_ms.restype = C.c_float
+    L.skred_fxbank_render_mix.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.skred_fxbank_master.argtypes = [vp, vp, i32, vp, vp]
+    L.skred_fxbank_set_master.argtypes = [vp, C.c_int64, C.c_int32, C.c_int64]
+    L.skred_fxbank_get_master_gain.argtypes = [vp]
+    L.skred_fxbank_get_master_gain.restype = C.c_int64
+    L.skred_fxbank_stamp.argtypes = [vp, vp, i32, i32, vp]
+    L.skred_fxshard_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.skred_fxshard_bank.argtypes = [vp]
+    L.skred_fxshard_bank.restype = vp
+    L.skred_fxshard_upload.argtypes = [vp, C.POINTER(FxBankC)]
     return L
 
 
@@ -118,6 +133,16 @@ class DeviceFxBank:
     def set_tables(self, pool: np.ndarray):
         pool = np.ascontiguousarray(pool, np.int16)
         _check(self.L.skred_fxbank_set_tables_i16(self.h, pool.ctypes.data, pool.size), "skred_fxbank_set_tables_i16")
+
+    @classmethod
+    def borrowed(cls, handle, n_voices: int) -> "DeviceFxBank":
+        """A view of a bank a shard owns (skred_fxshard_bank): close() does not destroy it."""
+        self = cls.__new__(cls)
+        self.L = _bind(load())
+        self.n = int(n_voices)
+        self.h = C.c_void_p(handle)
+        self.close = lambda: None
+        return self
 
     def upload(self, bank: FxVoiceBank):
         cb = bank.as_c()
@@ -145,6 +170,23 @@ class DeviceFxBank:
 
     def last_render_ms(self) -> float:
         return float(self.L.skred_fxbank_last_render_ms(self.h))
+
+    def render_mix(self, frames: int, d_out: int, interp: int = 0, d_stems: int = 0, stream: int = 0):
+        """Render + mix-down + master stage in one launch; d_out: device int64 [frames][2]."""
+        _check(self.L.skred_fxbank_render_mix(self.h, frames, interp, d_out, d_stems or None, stream or None), "skred_fxbank_render_mix")
+
+    def master(self, d_sum: int, frames: int, d_out: int, stream: int = 0):
+        _check(self.L.skred_fxbank_master(self.h, d_sum, frames, d_out, stream or None), "skred_fxbank_master")
+
+    def set_master(self, target_q31: int = MASTER_TARGET_Q31, k_q15: int = MASTER_K_Q15, gain_q31: int = 0):
+        _check(self.L.skred_fxbank_set_master(self.h, target_q31, k_q15, gain_q31), "skred_fxbank_set_master")
+
+    def master_gain(self) -> int:
+        return int(self.L.skred_fxbank_get_master_gain(self.h))
+
+    def stamp(self, voices, which: int, stream: int = 0):
+        v = np.ascontiguousarray(voices, np.int32)
+        _check(self.L.skred_fxbank_stamp(self.h, v.ctypes.data, len(v), which, stream or None), "skred_fxbank_stamp")
 
 
 # ------------------------------------------------------------------ synthetic fixed-point bank

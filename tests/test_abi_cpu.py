@@ -26,7 +26,10 @@ def test_fxpt_header_and_binding_agree():
     from skred_amd import fxbank
     text = open(os.path.join(ROOT, "include", "skred_amd_fxpt.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    assert sorted(set(re.findall(r"\b(skred_fxbank_\w+)\s*\(", text))) == sorted(fxbank.FX_ABI_SYMBOLS)
+    assert sorted(set(re.findall(r"\b(skred_fx(?:bank|shard)_\w+)\s*\(", text))) == sorted(fxbank.FX_ABI_SYMBOLS)
+    L = device.load()
+    for sym in fxbank.FX_ABI_SYMBOLS:
+        assert hasattr(L, sym), f"libskred_amd.so does not export {sym}"
 
 
 def test_library_exports_every_declared_symbol():

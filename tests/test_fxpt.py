@@ -259,3 +259,114 @@ def test_fx_bad_arguments():
     with pytest.raises(device.SkredAmdError):
         db.upload(b)
     db.close()
+
+
+def test_fx_master_definition_properties():
+    """CPU definition of the integer master stage: the gain climbs monotonically from 0 to its target and rests there exactly
+    (Q31 state: the smoother stalls within 2^-22 of the target); the output is the mix scaled by the Q15 gain, floor-shifted."""
+    mix = np.tile(np.array([[1 << 30, -(1 << 30)]], np.int64), (20000, 1))
+    out, g = cpuref.fx_master(fxbank.MASTER_TARGET_Q31, fxbank.MASTER_K_Q15, 0, mix)
+    gains = out[:, 0] * 32768 // (1 << 30)
+    assert (np.diff(gains) >= 0).all() and gains[0] < gains[-1]
+    assert abs(g - fxbank.MASTER_TARGET_Q31) < 512 and gains[-1] == (g >> 16)
+    assert (out[:, 1] == ((-(1 << 30)) * (out[:, 0] * 32768 // (1 << 30))) >> 15).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,frames", [(3000, 700), (70000, 512), (1 << 20, 512)])
+def test_fx_render_mix_is_one_launch_with_the_master_stage(n, frames):
+    """skred_fxbank_render_mix: render + in-kernel mix-down + integer master stage in one launch, over several blocks (the
+    gain carries), == the definition bit for bit; and skred_fxbank_render + skred_fxbank_master (the multi-GPU split) gives
+    the same bytes.  Flat (<= 64 rows) and two-level mix-downs, up to the bench's 2^20 voices."""
+    import torch
+    b, pool, c0 = fxbank.bank_fx(n)
+    ref, cnt, g = b.copy(), c0, 0
+    want = []
+    blocks = 3 if n <= 70000 else 2
+    for _ in range(blocks):
+        mix, _, cnt = cpuref.fx_render(ref, pool, cnt, frames, 1, fast=(n > 70000))
+        out, g = cpuref.fx_master(fxbank.MASTER_TARGET_Q31, fxbank.MASTER_K_Q15, g, mix)
+        want.append(out)
+    for split in (False, True):
+        db = fxbank.DeviceFxBank(n)
+        db.set_tables(pool)
+        db.upload(b)
+        db.set_sample_count(c0)
+        d_out = torch.zeros(frames, 2, dtype=torch.int64, device="cuda")
+        d_sum = torch.zeros(frames, 2, dtype=torch.int64, device="cuda")
+        for k in range(blocks):
+            if split:
+                db.render(frames, d_sum.data_ptr(), 1)
+                db.master(d_sum.data_ptr(), frames, d_out.data_ptr())
+            else:
+                db.render_mix(frames, d_out.data_ptr(), 1)
+            torch.cuda.synchronize()
+            assert (d_out.cpu().numpy() == want[k]).all(), (split, k)
+        assert db.master_gain() == g
+        got = b.copy()
+        db.download(got)
+        db.close()
+        assert not got.rw_mismatch(ref), got.rw_mismatch(ref)
+
+
+@pytest.mark.gpu
+def test_fx_stamps_on_resident_voices():
+    """skred_fxbank_stamp: note-offs and note-ons on device-resident voices, stamped with the bank's clock when they run,
+    against the definition given the same stores at the same blocks (release only takes if the envelope is active)."""
+    n, frames = 6000, 256
+    b, pool, c0 = fxbank.bank_fx(n)
+    b["is_active"][::9] = 0                                # some voices are not sounding: a release must not stamp them
+    ref, cnt = b.copy(), c0
+    db = fxbank.DeviceFxBank(n)
+    db.set_tables(pool)
+    db.upload(b)
+    db.set_sample_count(c0)
+    rng = np.random.default_rng(3)
+    for k in range(12):
+        off = rng.choice(n, 40, replace=False).astype(np.int32)
+        on = rng.choice(n, 40, replace=False).astype(np.int32)
+        db.stamp(off, fxbank.FX_STAMP_RELEASE)
+        db.stamp(on, fxbank.FX_STAMP_TRIGGER)
+        act = ref["is_active"][off] != 0
+        ref["sample_release"][off[act]] = cnt
+        ref["sample_start"][on] = cnt
+        ref["sample_release"][on] = 0
+        ref["is_active"][on] = 1
+        mix, _ = db.render_host(frames, 1)
+        want, _, cnt = cpuref.fx_render(ref, pool, cnt, frames, 1)
+        assert (mix == want).all(), k
+    got = b.copy()
+    db.download(got)
+    db.close()
+    assert not got.rw_mismatch(ref), got.rw_mismatch(ref)
+
+
+@pytest.mark.gpu
+def test_fx_shard_with_one_rank_rccl_equals_the_unsharded_render():
+    """skred_fxshard_*: the fixed-point bank through the N > 1 sequence (sum-only render -> ncclReduce(sum, int64) -> integer
+    master stage on the root) with the library's own one-rank RCCL communicator: the bytes of skred_fxbank_render_mix."""
+    import ctypes as C
+    import torch
+    from skred_amd.sharded import Shard, _lib
+    n, frames = 20000, 300
+    b, pool, c0 = fxbank.bank_fx(n)
+    ref, cnt, g = b.copy(), c0, 0
+    L = fxbank._bind(_lib())
+    h = C.c_void_p()
+    assert L.skred_fxshard_create(0, 0, 1, 0, n, C.byref(h)) == 0
+    fx = fxbank.DeviceFxBank.borrowed(L.skred_fxshard_bank(h), n)
+    fx.set_tables(pool)
+    cb = b.as_c()
+    assert L.skred_fxshard_upload(h, C.byref(cb)) == 0
+    fx.set_sample_count(c0)
+    idb = C.create_string_buffer(Shard.rccl_unique_id(), 128)
+    assert L.skred_shard_init_rccl(h, idb) == 0
+    assert L.skred_shard_set_ops(h, None, 1) == 0
+    d_out = torch.zeros(frames, 2, dtype=torch.int64, device="cuda")
+    for k in range(3):
+        assert L.skred_shard_render_mix(h, frames, 1, None, d_out.data_ptr(), 2, None) == 0, L.skred_amd_last_error()
+        torch.cuda.synchronize()
+        mix, _, cnt = cpuref.fx_render(ref, pool, cnt, frames, 1)
+        want, g = cpuref.fx_master(fxbank.MASTER_TARGET_Q31, fxbank.MASTER_K_Q15, g, mix)
+        assert (d_out.cpu().numpy() == want).all(), k
+    L.skred_shard_destroy(h)

@@ -806,6 +806,40 @@ def test_noise_voices_on_the_specialised_kernel(dev, recipe, interp):
     assert rel_rms(mix, ref_mix) <= 1e-5
 
 
+def _without_guards(bank, tables):
+    """The same pool with every guard sample (the float behind a table: banks.py) overwritten: no voice is SKF_GUARD any more, the
+    linear lookup takes its general form (fold test at the loop end).  The oracle never reads those floats."""
+    t = tables.copy()
+    pos = np.unique(bank["voice_table_offset"].astype(np.int64) + bank["voice_table_size"].astype(np.int64))
+    t[pos[pos < len(t)]] = np.float32(7.0)
+    return t
+
+
+@pytest.mark.parametrize("recipe,interp,one_voice", [("c1", 1, True), ("c2", 1, True), ("c2", 1, False)])
+def test_linear_lookup_guarded_and_general_forms_agree(dev, recipe, interp, one_voice):
+    """Linear interpolation on LUT banks has two instantiations: without the fold test when every voice loops over a whole table
+    that has a guard sample behind it (INTERP == 2), and the general one.  Same bank, pool with and without guards: per-voice
+    state bit for bit equal to each other and to the oracle, on the one-voice and the two-per-lane kernels."""
+    n = 5000
+    bank, tables, g = banks.RECIPES[recipe](n)
+    ref_bank, ref_g = bank.copy(), g.copy()
+    r = cpuref.render(ref_bank, ref_g, tables, 700, interp)
+    ref_mix = cpuref.master(ref_g, r["sum64"].astype(np.float32))
+    for pool in (tables, _without_guards(bank, tables)):
+        db = dev.DeviceBank(n)
+        db.set_tables(pool)
+        db.upload(bank)
+        db.set_globals(g)
+        db.fast2_min_voices(1 << 30 if one_voice else 0)
+        mix, _ = db.render_host(700, 2, interp)
+        assert db.last_kernel() == (1 if one_voice else 3)
+        got = bank.copy()
+        db.download(got)
+        db.close()
+        assert not got.rw_equal(ref_bank), got.rw_equal(ref_bank)
+        assert rel_rms(mix, ref_mix) <= 1e-5
+
+
 @pytest.mark.parametrize("recipe,interp", [("c1", 0), ("c2", 0), ("c2", 1), ("c4", 0), ("c4", 1)])
 def test_two_per_lane_kernel_matches_oracle(dev, recipe, interp):
     """sk_render_fast2_kernel (two voices per lane, packed fp32): per-voice state bit-exact against the

@@ -67,3 +67,27 @@ def test_sharded_matches_single_process(tmp_path, world, n, form):
     ref, _ = cpuref.synth(bank, g, tables, frames * steps)
     err = np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))
     assert err <= 1e-5, err
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fixed_point_shards_sum_exactly(tmp_path, world):
+    """The fixed-point path through the same C sequencing (int64 partials, gloo's integer sum): the root's output equals the
+    single-process definition BIT FOR BIT, whatever the number of ranks -- integer sums do not depend on the order."""
+    from skred_amd import fxbank
+    n, frames, steps = 1500, 200, 3
+    out = str(tmp_path / "fxmix.npy")
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), out, str(n), str(frames), str(steps), "fx"], env=env))
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    got = np.load(out)
+    b, pool, cnt = fxbank.bank_fx(n)
+    g, want = 0, []
+    for _ in range(steps):
+        mix, _, cnt = cpuref.fx_render(b, pool, cnt, frames, 1)
+        o, g = cpuref.fx_master(fxbank.MASTER_TARGET_Q31, fxbank.MASTER_K_Q15, g, mix)
+        want.append(o)
+    assert got.dtype == np.int64 and (got == np.concatenate(want)).all()

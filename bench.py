@@ -189,7 +189,15 @@ def roofline(workload, voices, frames, gather_bytes, k_mean, k_min, k_cnt, kerne
         req = pm["l2_read_requests_per_launch"]
         out["l2_requests"] = {"bound": "l2_read_requests", "achieved": req / (k_mean * 1e-3), "peak": pm["l2_request_peak_per_s"],
                               "unit": "requests/s", "frac": req / (k_mean * 1e-3) / pm["l2_request_peak_per_s"],
-                              "requests_per_launch": req, "peak_source": pm.get("l2_request_peak_source", "")}
+                              "requests_per_launch": req, "peak_source": pm.get("l2_request_peak_source", ""),
+                              "units_note": "achieved counts CACHE-LINE requests that reached L2 (TCP_TCC_READ_REQ), peak counts LANE requests "
+                                            "of the microbenchmark: not the same unit -- see gather_rate for the like-for-like figure"}
+        # like for like: one lane-iteration of tools/ta_rate.hip's refill mode = one voice-frame of the kernel (every 8th iteration
+        # a lane fetches its 5 x 16 bytes): the kernel's voice-frames per second against the microbenchmark's lane-iterations per second
+        lane_peak = pm["l2_request_peak_per_s"] * 8.0 / 5.0
+        out["gather_rate"] = {"bound": "texture-address / L1 request rate of the window refill pattern", "achieved": voices * frames / (k_mean * 1e-3),
+                              "peak": lane_peak, "unit": "lane-iterations/s (= voice-frames/s)", "frac": voices * frames / (k_mean * 1e-3) / lane_peak,
+                              "peak_source": pm.get("l2_request_peak_source", "")}
     return out
 
 
@@ -481,11 +489,12 @@ def main():
         if not interp:
             def block_lin(frames):
                 db.render_mix(frames, out.data_ptr(), 2, 0, 1, stream)
-            dtl, kml, knl, kcl = timed(block_lin, db, F, a.steps, a.warmup, every)
+            steps_l = max(60, a.steps)                    # (another instantiation of the kernel: its own warm-up)
+            dtl, kml, knl, kcl = timed(block_lin, db, F, steps_l, 20, min(8, max(1, steps_l // 10)))
             rlin = roofline(a.workload, bank_voices, F, gather_bytes, kml, knl, kcl, KERNELS.get(db.last_kernel(), "?"))
             rlin.pop("traffic", None); rlin.pop("traffic_rate", None); rlin.pop("traffic_frac", None)   # (the PMC pass was the truncating run)
-            rlin["value"] = bank_voices * F * a.steps / dtl
-            rlin["ms_per_step"] = dtl / a.steps * 1e3
+            rlin["value"] = bank_voices * F * steps_l / dtl
+            rlin["ms_per_step"] = dtl / steps_l * 1e3
             rlin["interp"] = "linear"
             res[a.workload + "_linear"] = rlin
         # ---- other block lengths on the same bank (state keeps running): F = 64 (1.33 ms callbacks: the per-launch state

@@ -261,5 +261,42 @@ def bank_c4(n: int = 262144, sample_rate: int = 48000, seed: int = SEED) -> Tupl
     return b, pool, g
 
 
+PATCH_DIR = os.path.join(os.path.dirname(_HERE), "tests", "golden")
+
+
+def bank_patch(patch: str, n: int, sample_rate: int = 44100) -> Tuple[VoiceBank, np.ndarray, GlobalsC]:
+    """A reference PATCH tiled over a large bank: the voice state the unmodified reference holds after loading `patch`
+    (tests/golden/patch_<patch>.npz, written by tests/golden/gen_patch_voices.py from the reference's own wire()) -- its first K
+    voices, K the smallest power of two that holds every voice in use -- repeated n / K times, every copy with its modulator
+    indices moved along (a copy never straddles an aligned 64-voice group) and its start phases spread by the LCG.  The routings
+    the shipped patches use: a modulator shared by three carriers (3sk), frequency + pan modulation from two voices and sample &
+    hold (37sk), chains (7sk), a modulator BELOW its carrier (18sk)."""
+    z = np.load(os.path.join(PATCH_DIR, f"patch_{patch}.npz"))
+    from .bank import FIELDS
+    src = {name: z["in_" + name] for name, _, _ in FIELDS}
+    used = np.where((src["voice_amp"] != 0) & (src["voice_table_size"] > 0))[0]
+    K = 1
+    while K <= int(used.max()):
+        K *= 2
+    assert K <= 64 and n % K == 0
+    b = VoiceBank(n)
+    copies = n // K
+    for name, _, _ in FIELDS:
+        b.a[name] = np.ascontiguousarray(np.tile(src[name][:K], copies))
+    base = np.repeat(np.arange(copies, dtype=np.int32) * K, K)
+    for f in ("voice_freq_mod_osc", "voice_amp_mod_osc", "voice_pan_mod_osc", "voice_cz_mod_osc"):
+        m = b.a[f]
+        b.a[f] = np.where(m >= 0, m + base, m).astype(np.int32)
+    dead = np.ones(K, bool)
+    dead[used[used < K]] = False
+    b.a["voice_amp"][np.tile(dead, copies)] = 0.0           # slots the patch does not use stay silent (skipped)
+    u = lcg_uniform(n, SEED)
+    span = np.maximum(b.a["voice_table_size"].astype(np.float32) - np.float32(1.0), np.float32(0.0))
+    b.a["voice_phase"] = (u * span).astype(np.float32)
+    g = GlobalsC.defaults()
+    g.synth_sample_count = 2 * sample_rate
+    return b, z["tables"].astype(np.float32), g
+
+
 RECIPES = {"c1": bank_c1, "c2": bank_c2, "c3": bank_c2, "c4": bank_c4}
 DEFAULT_N = {"c1": 4096, "c2": 65536, "c3": 1048576, "c4": 262144}

@@ -24,11 +24,13 @@ typedef struct {
   hipEvent_t ev;              /* fired once the copy and the scatter that read them have run */
 } sk_upd_slot_t;
 #define SK_FM2_MIN_VOICES 1024      /* two-operator FM banks at least this large keep each (carrier, modulator) pair in one lane */
-#define SK_FAST2_MOTION_MIN_VOICES 393216   /* ... while envelopes move: banks smaller than this stay on the one-voice kernel */
+#define SK_FAST2_MOTION_MIN_VOICES 278528   /* ... while envelopes move: banks smaller than this stay on the one-voice kernel (round 3, the envelope kernel
+                                               beside the steady one: 262 144 voices 184 vs 198 us per block, 294 912 voices 214 vs 202; tools/ab_env_mid.py) */
 #define SK_FAST2_MIN_VOICES 212992   /* banks at least this large use two voices per lane (measured crossover, 512-frame blocks, C2 recipe: 196608 voices 86 vs 95 us, 262144 voices 108 vs 101 us; profiles/r02_v1_measure_banks.txt) */
 
 struct skred_bank {
   int device;
+  int n_cus;                  /* compute units of the device (the two-per-lane kernel's passes come one per CU, then two) */
   int n_voices, n_padded, n_groups;
   sk_plane_t *d_planes;       /* the slab behind d_ro[] / d_rw[] */
   sk_plane_t *d_ro[SKP_COUNT];

@@ -90,7 +90,8 @@ enum {
 #ifndef SK_FAST2_NW_LDS
 #define SK_FAST2_NW_LDS 8   /* sk_render_fast2_kernel, LDS-table banks: wavefronts (128-voice slices) per workgroup pass */
 #endif
-#define SK_LDS_TABLE_MAX_FLOATS 12288  /* 48 KiB: pools up to this size are staged in LDS */
+#define SK_LDS_TABLE_MAX_FLOATS 12320  /* 48 KiB + the pad the host appends (SK_TABLE_PAD): pools up to this size are staged in LDS --
+                                          three of the reference's 4096-entry built-in waves still fit */
 #define SK_MAX_WORKGROUPS 2048
 #define SK_WIN 20                  /* floats of one voice's table window (skred_render_fast2.hip: 8 frames at up to
                                       2.1875 table samples per frame, plus the second tap) */

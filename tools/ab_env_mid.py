@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from skred_amd import banks, device
 F = 512
-for rec, n in (("c2", 65536), ("c2", 131072), ("c1", 4096), ("c2", 262144), ("c2", 393216), ("c2", 524288), ("c2", 786432)):
+SIZES = [int(x) for x in sys.argv[1:]] or [65536, 131072, 262144, 393216, 524288, 786432]
+for rec, n in [("c2", x) for x in SIZES]:
     for min2, label in ((1 << 30, "one per lane"), (0, "two per lane + envelope kernel")):
         bank, t, g = banks.RECIPES[rec](n)
         out = torch.zeros(F, 2, device="cuda")

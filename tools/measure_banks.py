@@ -3,11 +3,14 @@
 
   kernels    the users of the one-voice kernel at BASELINE sizes (C1/C2, 2^18 / 2^20 banks forced onto it, FM, one-shots)
   crossover  one voice per lane vs two per lane, 32 768 .. 262 144 voices  (SK_FAST2_MIN_VOICES)
-  overhead   per-block time outside the render kernel on small banks (overlapped tail, sampled kernel timing)
+  overhead   what the event pairs of the sampled kernel timing cost a small bank per block
   frames     kernel time vs frames per launch on a 4096-voice bank (per-frame cost of a lone wavefront + fixed cost)
   fm         2^20-voice two-operator FM banks (carrier v, modulator v+1)
   noise      2^20-voice banks with w6 voices, specialised vs generic kernel
   live       notes starting / ending every block on a 2^20-voice bank (cost of control)
+  patches    2^20-voice banks made by tiling a reference patch (banks.bank_patch: the routings of 3.sk, 37.sk, 1.sk, 7.sk, 18.sk)
+  linear     C1 / C2 / C3 with linear interpolation, pools with and without guard samples
+  mid        mid-size enveloped banks: which kernel family renders them, steady
 
 Each line: ms per block over the timed blocks (wall clock), voice-samples/s, and the render kernel's duration from the
 library's own event pair around the latest bracketed launch (a bracketed launch runs alone).  kernels / fm / noise print
@@ -24,8 +27,6 @@ from skred_amd import banks, device  # noqa: E402
 
 
 def run(name, bank, tables, g, interp=0, F=512, steps=60, min2=None, generic=False, overlap=None, timing=4):
-    """overlap=None: both forms of the block (tail overlapped with the next render / in stream order), two lines."""
-    overlap = False          # (a block is one launch since round 2: there is no tail to overlap; the parameter stays for old scripts)
     n = bank.n
     out = torch.zeros(F, 2, device="cuda")
     db = device.DeviceBank(n)
@@ -35,7 +36,6 @@ def run(name, bank, tables, g, interp=0, F=512, steps=60, min2=None, generic=Fal
     if min2 is not None:
         db.fast2_min_voices(min2)
     db.force_generic(generic)
-    db.overlap_tail(overlap)
     db.kernel_timing(timing)
     for _ in range(25):
         db.render_mix(F, out.data_ptr(), 2, 0, interp)
@@ -101,9 +101,8 @@ def crossover():
 def overhead():
     for n in (4096, 65536):
         b, t, g = banks.bank_c1(n)
-        run(f"c1 {n} overlapped tail, timing every 4th", b, t, g, steps=200, overlap=True)
-        run(f"c1 {n} overlapped tail, no timing", b, t, g, steps=200, timing=0, overlap=True)
-        run(f"c1 {n} in-order tail, no timing", b, t, g, steps=200, timing=0, overlap=False)
+        run(f"c1 {n} an event pair on every 4th launch", b, t, g, steps=200)
+        run(f"c1 {n} no event pairs", b, t, g, steps=200, timing=0)
 
 
 def frames():
@@ -147,6 +146,31 @@ def noise():
         run("c2 2^20 " + label + " (generic kernel)", b, t, g, steps=30, generic=True)
 
 
+def patches():
+    for p in ("3sk", "37sk", "1sk", "7sk", "18sk"):
+        b, t, g = banks.bank_patch(p, 1 << 20)
+        run(f"patch {p} tiled over 2^20 voices", b, t, g, steps=20)
+
+
+def linear():
+    for rec, n in (("c1", 4096), ("c2", 65536), ("c2", 1 << 20)):
+        b, t, g = banks.RECIPES[rec](n)
+        run(f"{rec} {n} truncating lookup", b, t, g, interp=0)
+        run(f"{rec} {n} linear, guarded pool (INTERP 2)", b, t, g, interp=1)
+        tn = t.copy()
+        pos = np.unique(b["voice_table_offset"].astype(np.int64) + b["voice_table_size"].astype(np.int64))
+        tn[pos[pos < len(tn)]] = 7.0
+        run(f"{rec} {n} linear, pool without guard samples (general form)", b, tn, g, interp=1)
+
+
+def mid():
+    for n in (196608, 229376, 262144, 294912, 327680, 360448, 393216, 458752, 524288):
+        b, t, g = banks.bank_c2(n)
+        run(f"c2 {n} library's choice", b, t, g, steps=100)
+        run(f"c2 {n} one per lane", b, t, g, min2=1 << 30, steps=100)
+        run(f"c2 {n} two per lane", b, t, g, min2=1, steps=100)
+
+
 def live():
     D = device
     n, F = 1 << 20, 512
@@ -156,31 +180,34 @@ def live():
     db.set_tables(tables)
     db.upload(bank)
     db.set_globals(g)
-    db.overlap_tail(True)
     db.kernel_timing(0)
     for _ in range(30):
         db.render_mix(F, out.data_ptr(), 2)
     rng = np.random.default_rng(1)
     for frac in (0.0, 0.0001, 0.0005, 0.005, 0.02):
         k = int(n * frac)
-        for _rep in range(2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(60):
-                if k:
-                    vs = rng.choice(n, k, replace=False).astype(np.int32)
-                    db.update(bank, vs[:k // 2], D.STAMP_RELEASE)
-                    db.update(bank, vs[k // 2:], D.STAMP_TRIGGER | D.DIRTY_PHASE | D.DIRTY_PARAMS)
-                db.render_mix(F, out.data_ptr(), 2)
+        res = {}
+        for mode in ("stream", "sync"):          # blocks queued back to back (what bench.py's live_control times) / a host that waits for every block
+            for _rep in range(2):
                 torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 60
-        print(f"{frac * 100:.2f} % of the voices get a note-off / note-on per block: {dt * 1e3:.3f} ms/block  "
-              f"{n * F / dt:.3e} voice-samples/s")
+                t0 = time.perf_counter()
+                for _ in range(60):
+                    if k:
+                        vs = rng.choice(n, k, replace=False).astype(np.int32)
+                        db.update(bank, vs[:k // 2], D.STAMP_RELEASE)
+                        db.update(bank, vs[k // 2:], D.STAMP_TRIGGER | D.DIRTY_PHASE | D.DIRTY_PARAMS)
+                    db.render_mix(F, out.data_ptr(), 2)
+                    if mode == "sync":
+                        torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                res[mode] = (time.perf_counter() - t0) / 60
+        print(f"{frac * 100:.2f} % of the voices get a note-off / note-on per block: {res['stream'] * 1e3:.3f} ms/block queued back to back "
+              f"({n * F / res['stream']:.3e} voice-samples/s), {res['sync'] * 1e3:.3f} ms/block when the host waits for every block")
     db.close()
 
 
 SCENARIOS = {"kernels": kernels, "crossover": crossover, "overhead": overhead, "frames": frames, "fm": fm,
-             "noise": noise, "live": live}
+             "noise": noise, "live": live, "patches": patches, "linear": linear, "mid": mid}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(SCENARIOS)

@@ -20,7 +20,7 @@ def main():
     traffic_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     traffic = json.load(open(traffic_path))
     ta = {}
-    ta_file = os.path.join(ROOT, "gpurun_out", "ta_rate_r02.txt")
+    ta_file = os.path.join(ROOT, "profiles", "r03_ta_rate.txt")
     if os.path.exists(ta_file):
         import re
         for line in open(ta_file):
@@ -32,6 +32,7 @@ def main():
         if not os.path.isdir(d):
             continue
         stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
+        stats = [f for f in stats if "sk_render" in open(f).read()]      # (bench.py's child processes -- tools/issue_rate -- are traced too)
         if stats:
             shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{prefix}_{w}_kernel_stats.csv"))
         B = gbytes + 292.0 / 512
@@ -39,7 +40,7 @@ def main():
                               "--frames", "512", "--voices-per-wave", str(vpw), "--algorithmic-bytes-per-voice-sample", str(B),
                               "--command", f"tools/profile_round.sh {w} {tag} (rocprofv3 --pmc ... -- python3 bench.py --workload {w} --steps 5 "
                                            "--warmup 5 --no-cpu --no-extra --time-every 1; separate passes for FETCH_SIZE, WRITE_SIZE, SQ and memory counters)",
-                              "--note", f"round 2: {w} on {kernel}; one dispatch = one block (render + in-kernel mix-down + master volume)",
+                              "--note", f"round 3: {w} on {kernel}; one dispatch = one block (render + in-kernel mix-down + master volume)",
                               os.path.join(d, "fetch"), os.path.join(d, "write"), os.path.join(d, "sq"), os.path.join(d, "mem")],
                              capture_output=True, text=True, check=True)
         summ = json.loads(out.stdout)
@@ -61,7 +62,7 @@ def main():
                 # the tool counts lane-iterations; that mode issues 5 dwordx4 lane-requests per 8 of them
                 e["l2_request_peak_per_s"] = ta[key] * 5.0 / 8.0
                 e["l2_request_peak_source"] = ("tools/ta_rate.hip on the same box, mode '5 x dwordx4 every 8th iter' (the window refill pattern: "
-                                               f"{ta[key]:.3e} lane-iterations/s x 5/8 lane-requests each), gpurun_out/ta_rate_r02.txt")
+                                               f"{ta[key]:.3e} lane-iterations/s x 5/8 lane-requests each), profiles/r03_ta_rate.txt")
         traffic[w] = e
         print(w, json.dumps({k: summ.get(k) for k in ("per_wave_frame", "valu_busy_fraction", "ta_busy_fraction", "kernel_cycles_per_xcd")}),
               "hbm MB", summ["hbm_bytes_per_launch"]["total"] / 1e6)

@@ -313,10 +313,17 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
                                       launches; an event pair costs ~6 us of stream time on an MI355X, hence the knob */,
        SKRED_OPT_FM2_MIN_VOICES = 5 /* bank size from which a two-operator FM bank (every carrier an even voice, frequency-
                                        modulated by the voice after it and by nothing else) keeps carrier and modulator in
-                                       one lane of the two-voices-per-lane kernel */ };
+                                       one lane of the two-voices-per-lane kernel */,
+       SKRED_OPT_IN_PLACE = 6 /* how the motion list of a two-voices-per-lane LDS-table bank is rendered while it is short: in the
+                                 steady kernel's own lanes, from per-frame gain rows written by sk_gain_kernel just ahead of it
+                                 ("in place"), or by the envelope kernel beside the steady one.  1 (default): in place where that
+                                 is the faster path (sparse lists; bank sizes at which a second kernel costs the steady one a
+                                 whole round of workgroups); 0: never; 2: whenever the rows provably suffice (tests).  Same
+                                 per-voice results either way */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */
+int  skred_bank_last_in_place(const skred_bank_t *bank);  /* 1: the latest block rendered its motion list in place (SKRED_OPT_IN_PLACE) */
 
 /* Cross-check of the motion list of the two-voices-per-lane path ("The motion list"): voices whose envelope may be
  * in motion are kept on a per-voice list ON THE DEVICE (every control action lists the voices it touches, the envelope kernel

@@ -81,11 +81,12 @@ static int bank_build(skred_bank_t *b) {
   HIP_TRY(hipMemset(b->d_env_list, 0, (size_t)b->n_groups * SK_GROUP * sizeof(int32_t)));
   HIP_TRY(hipMalloc((void **)&b->d_env_off, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
   HIP_TRY(hipMemset(b->d_env_off, 0, (size_t)(b->n_groups * 2 + 1) * sizeof(int32_t)));
-  /* the motion list, double-buffered (a bit per voice), and the violation counter behind it: one allocation */
+  /* the motion list, double-buffered (a bit per voice), and behind it the violation counter and sk_gain_kernel's two counters
+   * (skred_device_layout.h: env_count): one allocation */
   {
     const size_t words = (size_t)b->n_groups * 4;
-    HIP_TRY(hipMalloc((void **)&b->d_mask[0], (2 * words + 1) * sizeof(uint64_t)));
-    HIP_TRY(hipMemset(b->d_mask[0], 0, (2 * words + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&b->d_mask[0], (2 * words + 2) * sizeof(uint64_t)));   /* + violations, env_count[0], env_count[1], pad */
+    HIP_TRY(hipMemset(b->d_mask[0], 0, (2 * words + 2) * sizeof(uint64_t)));
     b->d_mask[1] = b->d_mask[0] + words;
     b->d_violations = (uint32_t *)(b->d_mask[0] + 2 * words);
     b->mask_dirty = 1;
@@ -127,6 +128,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   b->n_groups = ((n_voices + 4 * SK_GROUP - 1) / (4 * SK_GROUP)) * 4;   /* multiple of 4: the two-per-lane kernel takes up to 1024 voices per pass */
   b->fast2_min_voices = SK_FAST2_MIN_VOICES;
   b->fm2_min_voices = SK_FM2_MIN_VOICES;
+  b->in_place_mode = 1;
   b->timing_every = 1;
   b->pp_parity = -1;
   b->n_padded = b->n_groups * SK_GROUP;
@@ -168,6 +170,7 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_level) hipFree(b->d_level);
   if (b->d_group_flag) hipFree(b->d_group_flag);
   if (b->d_env_list) hipFree(b->d_env_list);
+  if (b->d_env_gain) hipFree(b->d_env_gain);
   if (b->d_env_off) hipFree(b->d_env_off);
   if (b->d_mask[0]) hipFree(b->d_mask[0]);
   if (b->side) hipStreamDestroy(b->side);
@@ -288,12 +291,14 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
     case SKRED_OPT_FORCE_GENERIC: b->force_generic = value != 0; return SKRED_OK;
     case SKRED_OPT_FAST2_MIN_VOICES: b->fast2_min_voices = value; b->fast2_min_user = 1; return SKRED_OK;
     case SKRED_OPT_FM2_MIN_VOICES: b->fm2_min_voices = value; return SKRED_OK;
+    case SKRED_OPT_IN_PLACE: b->in_place_mode = value < 0 ? 0 : value > 2 ? 2 : value; return SKRED_OK;
     case SKRED_OPT_KERNEL_TIMING: b->timing_every = value < 0 ? 0 : value; return SKRED_OK;
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
 }
 
 int skred_bank_last_kernel(const skred_bank_t *b) { return b ? b->last_kernel : -1; }
+int skred_bank_last_in_place(const skred_bank_t *b) { return b ? b->last_in_place : 0; }
 unsigned skred_bank_list_violations(const skred_bank_t *b) { return b ? b->violations_seen : 0u; }
 
 int skred_bank_download(skred_bank_t *b, skred_voice_bank_t *h, int src_first, int dst_first, int count) {
@@ -378,6 +383,11 @@ static void poll_reports(skred_bank_t *b) {
          * empty too (a list is the survivors of the one before plus what control actions add) -- a structural fact, not an
          * inference about envelopes.  And the cross-check counter of sk_render_fast2_kernel: should it ever move, rebuild. */
         if (b->report_kind[slot] == 2 && found == 0 && fresh) b->list_empty = 1;
+        if (b->report_kind[slot] == 2 && (int32_t)(t0 - b->bound_min_ticket) >= 0) {   /* (not a list from before the last rebuild) */
+          b->bound_len = found;
+          b->bound_touched = b->report_touched[slot];
+          b->bound_valid = 1;
+        }
         if ((uint32_t)w1 != b->violations_seen) {
           b->violations_seen = (uint32_t)w1;
           b->mask_dirty = 1;
@@ -399,6 +409,7 @@ static int expect_report(skred_bank_t *b, sk_render_args_t *a, int kind) {
   b->report_ticket[slot] = a->launch_ticket;
   b->report_epoch[slot] = b->control_epoch;
   b->report_kind[slot] = (uint8_t)kind;
+  b->report_touched[slot] = b->touched_total;
   a->report = (unsigned long long *)b->h_report;
   return SKRED_OK;
 }
@@ -502,9 +513,51 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
       if (ec != hipSuccess) return fail(SKRED_E_NO_DEVICE, "classify launch -> %s", hipGetErrorString(ec));
       b->mask_dirty = 0;
       b->list_empty = 0;
+      b->bound_valid = 0;                              /* the rebuilt list's length is not known until this block reports it */
+      b->bound_min_ticket = b->launch_ticket + 1;
     }
   }
-  const int env_beside = two_env && !b->list_empty;
+  /* Sparse lists of LDS-table banks: the listed voices stay in their lanes (skred_gain_kernels.hip ahead of the steady kernel's
+   * in-place instantiations, same stream) instead of going through the envelope kernel beside it -- a second kernel costs the
+   * steady one a third round of workgroups however few voices it holds (DESIGN "The motion list").  The gain rows are a
+   * buffer of fixed capacity, so this path is only taken under a PROVEN bound on the list's length: the length a launch
+   * reported (sk_final_cols) plus every voice a control action has touched since that launch was issued -- a list is the
+   * survivors of the one before plus what control actions add. */
+  int inplace = 0;
+  if (two_env && !b->list_empty && b->bound_valid && b->in_place_mode && a.lds_table_floats > 0 && !(a.fast_mode & SKM_FM_PAIR)) {
+    const uint64_t bound = (uint64_t)b->bound_len + (b->touched_total - b->bound_touched);
+    const size_t stride = (size_t)num_frames + 8;
+    /* rows: SK_INPLACE_WORD_ROWS per 64-voice word of the list (handed out without an atomic), then an overflow area for words
+     * that hold more -- as large as the bound must be small, so the rows cannot run out */
+    const size_t own = (size_t)b->n_groups * 4 * SK_INPLACE_WORD_ROWS;
+    const size_t over = (size_t)b->n_voices / (b->in_place_mode == 2 ? SK_INPLACE_DENOM : 64) + 64;   /* (mode 1 never takes lists beyond n / 128) */
+    const size_t rows = own + over;
+    /* ... and only where it is the faster of the two (tools/ab_inplace.py, MI355X; DESIGN "The motion list"): every wave
+     * of the steady kernel that holds a listed voice runs its smoothers and reads gains (~ +30 %), so the list must be sparse;
+     * and the envelope kernel beside the steady one is cheap when the steady kernel's last round of workgroups leaves slots
+     * free -- it costs a whole extra round when that round is full (2^19, 2^20 voices on 256 CUs) */
+    uint64_t limit = over;
+    if (b->in_place_mode == 1) {
+      const int slots = 2 * b->n_cus, passes = b->n_groups * 2 / SK_FAST2_NW_LDS;
+      const int rounds = passes / slots, last = passes % slots;
+      if (last == 0) limit = (uint64_t)b->n_voices / (128u * (unsigned)(rounds > 0 ? rounds : 1));
+      else if (rounds == 0 || last * 20 <= slots * 11) limit = (uint64_t)b->n_voices / 600u;
+      else limit = 0;
+    }
+    if (bound <= limit && bound <= over && rows * stride * sizeof(float) <= SK_INPLACE_MAX_BYTES) {
+      if (rows * stride + 8 > b->env_gain_cap) {
+        HIP_TRY(hipDeviceSynchronize());               /* (a block on another stream may still read the old rows) */
+        if ((rc = grow(&b->d_env_gain, &b->env_gain_cap, rows * stride + 8))) return rc;
+      }
+      a.env_gain = b->d_env_gain;
+      a.env_gain_stride = (int32_t)stride;
+      a.env_gain_cap = (int32_t)rows;
+      a.env_word_rows = SK_INPLACE_WORD_ROWS;
+      a.env_count = b->d_violations + 1;
+      inplace = 1;
+    }
+  }
+  const int env_beside = two_env && !b->list_empty && !inplace;
   const int n_env = env_beside ? sk_env2_grid(&a) : 0;
   /* rows of the partial mix, the slab sums of the two-level mix-down, the per-frame master gains, and (when the envelope kernel
    * runs beside) its rows and its sum: one allocation */
@@ -551,7 +604,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   const int timed = b->timing_every > 0 && (b->launch_ticket % (uint32_t)b->timing_every) == 0;
   if (timed) HIP_TRY(hipEventRecord(b->ev0[tslot], s));
   hipError_t e;
-  if (two_env && (env_beside || (a.launch_ticket & 63u) == 0)) { if ((rc = expect_report(b, &a, env_beside ? 2 : 3))) return rc; }
+  if (two_env && (env_beside || inplace || (a.launch_ticket & 63u) == 0)) { if ((rc = expect_report(b, &a, (env_beside || inplace) ? 2 : 3))) return rc; }
   else if (one_env && (!a.skip_env2 || (a.launch_ticket & 15u) == 0)) { if ((rc = expect_report(b, &a, 1))) return rc; }
   if (env_beside) {
     /* the list of this block, then fork: everything queued on `s` so far (updates, the classify pass, the list) is ahead of
@@ -564,6 +617,11 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "envelope kernel launch -> %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(b->ev_join, b->side));
   }
+  if (inplace) {
+    e = (hipError_t)sk_launch_gain(&a, s);
+    if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "gain kernel launch -> %s", hipGetErrorString(e));
+    b->mask_p ^= 1;                                                  /* it wrote the next block's list */
+  }
   if (modulated) {
     e = (hipError_t)sk_launch_render_mod(&a, n_wg, b->d_level, b->max_level, s);
   } else {
@@ -574,11 +632,13 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     HIP_TRY(hipStreamWaitEvent(s, b->ev_join, 0));                   /* join: the block is complete on `s` */
     b->mask_p ^= 1;                                                  /* the survivors are the next block's list */
   }
+
   if (timed) {
     HIP_TRY(hipEventRecord(b->ev1[tslot], s));
     b->n_timed++;
   }
   b->last_family = b->last_kernel;
+  b->last_in_place = inplace;
 
   /* advance the timeline exactly as synth.c:521,525 do: one count and one LCG draw per frame */
   b->g.synth_sample_count += (uint64_t)num_frames;

@@ -64,7 +64,18 @@ struct skred_bank {
                                  a stretch on another kernel family, a violation report) */
   int list_empty;             /* STRUCTURAL: the last list the device built was empty and nothing was added since (no control action);
                                  the envelope kernel is then not launched -- with an empty list it has nothing to render */
-  uint32_t *d_violations;     /* sticky device counter: sk_render_fast2_kernel found a moving voice that was not listed */
+  uint32_t *d_violations;     /* sticky device counter: sk_render_fast2_kernel found a moving voice that was not listed; the word behind
+                                 it: sk_gain_kernel's row counter (skred_device_layout.h: env_count) */
+  /* listed voices rendered in place (render_block): the gain rows, and a proven upper bound on the current list's length --
+   * the length launch t reported plus the voices control actions have touched since launch t was issued */
+  float *d_env_gain;
+  size_t env_gain_cap;        /* floats */
+  uint64_t touched_total;     /* voices named by control actions so far (every one of them goes on the list: sk_list_voice) */
+  uint64_t bound_touched;     /* ... when the launch that reported bound_len was issued */
+  uint32_t bound_len, bound_min_ticket;   /* reports of launches before bound_min_ticket (the last rebuild of the list) do not count */
+  int bound_valid;
+  int last_in_place;          /* the latest block took that path */
+  int in_place_mode;          /* SKRED_OPT_IN_PLACE: 0 never, 1 where it is the faster path (default), 2 wherever the rows provably suffice */
   uint32_t violations_seen;   /* ... as last read back */
   hipStream_t side;           /* the envelope kernel's stream, beside the caller's */
   hipEvent_t ev_fork, ev_join;
@@ -98,6 +109,7 @@ struct skred_bank {
   uint32_t report_seen;                   /* ticket of the last report taken */
   uint32_t report_ticket[SK_REPORT_RING], report_epoch[SK_REPORT_RING];   /* what the launches that will report were issued under */
   uint8_t report_kind[SK_REPORT_RING];
+  uint64_t report_touched[SK_REPORT_RING];   /* touched_total when the launch was issued */
   skred_seq_t *seq;             /* the pattern step clock (skred_seq.c), created on first use */
   struct sk_pat_step *pat;      /* [SKRED_PATTERNS_MAX][SKRED_SEQ_STEPS_MAX] batches the steps apply (skred_bank_update.c) */
   float seq_rate;               /* sample rate the step clock counts blocks in (0: the reference's 44100) */
@@ -110,6 +122,9 @@ struct skred_bank {
 };
 
 /* per-voice classification (host shadow) */
+#define SK_INPLACE_WORD_ROWS 8                   /* gain rows every 64-voice word of the list owns */
+#define SK_INPLACE_DENOM 6                       /* lists up to n_voices / 6 are rendered in place (a 128-voice wave stages at most 32) */
+#define SK_INPLACE_MAX_BYTES ((size_t)4 << 30)   /* ... while the gain rows stay below this */
 #define SKC_REAL   1u   /* a voice was uploaded into this slot and it can sound (has a table) */
 #define SKC_FILTER 2u
 #define SKC_ENV    4u

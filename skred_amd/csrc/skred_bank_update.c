@@ -306,6 +306,7 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
     const hipError_t e = (hipError_t)sk_launch_stamp((const int32_t *)src, n, dirty, b->d_ro, b->d_rw, b->g.synth_sample_count, b->d_mask[b->mask_p], s);
     HIP_TRY(hipEventRecord(sl->ev, s));
     if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "stamp launch -> %s", hipGetErrorString(e));
+    b->touched_total += (uint64_t)n;
     sk_control_changed(b);
     return SKRED_OK;
   }
@@ -334,6 +335,7 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
   }
   HIP_TRY(hipEventRecord(sl->ev, s));
   if (meta && (dirty & SKRED_DIRTY_PARAMS)) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i], 1);
+  b->touched_total += (uint64_t)n;
   sk_control_changed(b);
   return SKRED_OK;
 }

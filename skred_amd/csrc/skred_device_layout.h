@@ -173,6 +173,18 @@ typedef struct {
   float *env_rows;         /* [n_env_rows][num_frames][2] */
   float *env_sum;          /* [num_frames][2] */
   uint32_t *env_ticket;    /* [1] */
+  /* ---- listed voices rendered IN PLACE (two-per-lane family, sparse lists): sk_gain_kernel, ahead of the steady kernel on the
+   * same stream, evaluates the envelope of every listed voice for every frame of the block and leaves the gains in a row of
+   * env_gain; the steady kernel's in-place instantiation keeps such a voice in its lane and feeds its smoother from that row
+   * instead of a constant.  No second kernel beside it, no list to collect. ---- */
+  float *env_gain;         /* [env_gain_cap][env_gain_stride]: row r = amp * (level * velocity) (synth.c:582; what the voice's amp smoother
+                              is fed) of every frame of the block for the voice that holds row r (env_list[voice] = r, handed out
+                              by sk_gain_kernel); NULL: the envelope kernel renders the list */
+  int32_t env_gain_stride; /* floats per row: num_frames + 8 (the steady kernel fetches one 8-frame block ahead) */
+  int32_t env_gain_cap;    /* rows: n_groups * 4 * env_word_rows that the 64-voice words of the list own, then the overflow area */
+  int32_t env_word_rows;   /* rows every 64-voice word owns (a word with more listed voices takes rows from the overflow area) */
+  uint32_t *env_count;     /* [0] the length of the list this block rendered (counted by the steady kernel's waves), [1] overflow rows
+                              handed out by sk_gain_kernel; the block's final arriver reports [0] and sets both back to 0 */
   /* ---- the block's mix-down, inside the last render kernel of the block (skred_kernel_common.hpp: sk_finish_block) ----
    * Every workgroup leaves its partial-mix row in `partial`; with `finish` set the workgroup that arrives LAST at a
    * ticket adds the rows up in a fixed order (slab by slab when there are many), writes the pre-master sum and, in

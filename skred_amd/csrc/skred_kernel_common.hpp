@@ -188,6 +188,9 @@ __device__ __forceinline__ void sk_final_cols(const sk_render_args_t &a, int tid
     uint32_t w0 = 0, w1 = 0;
     if (a.fast_mode & SKM_TWO_PER_LANE) {
       w0 = a.env_beside ? (uint32_t)__hip_atomic_load(a.env_off + a.n_groups * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#ifdef SK_TWO_PER_LANE_TU
+      if (a.env_gain) w0 = __hip_atomic_load(a.env_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the listed voices this kernel's waves counted)
+#endif
       w1 = __hip_atomic_load(a.violations, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       // one-voice family: did any workgroup see an envelope move (sk_note_moved: one word per row, written through)
@@ -202,6 +205,9 @@ __device__ __forceinline__ void sk_final_cols(const sk_render_args_t &a, int tid
       __hip_atomic_store(a.report, t | w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+#ifdef SK_TWO_PER_LANE_TU
+  if (a.env_gain && tid == 0) { a.env_count[0] = 0u; a.env_count[1] = 0u; }   // re-armed for the next block (later kernels on the stream)
+#endif
 }
 // one-voice family, RAMPK instantiation: this workgroup saw an envelope in motion in this launch (one word per row, written
 // through: the block's final arriver, possibly on another XCD, collects them for the host's report)

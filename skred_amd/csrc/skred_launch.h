@@ -5,6 +5,7 @@
  *   skred_render_generic.hip  sk_launch_render (dispatcher), sk_launch_render_mod
  *   skred_render_fast.hip     sk_launch_render_fast
  *   skred_render_fast2.hip    sk_launch_render_fast2, sk_launch_env_fast2, sk_env2_grid, sk_launch_classify
+ *   skred_gain_kernels.hip    sk_launch_gain
  *   skred_mix_kernels.hip     sk_launch_master, sk_launch_master_apply
  *   skred_update_kernels.hip  sk_launch_update
  *   skred_rec_kernels.hip     sk_launch_rec_minmax, sk_rec_partial_floats, sk_launch_rec_convert
@@ -42,6 +43,10 @@ int sk_launch_collect(const sk_render_args_t *args, hipStream_t stream);      /*
 int sk_launch_env_fast2(const sk_render_args_t *args, hipStream_t stream);
 int sk_env2_grid(const sk_render_args_t *args);
 int sk_launch_classify(const sk_render_args_t *args, uint64_t *mask, hipStream_t stream);
+/* sparse lists of LDS-table banks: the listed voices stay in their lanes.  sk_launch_gain (skred_gain_kernels.hip) writes their
+ * per-frame gains into args->env_gain and the next block's list into args->mask_next, then sk_launch_render_fast2 -- with
+ * args->env_gain set it launches the in-place instantiations -- renders the whole bank; same stream, in this order */
+int sk_launch_gain(const sk_render_args_t *args, hipStream_t stream);
 
 int sk_launch_master(const float *sum, float *out, int num_frames, int num_channels, float target, float k,
                      float *gain_state, hipStream_t stream);

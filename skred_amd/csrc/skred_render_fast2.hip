@@ -1,4 +1,5 @@
 // skred_render_fast2.hip -- sk_render_fast2_kernel / sk_render_env2_kernel: two voices per lane, large clean banks.
+#define SK_TWO_PER_LANE_TU 1   /* skred_kernel_common.hpp: the final arriver also reports and re-arms sk_gain_kernel's row counter */
 #include "skred_kernel_common.hpp"
 #include "skred_launch.h"
 
@@ -54,6 +55,10 @@ struct Fast2Regs {
   bool am_on, am_self, pm_on, pm_self, pan_dirty;
   float am_depth, pm_depth, mprev;         // mprev: voice 1's sample of the previous frame, read before this frame changes it
   uint32_t misc_x, misc_y;                 // voice 0's sample & hold words: they travel back with a modulated pan (one 16-byte store)
+  // in-place instantiation (GT): a voice on the motion list stays in its lane and takes the gain of every frame from the row
+  // sk_gain_kernel left for it (skred_device_layout.h: env_gain)
+  bool lst[2];                             // this voice is listed
+  v2f gt;                                  // the current frame's gains of the lane's listed voices (set by the caller)
 };
 
 struct Env2Regs {                 // sk_render_env2_kernel only
@@ -225,7 +230,8 @@ __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, cons
 // The rest of the frame: biquad, envelope/gain, smoother, pan, lane-local sum of the two voices.
 // EM (envelope mode): 0 every lane has a constant gain; 1 "ramp": every lane keeps one stage, straight-line
 // with the short exact division; 2 general; 3 constant gain AND the amp smoother has stalled in every lane
-// (fast2_smoother_stalled: its update no longer changes it, so it is skipped).  TAME: see fast_frame.
+// (fast2_smoother_stalled: its update no longer changes it, so it is skipped); 6: as 0 with the lane's listed voices taking
+// this frame's gain from r.gt (in-place instantiation).  TAME: see fast_frame.
 template <bool FILTER, int EM, bool TAME, bool MIXED = false, bool MUTESEL = false, int FMP = 0>
 __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f &xn, v2f &xo, v2f &yn, v2f &yo,
                                            const bool rel0, const bool rel1, const bool silent0,
@@ -249,8 +255,12 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
   }
   // ---- gain ----
   v2f gain;
-  if (EM == 0 || EM == 3) {
+  if (EM == 0 || EM == 3 || EM == 6) {
     gain = r.gain_const;
+    if (EM == 6) {                                     // a listed voice: amp * (level * velocity) of this frame from its gain row
+      gain.x = r.lst[0] ? r.gt.x : gain.x;
+      gain.y = r.lst[1] ? r.gt.y : gain.y;
+    }
   } else if (EM == 1) {
     e.clk = e.clk + 1.0f;                              // exact: clocks stay below 2^24 in this mode
     const v2f num = e.clk - e.ebase;                   // t | t - attack_time | t_release
@@ -491,6 +501,70 @@ __device__ __forceinline__ v2f fast2_osc_win(Fast2Regs &r, const WinRegs &w, con
 // the same for a tame wave with muted live lanes (tame_m): their contribution is selected away, synth.c:596
 #define SK_FAST2_LDS_BLOCK_M(J, EM_)                                                                     \
   { if (loz) SK_FAST2_LDS_BLOCK_Z(J, EM_, true, true) else SK_FAST2_LDS_BLOCK_Z(J, EM_, false, true) }
+// Eight frames of a tame wave that holds listed voices (in-place instantiation): SK_FAST2_LDS_BLOCK_Z with the listed voices'
+// gains of the block's frames in gtile[8][SK_GT_RANKS] (rank: the listed voice's number within the wave), parked there by
+// the block before.  This block fetches the NEXT eight frames at its start -- lane (frame = lane & 7, rank = (lane >> 3) +
+// 8 i) for as many i as the wave has listed voices, srank[rank] = where that voice's row starts -- and parks them behind its
+// own frames (one wavefront: its LDS accesses execute in order).
+#ifndef SK_GT_RANKS
+#define SK_GT_RANKS 32
+#endif
+#define SK_GT_LDS_FLOATS (8 * SK_GT_RANKS + SK_GT_RANKS)   /* per wave: gtile + srank */
+/* (row offsets kept in two registers per lane for the first sixteen ranks instead of read from srank, 16 ranks instead of 32,
+   a double-buffered tile: all measured within 1 % of this form -- tools/ab_gt.sh) */
+#define SK_GT_FETCH(I, F0)   /* -> pf_[I] */                                                              \
+  if (SK_GT_RANKS > 8 * (I) && gcnt > 8 * (I) && (lane >> 3) + 8 * (I) < gcnt)   /* (wave-uniform: any rank of this round; then: this lane's rank exists) */ \
+    pf_[I] = a.env_gain[srank[(lane >> 3) + 8 * (I)] + ((F0) + (lane & 7))];
+#define SK_GT_PARK(I)                                                                                    \
+  if (SK_GT_RANKS > 8 * (I) && gcnt > 8 * (I)) gtile[(lane & 7) * SK_GT_RANKS + (lane >> 3) + 8 * (I)] = pf_[I];
+#define SK_FAST2_LDS_BLOCK_G(J, EM_, LOZ_)                                                                  \
+  {                                                                                                      \
+    float *const xt_ = reinterpret_cast<float *>(xp);                                                    \
+    float pf_[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                                             \
+    SK_GT_FETCH(0, c0 + (J) + 8) SK_GT_FETCH(1, c0 + (J) + 8) SK_GT_FETCH(2, c0 + (J) + 8) SK_GT_FETCH(3, c0 + (J) + 8) \
+    v2f s0_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                               \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      float l0, r0, l1, r1;                                                                              \
+      const v2f s1_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                       \
+      r.gt.x = gtile[q_ * SK_GT_RANKS + grank[0]]; r.gt.y = gtile[q_ * SK_GT_RANKS + grank[1]];          \
+      fast2_post<FILTER, EM_, true, MIXED, false>(r, e, s0_, r.x1, r.x2, r.y1, r.y2, released[0], released[1], silent[0], silent[1], l0, r0); \
+      if (q_ < 6) s0_ = fast2_osc<TAB_LDS, true, INTERP, LOZ_>(r, lds_tab, glb_tab);                     \
+      r.gt.x = gtile[(q_ + 1) * SK_GT_RANKS + grank[0]]; r.gt.y = gtile[(q_ + 1) * SK_GT_RANKS + grank[1]]; \
+      fast2_post<FILTER, EM_, true, MIXED, false>(r, e, s1_, r.x2, r.x1, r.y2, r.y1, released[0], released[1], silent[0], silent[1], l1, r1); \
+      xt_[q_ * SK_XT2 + lane] = fold_lr(l0, r0);                                                         \
+      xt_[(q_ + 1) * SK_XT2 + lane] = fold_lr(l1, r1);                                                   \
+    }                                                                                                    \
+    SK_GT_PARK(0) SK_GT_PARK(1) SK_GT_PARK(2) SK_GT_PARK(3)                                              \
+    SK_WAVE_SYNC()                                                                                       \
+    {                                                                                                    \
+      const float4 *src_ = reinterpret_cast<const float4 *>(xt_ + (lane & 7) * SK_XT2 + (lane >> 3) * 8); \
+      const float4 a_ = src_[0], b_ = src_[1];                                                           \
+      float t_ = ((((((a_.x + a_.y) + a_.z) + a_.w) + b_.x) + b_.y) + b_.z) + b_.w;                      \
+      t_ = row_pair_add(row_ror8_add(t_));                                                               \
+      if ((lane & 24) == 0) reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (J) + (lane & 7)])[lane >> 5] = t_; \
+    }                                                                                                    \
+    SK_WAVE_SYNC()                                                                                       \
+  }
+// a chunk of a wave with listed voices: staged 8-frame blocks (the wave is tame and holds at most SK_GT_RANKS of them), then --
+// or instead -- single general frames with every listed lane reading its own row
+#define SK_FAST2_CHUNK_G()                                                                               \
+  {                                                                                                      \
+    int j = 0;                                                                                           \
+    if (gstaged) {                                                                                       \
+      if (loz) for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK_G(j, 6, true)                              \
+      else for (; j + 8 <= cn; j += 8) SK_FAST2_LDS_BLOCK_G(j, 6, false)                                 \
+    }                                                                                                    \
+    if (j < cn) {                                                                                        \
+      const int go0_ = r.lst[0] ? a.env_list[vidx[0]] * a.env_gain_stride : 0;                           \
+      const int go1_ = r.lst[1] ? a.env_list[vidx[1]] * a.env_gain_stride : 0;                           \
+      for (; j < cn; ++j) {                                                                              \
+        r.gt.x = a.env_gain[go0_ + (c0 + j)];                                                            \
+        r.gt.y = a.env_gain[go1_ + (c0 + j)];                                                            \
+        SK_FAST2_ONE(j, 6, false)                                                                        \
+      }                                                                                                  \
+      /* (if staged blocks follow in the next chunk -- a ragged chunk is the block's last -- nothing is parked for them) */ \
+    }                                                                                                    \
+  }
 // Eight frames (J..J+7) of a tame wave of a global-table bank through the table windows; DPP pair reductions.
 #define SK_FAST2_WIN_BLOCK(J, EM_)                                                                       \
   {                                                                                                      \
@@ -726,11 +800,19 @@ template <bool TAB_LDS> struct Fast2Shape { static constexpr int NW = TAB_LDS ? 
 
 // FMP: a two-operator FM bank (SKM_FM_PAIR) -- a lane holds voices 2i and 2i+1 of its slice, carrier and modulator.
 // FMP == 2 (SKM_PAIR_AP): some carrier's amplitude or pan is modulated too (by the voice after it or by itself).
-template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED, int FMP = 0>
+// GT: the in-place instantiation (LDS-table banks with envelopes; a.env_gain set): listed voices stay in their lanes, their
+// gains come from the rows sk_gain_kernel wrote just before on this stream.  A kernel of its own so that the steady
+// instantiation keeps its registers (it sits at 126 of 128).
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED, int FMP = 0, bool GT = false>
 __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
   constexpr int NW = Fast2Shape<TAB_LDS>::NW;
   SK_FAST2_PROLOGUE()
   (void)n_flags;
+  // GT: per wave, behind the tiles: gtile[8][SK_GT_RANKS] (the listed voices' gains of one 8-frame block) and
+  // srank[SK_GT_RANKS] (rank -> where that voice's row starts in a.env_gain)
+  float *const gtile = reinterpret_cast<float *>(wsum0 + 2 * NW * SK_CHUNK + NW * (8 * 65 + 64)) + wave * SK_GT_LDS_FLOATS;
+  int *const srank = reinterpret_cast<int *>(gtile + 8 * SK_GT_RANKS);
+  (void)gtile; (void)srank;
   bool first_pass = true;
   bool row_published = false;
   for (int g = bid; g < n_pass; g += a.n_rows) {
@@ -748,6 +830,11 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
     bool wave_ok = true;
+    r.lst[0] = r.lst[1] = false; r.gt = (v2f){0.0f, 0.0f};
+    int grank[2] = {0, 0};            // GT: the lane's listed voices' numbers within the wave (ascending voice order)
+    int gcnt = 0;                     // GT: listed voices of the wave
+    bool gstaged = false;             // GT: 8-frame blocks through gtile (a tame wave with at most SK_GT_RANKS listed voices)
+    (void)grank; (void)gcnt; (void)gstaged;
     if (ENV) {
       // The motion list: voices whose envelope may be in motion sit this launch out here -- pan gains at zero, exact zeros
       // into the mix, nothing stored -- and are rendered by sk_render_env2_kernel, which reads the same bits (collected into
@@ -771,13 +858,38 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
         const sk_motion_t mo = sk_env_motion(a.count0 + 1, dead[c], (r.rw[c] & SKR_ENV_ACTIVE) != 0, t_start[c], t_release[c], e.att[c],
                                              e.attdec[c], e.rel[c], e.susv[c], e.ampv[c], e.velv[c], r.k[c], r.sgain[c]);
         r.gain_const[c] = mo.gain_const;                                         // synth.c:582,588
-        if (!dead[c] && mo.code == 5) r.rw[c] &= ~SKR_ENV_ACTIVE;                // synth.c:429
+        if (!dead[c] && mo.code == 5 && !(GT && (((c ? m1 : m0) >> lane) & 1))) r.rw[c] &= ~SKR_ENV_ACTIVE;   // synth.c:429 (a listed voice's flag is sk_gain_kernel's)
         stray = stray || (mo.moving && !(((c ? m1 : m0) >> lane) & 1));
       }
       {   // cross-check of the list (unreachable by construction: see DESIGN "The motion list"): counted, the host rebuilds the list
         const uint64_t sb = __ballot(stray);
         if (sb != 0 && lane == 0) atomicAdd(a.violations, (uint32_t)__popcll(sb));
       }
+      if (GT && (m0 | m1) != 0) {
+        // in place: a listed voice keeps its lane; the gain its smoother is fed (amp * (level * velocity), synth.c:582-588)
+        // comes from the row sk_gain_kernel wrote for it, frame by frame
+        const uint64_t below = ((uint64_t)1 << lane) - 1;
+        const int n0 = __popcll(m0);
+        gcnt = n0 + __popcll(m1);
+        if (lane == 0) atomicAdd(a.env_count, (uint32_t)gcnt);   // the list's length, for the block's report (sk_final_cols)
+        grank[0] = __popcll(m0 & below);
+        grank[1] = n0 + __popcll(m1 & below);
+        gstaged = tame && TAB_LDS && gcnt <= SK_GT_RANKS;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bool listed = ((c ? m1 : m0) >> lane) & 1;
+          r.lst[c] = listed && !dead[c];
+          if (listed && gstaged) srank[grank[c]] = a.env_list[vidx[c]] * a.env_gain_stride;
+          if (!listed || !gstaged) grank[c] = 0;
+        }
+        if (gstaged) {                                  // the first block's gains
+          SK_WAVE_SYNC()
+          float pf_[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          SK_GT_FETCH(0, 0) SK_GT_FETCH(1, 0) SK_GT_FETCH(2, 0) SK_GT_FETCH(3, 0)
+          SK_GT_PARK(0) SK_GT_PARK(1) SK_GT_PARK(2) SK_GT_PARK(3)
+          SK_WAVE_SYNC()
+        }
+      } else
       if ((m0 | m1) != 0) {                           // (wave-uniform: the steady state pays for none of this)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -788,7 +900,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
           }
         wave_ok = __any((!dead[0] && !((m0 >> lane) & 1)) || (!dead[1] && !((m1 >> lane) & 1)));   // (nothing left to render: zeros to the chunk sums)
       }
-      if (!__syncthreads_or(wave_ok ? 1 : 0)) {       // nothing of this pass is rendered here
+      if (!GT && !__syncthreads_or(wave_ok ? 1 : 0)) {       // nothing of this pass is rendered here
 #pragma unroll
         for (int c = 0; c < 2; ++c)                   // (really dead voices still get voice_sample = 0, synth.c:532,538 --
           if (dead[c] && !(((c ? m1 : m0) >> lane) & 1))   //  unless they are on the list: the envelope kernel does it, and a listed pair's carrier reads it)
@@ -798,14 +910,17 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     }
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
-      if (wave_ok) {
+      if (GT && (m0 | m1) != 0) {
+        SK_FAST2_CHUNK_G()
+      } else if (wave_ok) {
         SK_FAST2_CHUNK(0)
       } else if (lane < cn) {
         wsum[wave * SK_CHUNK + lane] = make_float2(0.0f, 0.0f);             // a wave of listed voices adds nothing to the chunk
       }
       SK_FAST2_FLUSH(!first_pass)
     }
-    SK_FAST2_STORE_MINE()
+    if (GT) { const bool skip_[2] = {false, false}; fast2_store<MIXED>(a, r, dead, vidx, skip_); }
+    else SK_FAST2_STORE_MINE()
     first_pass = false;
     row_published = publish;
   }
@@ -984,7 +1099,10 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
 
 // ---------------------------------------------------------------- the motion list: collect, classify (plain TU only)
 
-#ifndef SK_FAST2_FMP_TU
+#if !defined(SK_FAST2_FMP_TU) && !defined(SK_FAST2_GT_TU)
+#define SK_FAST2_PLAIN_TU 1
+#endif
+#ifdef SK_FAST2_PLAIN_TU
 // mask[2 n] (a bit per voice; a 128-voice wave slice = two words) -> counts[n] (listed voices per slice), off[n] exclusive
 // prefix sums, off[n] = their total; and the NEXT block's mask zeroed (sk_render_env2_kernel, next on this stream, ORs its
 // survivors in).  pairs: two-operator FM banks list whole (2i, 2i+1) pairs -- either bit lists both voices.
@@ -1112,13 +1230,15 @@ extern "C" int sk_launch_classify(const sk_render_args_t *args, uint64_t *mask, 
   hipLaunchKernelGGL(sk_classify_kernel, dim3((unsigned)((args->n_groups * 2 + 3) / 4)), dim3(256), 0, stream, *args, mask);
   return (int)hipGetLastError();
 }
-#endif   // !SK_FAST2_FMP_TU
+#endif   // SK_FAST2_PLAIN_TU
 
 // ---------------------------------------------------------------- launchers (C linkage)
 
 // sk_launch_render_fast2: the steady kernel (args->skip_env2: alone; otherwise the host has put sk_launch_render_env2 on
 // its second stream first -- skred_bank.c: render_block).  sk_launch_render_env2: collect + the envelope kernel.
-#if defined(SK_FAST2_FMP_TU) && SK_FAST2_FMP_TU == 2
+#if defined(SK_FAST2_GT_TU)
+#define SK_FAST2_LAUNCHER sk_launch_render_fast2g
+#elif defined(SK_FAST2_FMP_TU) && SK_FAST2_FMP_TU == 2
 #define SK_FAST2_LAUNCHER sk_launch_render_fm2ap
 #define SK_ENV2_LAUNCHER sk_launch_env_fm2ap
 #elif defined(SK_FAST2_FMP_TU)
@@ -1131,15 +1251,16 @@ extern "C" int sk_launch_render_fm2(const sk_render_args_t *args, int n_workgrou
 extern "C" int sk_launch_render_fm2ap(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 extern "C" int sk_launch_env_fm2(const sk_render_args_t *args, hipStream_t stream);
 extern "C" int sk_launch_env_fm2ap(const sk_render_args_t *args, hipStream_t stream);
+extern "C" int sk_launch_render_fast2g(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 #endif
 
-static inline size_t sk_fast2_lds(const sk_render_args_t *args, int nw) {
+static inline size_t sk_fast2_lds(const sk_render_args_t *args, int nw, bool gt = false) {
   // LDS: [tables] + wsum[2][NW][SK_CHUNK] + per wave the transposition tile and row sums (LDS-table banks) or the table
   // windows (global-table banks)
   const bool tab_lds = args->lds_table_floats > 0;
   const size_t tab_bytes = (size_t)(tab_lds ? args->lds_table_floats : 0) * sizeof(float);
   const size_t per_wave = tab_lds ? (size_t)(8 * 65 + 64) * sizeof(float2) : (size_t)(2 * SK_WIN * 64) * sizeof(float);
-  return tab_bytes + (size_t)nw * (2 * SK_CHUNK * sizeof(float2) + per_wave);
+  return tab_bytes + (size_t)nw * (2 * SK_CHUNK * sizeof(float2) + per_wave + (gt ? (size_t)SK_GT_LDS_FLOATS * sizeof(float) : 0));
 }
 static inline int sk_fast2_key(const sk_render_args_t *args) {
   return (args->lds_table_floats > 0 ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
@@ -1149,7 +1270,17 @@ static inline int sk_fast2_key(const sk_render_args_t *args) {
    in the other translation units) */
 /* (I = 1: linear; with every live voice on a guarded whole-table loop -- args->interp == 2, SKF_GUARD -- the instantiation
    without the fold test, INTERP == 2: plain translation unit only, two-operator FM banks keep the general form) */
-#ifdef SK_FAST2_FMP_TU
+#if defined(SK_FAST2_GT_TU)
+/* (the in-place instantiations: LDS-table banks with envelopes) */
+#define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
+  case K:                                                                                               \
+    if (T && E) {                                                                                       \
+      if (I && args->interp == 2) { if (mixed) SK_FAST2_LAUNCH(true, F, true, (I ? 2 : 0), true, 0) else SK_FAST2_LAUNCH(true, F, true, (I ? 2 : 0), false, 0) } \
+      else if (mixed) SK_FAST2_LAUNCH(true, F, true, I, true, 0)                                        \
+      else SK_FAST2_LAUNCH(true, F, true, I, false, 0)                                                  \
+    } else return (int)hipErrorInvalidValue;                                                            \
+    break;
+#elif defined(SK_FAST2_FMP_TU)
 #define SK_FAST2_CASE(K, T, F, E, I)                                                                    \
   case K:                                                                                               \
     if (mixed) SK_FAST2_LAUNCH(true, F, E, I, true, SK_FAST2_FMP_TU) else SK_FAST2_LAUNCH(true, F, E, I, false, SK_FAST2_FMP_TU) \
@@ -1177,18 +1308,27 @@ static inline int sk_fast2_key(const sk_render_args_t *args) {
 extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
                                  hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
-#ifndef SK_FAST2_FMP_TU
+#ifdef SK_FAST2_PLAIN_TU
   if ((args->fast_mode & SKM_FM_PAIR) && tab_lds)
     return (args->fast_mode & SKM_PAIR_AP) ? sk_launch_render_fm2ap(args, n_workgroups, lds_bytes, stream)
                                            : sk_launch_render_fm2(args, n_workgroups, lds_bytes, stream);
+  if (args->env_gain) return sk_launch_render_fast2g(args, n_workgroups, lds_bytes, stream);
 #endif
   (void)lds_bytes;
   const int nw = tab_lds ? Fast2Shape<true>::NW : Fast2Shape<false>::NW;
+#ifdef SK_FAST2_GT_TU
+  const size_t lds_fast2 = sk_fast2_lds(args, nw, true);
+#else
   const size_t lds_fast2 = sk_fast2_lds(args, nw);
+#endif
   dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block((unsigned)nw * 64);
   const bool mixed = (args->fast_mode & SKM_MIXED) != 0;     // filter / envelope on some voices only: per-lane flags
   const int key = sk_fast2_key(args);
+#ifdef SK_FAST2_GT_TU
+#define SK_FAST2_LAUNCH(T, F, E, I, M, P) { hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, M, P, true>), grid, block, lds_fast2, stream, *args); }
+#else
 #define SK_FAST2_LAUNCH(T, F, E, I, M, P) { hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, M, P>), grid, block, lds_fast2, stream, *args); }
+#endif
   SK_FAST2_SWITCH()
 #undef SK_FAST2_LAUNCH
   return (int)hipGetLastError();
@@ -1196,7 +1336,7 @@ extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups,
 
 // the envelope kernel's workgroups the device holds at once: 3 per CU by registers (SK_ENV2_MIN_WAVES), fewer by LDS
 extern "C" int sk_env2_grid(const sk_render_args_t *args);
-#ifndef SK_FAST2_FMP_TU
+#ifdef SK_FAST2_PLAIN_TU
 extern "C" int sk_env2_grid(const sk_render_args_t *args) {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
@@ -1211,7 +1351,7 @@ extern "C" int sk_env2_grid(const sk_render_args_t *args) {
 }
 #endif
 
-#ifndef SK_FAST2_FMP_TU
+#ifdef SK_FAST2_PLAIN_TU
 // collect the list (this block's mask -> counts, offsets, voices; the next block's mask zeroed): on the block's own stream,
 // ahead of both render kernels (an idle machine runs it in ~18 us; beside a full one it took 130)
 extern "C" int sk_launch_collect(const sk_render_args_t *args, hipStream_t stream) {
@@ -1224,10 +1364,11 @@ extern "C" int sk_launch_collect(const sk_render_args_t *args, hipStream_t strea
 }
 #endif
 
+#ifndef SK_FAST2_GT_TU
 // render the list: on the SECOND stream of the block, beside the steady kernel; args->n_env_rows workgroups (sk_env2_grid)
 extern "C" int SK_ENV2_LAUNCHER(const sk_render_args_t *args, hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
-#ifndef SK_FAST2_FMP_TU
+#ifdef SK_FAST2_PLAIN_TU
   if ((args->fast_mode & SKM_FM_PAIR) != 0 && tab_lds)
     return (args->fast_mode & SKM_PAIR_AP) ? sk_launch_env_fm2ap(args, stream) : sk_launch_env_fm2(args, stream);
 #endif
@@ -1241,5 +1382,6 @@ extern "C" int SK_ENV2_LAUNCHER(const sk_render_args_t *args, hipStream_t stream
 #undef SK_FAST2_LAUNCH
   return (int)hipGetLastError();
 }
+#endif   // !SK_FAST2_GT_TU
 #undef SK_FAST2_CASE
 #undef SK_FAST2_SWITCH

@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(path)))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
 ev.sort()
 def short(n):
-    for k in ("sk_render_fast2", "sk_render_env2", "sk_collect_scan", "sk_collect_expand", "sk_update", "sk_stamp", "sk_classify"):
+    for k in ("sk_gain", "sk_render_fast2", "sk_render_env2", "sk_collect_scan", "sk_collect_expand", "sk_update", "sk_stamp", "sk_classify"):
         if k in n: return k[3:]
     return n[:24]
 steady = [i for i, e in enumerate(ev) if "sk_render_fast2" in e[2]]

@@ -539,21 +539,26 @@ def main():
         # new parameters, through skred_bank_update on the render stream
         for _ in range(12):                                    # back to the all-sustain state
             db.render_mix(F, out.data_ptr(), 2, 0, interp, stream)
-        k_ev = max(2, int(bank_voices * 0.0005))
         rng = np.random.default_rng(1)
         D = device
+        for key, share in (("live_control", 0.0005), ("live_control_sparse", 0.0001)):
+            k_ev = max(2, int(bank_voices * share))
 
-        def control_block(frames):
-            vs = rng.choice(bank_voices, k_ev, replace=False).astype(np.int32)
-            db.update(bank, vs[:k_ev // 2], D.STAMP_RELEASE, stream)
-            db.update(bank, vs[k_ev // 2:], D.STAMP_TRIGGER | D.DIRTY_PHASE | D.DIRTY_PARAMS, stream)
-            db.render_mix(frames, out.data_ptr(), 2, 0, interp, stream)
-        steps_c = max(60, a.steps)
-        dtc, kmc, knc, kcc = timed(control_block, db, F, steps_c, 20, 0)
-        res["live_control"] = {"value": bank_voices * F * steps_c / dtc, "unit": "voice-samples/s", "ms_per_step": dtc / steps_c * 1e3,
-                               "voices_touched_per_block": k_ev, "note_events_per_s": k_ev * steps_c / dtc,
-                               "what": "0.05 % of the voices per block: half note-offs (SKRED_STAMP_RELEASE), half note-ons with new "
-                                       "parameters (SKRED_STAMP_TRIGGER | DIRTY_PHASE | DIRTY_PARAMS) via skred_bank_update, then the block"}
+            def control_block(frames):
+                vs = rng.choice(bank_voices, k_ev, replace=False).astype(np.int32)
+                db.update(bank, vs[:k_ev // 2], D.STAMP_RELEASE, stream)
+                db.update(bank, vs[k_ev // 2:], D.STAMP_TRIGGER | D.DIRTY_PHASE | D.DIRTY_PARAMS, stream)
+                db.render_mix(frames, out.data_ptr(), 2, 0, interp, stream)
+            steps_c = max(60, a.steps)
+            dtc, kmc, knc, kcc = timed(control_block, db, F, steps_c, 30, 0)
+            res[key] = {"value": bank_voices * F * steps_c / dtc, "unit": "voice-samples/s", "ms_per_step": dtc / steps_c * 1e3,
+                        "voices_touched_per_block": k_ev, "note_events_per_s": k_ev * steps_c / dtc,
+                        "motion_list_rendered": "in place (sk_gain_kernel + the steady kernel's in-place instantiation)" if db.last_in_place()
+                                                else "by the envelope kernel beside the steady kernel",
+                        "what": f"{share * 100:g} % of the voices per block: half note-offs (SKRED_STAMP_RELEASE), half note-ons with new "
+                                "parameters (SKRED_STAMP_TRIGGER | DIRTY_PHASE | DIRTY_PARAMS) via skred_bank_update, then the block"}
+            for _ in range(24):                                # the notes of this leg come to rest
+                db.render_mix(F, out.data_ptr(), 2, 0, interp, stream)
     db.close()
     del bank
 

@@ -202,7 +202,8 @@ def live():
                 torch.cuda.synchronize()
                 res[mode] = (time.perf_counter() - t0) / 60
         print(f"{frac * 100:.2f} % of the voices get a note-off / note-on per block: {res['stream'] * 1e3:.3f} ms/block queued back to back "
-              f"({n * F / res['stream']:.3e} voice-samples/s), {res['sync'] * 1e3:.3f} ms/block when the host waits for every block")
+              f"({n * F / res['stream']:.3e} voice-samples/s), {res['sync'] * 1e3:.3f} ms/block when the host waits for every block"
+              f"   [motion list {'in place' if db.last_in_place() else 'by the envelope kernel' if k else '-'}]")
     db.close()
 
 

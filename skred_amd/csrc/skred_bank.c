@@ -163,8 +163,9 @@ void skred_bank_destroy(skred_bank_t *b) {
   for (int i = 0; i < SK_UPD_RING; i++) {
     if (b->upd[i].d) hipFree(b->upd[i].d);
     if (b->upd[i].h) hipHostFree(b->upd[i].h);
-    if (b->upd[i].ev) hipEventDestroy(b->upd[i].ev);
   }
+  if (b->h_upd_done) hipHostFree((void *)b->h_upd_done);
+  if (b->d_upd_cnt) hipFree(b->d_upd_cnt);
   free(b->upd_mark);
   if (b->h_report) hipHostFree((void *)b->h_report);
   if (b->d_level) hipFree(b->d_level);

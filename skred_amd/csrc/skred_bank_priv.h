@@ -21,7 +21,8 @@
 typedef struct {
   void *h, *d;                /* pinned host buffer and its device twin */
   size_t cap;                 /* bytes */
-  hipEvent_t ev;              /* fired once the copy and the scatter that read them have run */
+  uint32_t seq;               /* != 0: a batch read from this slot is in flight; its last kernel stores this number into the bank's
+                                 h_upd_done[slot] when it has run (no event: skred_update_kernels.hip, sk_batch_done) */
 } sk_upd_slot_t;
 #define SK_FM2_MIN_VOICES 1024      /* two-operator FM banks at least this large keep each (carrier, modulator) pair in one lane */
 #define SK_FAST2_MOTION_MIN_VOICES 278528   /* ... while envelopes move: banks smaller than this stay on the one-voice kernel (round 3, the envelope kernel
@@ -118,6 +119,9 @@ struct skred_bank {
   int queue_len;
   sk_upd_slot_t upd[SK_UPD_RING];   /* staging ring of the update path (skred_bank_update.c) */
   uint32_t upd_head;
+  volatile uint32_t *h_upd_done;    /* pinned [SK_UPD_RING]: the sequence number of the last batch each slot's kernels have finished with */
+  uint32_t *d_upd_cnt;              /* device [SK_UPD_RING]: arrival counters of those kernels' workgroups */
+  uint32_t upd_seq;
   uint32_t *upd_mark, upd_epoch;    /* per-voice epoch marks: duplicate voices inside one batch */
 };
 

@@ -13,6 +13,8 @@
  */
 #include <stdlib.h>
 #include <pthread.h>
+#include <sched.h>
+#include <time.h>
 #include <string.h>
 
 #include "skred_bank_priv.h"
@@ -255,13 +257,32 @@ static int build_batch(const skred_bank_t *b, const skred_voice_bank_t *h, const
   return SKRED_OK;
 }
 
-/* One staging slot of the ring: pinned host buffer, device buffer, and the event after which both may be reused.
- * With a ring the host only ever waits for a copy issued SK_UPD_RING batches ago (i.e. never, in practice); a
- * single slot would stall every update behind the render that precedes its copy in the stream. */
+/* One staging slot of the ring: pinned host buffer, device buffer, and the number of the batch after which both may be
+ * reused -- the batch's last kernel stores it into pinned memory (sk_batch_done), the host looks there.  With a ring the
+ * host only ever waits for a batch issued SK_UPD_RING batches ago (a host that queues blocks far ahead of the device is
+ * held back here, as an event would hold it); a single slot would stall every update behind the render that precedes it in
+ * the stream. */
 static int staging_slot(skred_bank_t *b, size_t bytes, hipStream_t s, sk_upd_slot_t **out) {
-  sk_upd_slot_t *sl = &b->upd[b->upd_head++ % SK_UPD_RING];
-  if (!sl->ev) HIP_TRY(hipEventCreateWithFlags(&sl->ev, hipEventDisableTiming));
-  else HIP_TRY(hipEventSynchronize(sl->ev));
+  const int idx = (int)(b->upd_head++ % SK_UPD_RING);
+  sk_upd_slot_t *sl = &b->upd[idx];
+  if (!b->h_upd_done) {
+    HIP_TRY(hipHostMalloc((void **)&b->h_upd_done, SK_UPD_RING * sizeof(uint32_t), hipHostMallocDefault));
+    for (int i = 0; i < SK_UPD_RING; i++) b->h_upd_done[i] = 0;
+    HIP_TRY(hipMalloc((void **)&b->d_upd_cnt, SK_UPD_RING * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(b->d_upd_cnt, 0, SK_UPD_RING * sizeof(uint32_t)));
+  }
+  if (sl->seq) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0; __atomic_load_n(&b->h_upd_done[idx], __ATOMIC_ACQUIRE) != sl->seq; spins++) {
+      if ((spins & 63) == 63) {
+        sched_yield();
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (t1.tv_sec - t0.tv_sec > 5) { HIP_TRY(hipDeviceSynchronize()); break; }   /* (a stream that never ran: everything has now) */
+      }
+    }
+    sl->seq = 0;
+  }
   if (bytes > sl->cap) {
     if (sl->d) { (void)hipFree(sl->d); sl->d = NULL; }
     if (sl->h) { (void)hipHostFree(sl->h); sl->h = NULL; }
@@ -303,9 +324,12 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
     for (int i = 0; i < n; i++) ids[i] = rec[i].voice;
     const void *src = sk_stage(sl, (size_t)n * sizeof(int32_t), s);
     if (!src) return SKRED_E_NO_DEVICE;
-    const hipError_t e = (hipError_t)sk_launch_stamp((const int32_t *)src, n, dirty, b->d_ro, b->d_rw, b->g.synth_sample_count, b->d_mask[b->mask_p], s);
-    HIP_TRY(hipEventRecord(sl->ev, s));
+    const int idx = (int)(sl - b->upd);
+    if (++b->upd_seq == 0) b->upd_seq = 1;
+    const hipError_t e = (hipError_t)sk_launch_stamp((const int32_t *)src, n, dirty, b->d_ro, b->d_rw, b->g.synth_sample_count, b->d_mask[b->mask_p],
+                                                     b->d_upd_cnt + idx, (uint32_t *)b->h_upd_done + idx, b->upd_seq, s);
     if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "stamp launch -> %s", hipGetErrorString(e));
+    sl->seq = b->upd_seq;
     b->touched_total += (uint64_t)n;
     sk_control_changed(b);
     return SKRED_OK;
@@ -315,6 +339,7 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
   memcpy(sl->h, rec, (size_t)n * sizeof(sk_update_t));
   const sk_update_t *src = (const sk_update_t *)sk_stage(sl, (size_t)n * sizeof(sk_update_t), s);
   if (!src) return SKRED_E_NO_DEVICE;
+  const int idx = (int)(sl - b->upd);
   if (!b->upd_mark) {
     b->upd_mark = (uint32_t *)calloc((size_t)b->n_voices, sizeof(uint32_t));
     if (!b->upd_mark) return fail(SKRED_E_NO_MEM, "update marks");
@@ -328,12 +353,18 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
       if (*m == b->upd_epoch) break;                    /* named before in this run: the next launch takes it */
       *m = b->upd_epoch;
     }
+    const int last = end == n;                          /* the batch's last launch reports the slot free */
+    if (last && ++b->upd_seq == 0) b->upd_seq = 1;
     const hipError_t e = (hipError_t)sk_launch_update(src + start, end - start, b->d_ro, b->d_rw,
-                                                      b->g.synth_sample_count, b->d_mask[b->mask_p], s);
-    if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "update launch -> %s", hipGetErrorString(e));
+                                                      b->g.synth_sample_count, b->d_mask[b->mask_p],
+                                                      last ? b->d_upd_cnt + idx : NULL, last ? (uint32_t *)b->h_upd_done + idx : NULL, b->upd_seq, s);
+    if (e != hipSuccess) {                              /* (launches of this batch already queued still read the slot) */
+      (void)hipStreamSynchronize(s);
+      return fail(SKRED_E_NO_DEVICE, "update launch -> %s", hipGetErrorString(e));
+    }
+    if (last) sl->seq = b->upd_seq;
     start = end;
   }
-  HIP_TRY(hipEventRecord(sl->ev, s));
   if (meta && (dirty & SKRED_DIRTY_PARAMS)) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i], 1);
   b->touched_total += (uint64_t)n;
   sk_control_changed(b);

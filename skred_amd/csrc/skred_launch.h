@@ -56,12 +56,14 @@ int sk_launch_master_apply(const float *sum, const float *gains, float *out, int
 
 /* scatter n voice updates into the planes; `now` = synth_sample_count for the STAMP bits; every touched voice goes on the
  * motion list (`mask`: a bit per voice, skred_device_layout.h: mask_cur) */
+/* cnt / done / seq: when `done` is not NULL the workgroup that finishes last stores `seq` into *done (pinned host memory the
+ * host polls before it reuses the staging buffer the batch was read from); `cnt` is that slot's arrival counter on the device */
 int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[SKP_COUNT], sk_plane_t *const rw[SKS_COUNT],
-                     uint64_t now, uint64_t *mask, hipStream_t stream);
+                     uint64_t now, uint64_t *mask, uint32_t *cnt, uint32_t *done, uint32_t seq, hipStream_t stream);
 
 /* note-on / note-off stamps only: a list of voice ids */
 int sk_launch_stamp(const int32_t *d_ids, int n, uint32_t dirty, sk_plane_t *const ro[SKP_COUNT], sk_plane_t *const rw[SKS_COUNT],
-                    uint64_t now, uint64_t *mask, hipStream_t stream);
+                    uint64_t now, uint64_t *mask, uint32_t *cnt, uint32_t *done, uint32_t seq, hipStream_t stream);
 
 /* stem recorder (skred_recorder.c): min/max partials of rec[n_floats]; selected voices -> int16 pairs */
 int sk_rec_partial_floats(void);

@@ -21,10 +21,25 @@ __device__ __forceinline__ void sk_list_voice(uint64_t *mask, int v) {
   atomicOr(reinterpret_cast<unsigned long long *>(mask) + (v >> 6), 1ull << (v & 63));
 }
 
+// The batch was read (straight from the host's pinned staging buffer, for small batches): the workgroup that finishes last tells
+// the host, which then reuses the buffer -- a word in pinned memory the host polls, instead of an event behind every batch
+// (an event record costs the stream ~5 us of gap in front of the next kernel: four per block under note traffic).
+__device__ __forceinline__ void sk_batch_done(uint32_t *cnt, uint32_t *done, uint32_t seq) {
+  if (!done) return;
+  __syncthreads();                                   // every thread of this workgroup holds its record in registers
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(cnt, 1u) == gridDim.x - 1) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the slot's next batch
+      __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void sk_update_kernel(const sk_update_t *__restrict__ u, int n, sk_plane_ptrs_t p,
-                                                      uint64_t now, uint64_t *mask) {
+                                                      uint64_t now, uint64_t *mask, uint32_t *cnt, uint32_t *done, uint32_t seq) {
   const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
+  if (i < n) {
   const sk_update_t r = u[i];
   const int v = r.voice;
   sk_list_voice(mask, v);
@@ -59,13 +74,15 @@ __global__ __launch_bounds__(64) void sk_update_kernel(const sk_update_t *__rest
   *reinterpret_cast<uint4 *>(&p.rw[SKS_OSC][v]) = s0;
   *reinterpret_cast<uint4 *>(&p.rw[SKS_FILT][v]) = s1;
   *reinterpret_cast<uint4 *>(&p.rw[SKS_MISC][v]) = s2;
+  }
+  sk_batch_done(cnt, done, seq);
 }
 
 // note-ons / note-offs only: a list of voice ids, the clock, which stamp
 __global__ __launch_bounds__(256) void sk_stamp_kernel(const int32_t *__restrict__ ids, int n, uint32_t dirty, sk_plane_ptrs_t p,
-                                                       uint64_t now, uint64_t *mask) {
+                                                       uint64_t now, uint64_t *mask, uint32_t *cnt, uint32_t *done, uint32_t seq) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i < n) {
   const int v = ids[i];
   sk_list_voice(mask, v);
   uint32_t *rwflags = reinterpret_cast<uint32_t *>(&p.rw[SKS_FILT][v]) + 3;
@@ -80,24 +97,28 @@ __global__ __launch_bounds__(256) void sk_stamp_kernel(const int32_t *__restrict
   }
   *reinterpret_cast<uint4 *>(&p.ro[SKP_ENV_S][v]) = es;
   *rwflags = f;
+  }
+  sk_batch_done(cnt, done, seq);
 }
 
 extern "C" int sk_launch_stamp(const int32_t *d_ids, int n, uint32_t dirty, sk_plane_t *const ro[SKP_COUNT],
-                               sk_plane_t *const rw[SKS_COUNT], uint64_t now, uint64_t *mask, hipStream_t stream) {
+                               sk_plane_t *const rw[SKS_COUNT], uint64_t now, uint64_t *mask, uint32_t *cnt, uint32_t *done,
+                               uint32_t seq, hipStream_t stream) {
   if (n <= 0) return 0;
   sk_plane_ptrs_t p;
   for (int k = 0; k < SKP_COUNT; ++k) p.ro[k] = ro[k];
   for (int k = 0; k < SKS_COUNT; ++k) p.rw[k] = rw[k];
-  hipLaunchKernelGGL(sk_stamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ids, n, dirty, p, now, mask);
+  hipLaunchKernelGGL(sk_stamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_ids, n, dirty, p, now, mask, cnt, done, seq);
   return (int)hipGetLastError();
 }
 
 extern "C" int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[SKP_COUNT],
-                                sk_plane_t *const rw[SKS_COUNT], uint64_t now, uint64_t *mask, hipStream_t stream) {
+                                sk_plane_t *const rw[SKS_COUNT], uint64_t now, uint64_t *mask, uint32_t *cnt, uint32_t *done,
+                                uint32_t seq, hipStream_t stream) {
   if (n <= 0) return 0;
   sk_plane_ptrs_t p;
   for (int k = 0; k < SKP_COUNT; ++k) p.ro[k] = ro[k];
   for (int k = 0; k < SKS_COUNT; ++k) p.rw[k] = rw[k];
-  hipLaunchKernelGGL(sk_update_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_updates, n, p, now, mask);
+  hipLaunchKernelGGL(sk_update_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_updates, n, p, now, mask, cnt, done, seq);
   return (int)hipGetLastError();
 }

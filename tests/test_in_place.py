@@ -42,7 +42,7 @@ def stamp(truth, vs, dirty, now, D):
         e["sample_release"][vs[act]] = now
 
 
-def run(dev, n, frames, blocks, plan, mode, bank_fn=banks.bank_c2, prepare=None):
+def run(dev, n, frames, blocks, plan, mode, bank_fn=banks.bank_c2, prepare=None, interp=0):
     """Render `blocks` blocks with the control actions of `plan` ({block: [(voices, dirty), ...]}); returns the mixes, the
     oracle's mixes, the downloaded state, the oracle's state and which blocks took the in-place path."""
     import torch
@@ -67,12 +67,12 @@ def run(dev, n, frames, blocks, plan, mode, bank_fn=banks.bank_c2, prepare=None)
                 mirror["voice_finished"][vs] = 0
             db.update(mirror, vs, dirty, 0)
             stamp(truth, vs, dirty, gl.synth_sample_count, D)
-        db.render_mix(frames, out.data_ptr(), 2, 0, 0)          # asynchronous blocks: the way the host gets its reports
+        db.render_mix(frames, out.data_ptr(), 2, 0, interp)     # asynchronous blocks: the way the host gets its reports
         assert db.last_kernel() == 3
         taken.append(db.last_in_place())
         torch.cuda.synchronize()
         mixes.append(out.cpu().numpy().copy())
-        r = cpuref.render(truth, gl, tables, frames, 0)
+        r = cpuref.render(truth, gl, tables, frames, interp)
         refs.append(cpuref.master(gl, r["sum64"].astype(np.float32)))
     got = bank.copy()
     db.download(got)
@@ -106,6 +106,28 @@ def test_listed_voices_in_place_against_the_oracle(dev, frames):
     for k, (m, r) in enumerate(zip(mixes, refs)):
         assert rel_rms(m, r) <= 1e-5, f"block {k}"
     assert sum(taken) >= blocks // 2, taken                       # the path under test did run
+
+
+def _c2_without_guards(n):
+    """bank_c2 with the sample behind every table changed: no voice carries SKF_GUARD, the linear lookup keeps its fold test."""
+    bank, tables, g = banks.bank_c2(n)
+    t = tables.copy()
+    pos = np.unique(bank["voice_table_offset"].astype(np.int64) + bank["voice_table_size"].astype(np.int64))
+    t[pos[pos < len(t)]] = 7.0
+    return bank, t, g
+
+
+@pytest.mark.parametrize("bank_fn", [banks.bank_c2, _c2_without_guards], ids=["guarded_pool", "general_form"])
+def test_listed_voices_in_place_with_linear_lookup(dev, bank_fn):
+    """The in-place instantiations of both linear forms (INTERP 2: every voice loops over its whole table with a guard sample
+    behind it; INTERP 1: the general form with the fold test)."""
+    n = 6000
+    plan = traffic(n, dev, dense_at=13)
+    mixes, refs, got, truth, taken = run(dev, n, 512, 26, plan, 2, bank_fn=bank_fn, interp=1)
+    assert not got.rw_equal(truth), got.rw_equal(truth)
+    for k, (m, r) in enumerate(zip(mixes, refs)):
+        assert rel_rms(m, r) <= 1e-5, f"block {k}"
+    assert any(taken), taken
 
 
 def test_in_place_and_envelope_kernel_agree(dev):

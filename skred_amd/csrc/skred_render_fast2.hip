@@ -1107,23 +1107,24 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
 // prefix sums, off[n] = their total; and the NEXT block's mask zeroed (sk_render_env2_kernel, next on this stream, ORs its
 // survivors in).  pairs: two-operator FM banks list whole (2i, 2i+1) pairs -- either bit lists both voices.
 // One workgroup, tiles of 8192 slices staged through LDS (coalesced loads in flight together -- a thread walking its
-// contiguous share in global memory pays one memory latency per element): every thread sums its 32 contiguous counts, the
-// 256 sums are scanned across lanes (shuffles inside each wavefront, four wave totals through LDS), every thread writes its
-// prefixes back into the tile, and the tile leaves coalesced.
+// contiguous share in global memory pays one memory latency per element): every thread sums its contiguous share of the
+// counts, the threads' sums are scanned across lanes (shuffles inside each wavefront, the wave totals through LDS), every
+// thread writes its prefixes back into the tile, and the tile leaves coalesced.
 #define SK_SCAN_TILE 8192
 __device__ __forceinline__ uint64_t sk_pair_bits(uint64_t w) { return (w | (w >> 1)) & 0x5555555555555555ull; }   // bit 2i: pair i listed
-__global__ __launch_bounds__(256) void sk_collect_scan_kernel(const uint64_t *__restrict__ mask, uint64_t *__restrict__ mask_next, int n,
+#define SK_SCAN_NT 1024          /* threads: 16 wavefronts share the tile (256 threads: 13 us at 2^20 voices, latency of one CU's loads) */
+__global__ __launch_bounds__(SK_SCAN_NT) void sk_collect_scan_kernel(const uint64_t *__restrict__ mask, uint64_t *__restrict__ mask_next, int n,
                                                               int pairs, int32_t *__restrict__ counts, int32_t *__restrict__ off) {
   __shared__ int tile[SK_SCAN_TILE + SK_SCAN_TILE / 32];   // element k lives at k + k/32: a thread's 32 counts stay contiguous, the
                                                            // threads' shares start in different banks
 #define SK_SCAN_AT(k) ((k) + ((k) >> 5))
-  __shared__ int wave_total[4];
+  __shared__ int wave_total[SK_SCAN_NT / 64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int carry = 0;
   for (int t0 = 0; t0 < n; t0 += SK_SCAN_TILE) {
     const int m = min(SK_SCAN_TILE, n - t0);
 #pragma unroll 8
-    for (int k = t; k < SK_SCAN_TILE; k += 256) {
+    for (int k = t; k < SK_SCAN_TILE; k += SK_SCAN_NT) {
       int cnt = 0;
       if (k < m) {
         const ulonglong2 w = reinterpret_cast<const ulonglong2 *>(mask)[t0 + k];
@@ -1136,7 +1137,7 @@ __global__ __launch_bounds__(256) void sk_collect_scan_kernel(const uint64_t *__
     __syncthreads();
     int c = 0;
 #pragma unroll
-    for (int i = 0; i < SK_SCAN_TILE / 256; ++i) c += tile[SK_SCAN_AT(t * (SK_SCAN_TILE / 256) + i)];
+    for (int i = 0; i < SK_SCAN_TILE / SK_SCAN_NT; ++i) c += tile[SK_SCAN_AT(t * (SK_SCAN_TILE / SK_SCAN_NT) + i)];
     int incl = c;                                      // inclusive scan of the shares inside the wavefront
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -1147,13 +1148,15 @@ __global__ __launch_bounds__(256) void sk_collect_scan_kernel(const uint64_t *__
     __syncthreads();
     int base = carry;
     for (int w = 0; w < wave; ++w) base += wave_total[w];
-    const int total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    int total = 0;
+#pragma unroll
+    for (int w = 0; w < SK_SCAN_NT / 64; ++w) total += wave_total[w];
     int w = base + incl - c;                           // exclusive prefix of this thread's share
 #pragma unroll
-    for (int i = 0; i < SK_SCAN_TILE / 256; ++i) { int &e_ = tile[SK_SCAN_AT(t * (SK_SCAN_TILE / 256) + i)]; const int v = e_; e_ = w; w += v; }
+    for (int i = 0; i < SK_SCAN_TILE / SK_SCAN_NT; ++i) { int &e_ = tile[SK_SCAN_AT(t * (SK_SCAN_TILE / SK_SCAN_NT) + i)]; const int v = e_; e_ = w; w += v; }
     __syncthreads();
 #pragma unroll 8
-    for (int k = t; k < m; k += 256) off[t0 + k] = tile[SK_SCAN_AT(k)];
+    for (int k = t; k < m; k += SK_SCAN_NT) off[t0 + k] = tile[SK_SCAN_AT(k)];
     carry += total;
     __syncthreads();
   }
@@ -1356,7 +1359,7 @@ extern "C" int sk_env2_grid(const sk_render_args_t *args) {
 // ahead of both render kernels (an idle machine runs it in ~18 us; beside a full one it took 130)
 extern "C" int sk_launch_collect(const sk_render_args_t *args, hipStream_t stream) {
   const bool fmp = (args->fast_mode & SKM_FM_PAIR) != 0 && args->lds_table_floats > 0;
-  hipLaunchKernelGGL(sk_collect_scan_kernel, dim3(1), dim3(256), 0, stream, args->mask_cur, args->mask_next, args->n_groups * 2, fmp ? 1 : 0,
+  hipLaunchKernelGGL(sk_collect_scan_kernel, dim3(1), dim3(SK_SCAN_NT), 0, stream, args->mask_cur, args->mask_next, args->n_groups * 2, fmp ? 1 : 0,
                      args->group_flag, args->env_off);
   hipLaunchKernelGGL(sk_collect_expand_kernel, dim3((unsigned)((args->n_groups * 2 + 3) / 4)), dim3(256), 0, stream,
                      args->group_flag, args->mask_cur, args->env_off, args->n_groups * 2, args->env_list, fmp ? 1 : 0);

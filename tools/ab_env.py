@@ -9,6 +9,7 @@ n, F = 1 << 20, 512
 bank, t, g = banks.RECIPES["c3"](n)
 out = torch.zeros(F, 2, device="cuda")
 db = D.DeviceBank(n); db.set_tables(t); db.upload(bank); db.set_globals(g); db.kernel_timing(0)
+if os.environ.get("AB_IN_PLACE"): db.in_place(int(os.environ["AB_IN_PLACE"]))   # SKRED_OPT_IN_PLACE: 0 never, 2 whenever the rows suffice
 for _ in range(20): db.render_mix(F, out.data_ptr(), 2, 0, 0)
 torch.cuda.synchronize()
 reps = []

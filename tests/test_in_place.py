@@ -194,6 +194,53 @@ def test_mixed_bank_in_place(dev):
     assert any(taken), taken
 
 
+def test_block_length_changes_from_block_to_block(dev):
+    """The gain rows are as long as the block: a host that changes its callback size (520, 64, 200, 512 ... frames) makes the
+    buffer's row stride change between blocks.  Oracle, block by block; one update batch travels on a stream of its own."""
+    import torch
+    D = dev
+    n = 6000
+    bank, tables, g = banks.bank_c2(n)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    db.fast2_min_voices(0)
+    db.in_place(2)
+    mirror, truth, gl = bank.copy(), bank.copy(), g.copy()
+    rng = np.random.default_rng(11)
+    other = torch.cuda.Stream()
+    sizes = [512, 520, 64, 200, 512, 136, 512, 8, 300, 512, 72, 512, 512, 264, 512, 512]
+    taken = []
+    for k, frames in enumerate(sizes * 2):
+        if k >= 2:
+            vs = rng.choice(n, 24, replace=False).astype(np.int32)
+            for part, dirty in ((vs[:12], D.STAMP_RELEASE), (vs[12:], D.STAMP_TRIGGER | D.DIRTY_PHASE)):
+                if dirty & D.DIRTY_PHASE:
+                    mirror["voice_phase"][part] = 0.0
+                    mirror["voice_finished"][part] = 0
+                if k % 5 == 0:                                 # (ordered by hand: the bank's streams are the caller's business)
+                    torch.cuda.synchronize()
+                    db.update(mirror, part, dirty, other.cuda_stream)
+                    other.synchronize()
+                else:
+                    db.update(mirror, part, dirty, 0)
+                stamp(truth, part, dirty, gl.synth_sample_count, D)
+        out = torch.zeros(frames, 2, device="cuda")
+        db.render_mix(frames, out.data_ptr(), 2, 0, 0)
+        taken.append(db.last_in_place())
+        torch.cuda.synchronize()
+        r = cpuref.render(truth, gl, tables, frames, 0)
+        ref = cpuref.master(gl, r["sum64"].astype(np.float32))
+        assert rel_rms(out.cpu().numpy(), ref) <= 1e-5, f"block {k} ({frames} frames)"
+    got = bank.copy()
+    db.download(got)
+    assert db.list_violations() == 0
+    db.close()
+    assert not got.rw_equal(truth), got.rw_equal(truth)
+    assert sum(taken) >= len(taken) // 2, taken
+
+
 def test_default_rule_takes_the_path_on_a_full_machine_only_when_sparse(dev):
     """SKRED_OPT_IN_PLACE 1 (default) on a 2^19-voice bank (its 512 workgroup passes fill a 256-CU device exactly once): sparse
     traffic is rendered in place, the mix stays within tolerance of the envelope-kernel form of the same blocks."""

@@ -241,6 +241,48 @@ def test_block_length_changes_from_block_to_block(dev):
     assert sum(taken) >= len(taken) // 2, taken
 
 
+def test_sum_only_form_in_place(dev):
+    """The multi-GPU render's two halves (skred_bank_render: the pre-master sum; skred_bank_master behind it) with the list in
+    place: the same bytes as the one-launch form of a twin bank under the same traffic."""
+    import torch
+    D = dev
+    n, F = 6000, 512
+    bank, tables, g = banks.bank_c2(n)
+    plan = traffic(n, dev, dense_at=7)
+    outs = []
+    for two_halves in (False, True):
+        db = dev.DeviceBank(n)
+        db.set_tables(tables)
+        db.upload(bank)
+        db.set_globals(g)
+        db.fast2_min_voices(0)
+        db.in_place(2)
+        mirror = bank.copy()
+        out = torch.zeros(F, 2, device="cuda")
+        pre = torch.zeros(F, 2, device="cuda")
+        got, taken = [], []
+        for k in range(20):
+            for vs, dirty in plan.get(k, []):
+                vs = np.asarray(vs, np.int32)
+                if dirty & D.DIRTY_PHASE:
+                    mirror["voice_phase"][vs] = 0.0
+                    mirror["voice_finished"][vs] = 0
+                db.update(mirror, vs, dirty, 0)
+            if two_halves:
+                db.render(F, pre.data_ptr(), 0, 0, 0)
+                db.master(pre.data_ptr(), F, out.data_ptr(), 2, 0)
+            else:
+                db.render_mix(F, out.data_ptr(), 2, 0, 0)
+            taken.append(db.last_in_place())
+            torch.cuda.synchronize()
+            got.append(out.cpu().numpy().copy())
+        assert db.list_violations() == 0
+        db.close()
+        assert any(taken), taken
+        outs.append(np.concatenate(got))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
 def test_default_rule_takes_the_path_on_a_full_machine_only_when_sparse(dev):
     """SKRED_OPT_IN_PLACE 1 (default) on a 2^19-voice bank (its 512 workgroup passes fill a 256-CU device exactly once): sparse
     traffic is rendered in place, the mix stays within tolerance of the envelope-kernel form of the same blocks."""

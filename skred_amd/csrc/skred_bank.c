@@ -465,15 +465,16 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     a.fast_mode |= SKM_TWO_PER_LANE;        /* (voices that finish mid-launch are handled by the one-per-lane kernel only) */
   /* ... except where its 1024-voice passes fill the machine unevenly: one pass per CU up to n_cus passes, then SOME CUs with two
    * (the block takes as long as a full second layer: 262 144 voices 87 us, 294 912 voices 132 us, 524 288 voices 146 us), where
-   * the one-voice kernel's finer grain wins until the second layer is about half full (294 912 voices 113 us, 360 448 voices 129
-   * vs 134, 393 216 voices 136 vs 136; tools/ab_env_mid.py, steady columns) */
+   * the one-voice kernel's finer grain wins until the second layer is about five eighths full (294 912 voices 106 us, 360 448
+   * voices 121 vs 132, 393 216 voices 124 vs 133, 458 752 voices 140 vs 135; tools/measure_banks.py mid -- since the one-voice
+   * kernel's LDS-table instantiations stopped reserving a table window per wave they fit four workgroups per CU) */
   if ((a.fast_mode & SKM_TWO_PER_LANE) && !b->fast2_min_user && a.lds_table_floats > 0) {
     const int passes = b->n_groups * 2 / SK_FAST2_NW_LDS;
     /* (only while nothing moves -- with envelopes in motion the two-per-lane kernel and the envelope kernel beside it are
      * ahead at these sizes, 202 vs 214..255 us --: the family that rendered the previous block knows: an empty motion list,
      * or a one-voice launch that saw no envelope move) */
     const int quiet = !(a.fast_mode & SKM_ENV_ALL) || (b->last_family == SKRED_KERNEL_FAST2 ? b->list_empty : b->env_quiet);
-    if (quiet && passes > b->n_cus && passes < b->n_cus + b->n_cus / 2) a.fast_mode &= ~SKM_TWO_PER_LANE;
+    if (quiet && passes > b->n_cus && passes <= b->n_cus + b->n_cus * 5 / 8) a.fast_mode &= ~SKM_TWO_PER_LANE;
   }
   /* ... but while envelopes move the one-voice kernel's block form of them beats the two-per-lane kernel + envelope kernel on
    * mid-size banks (tools/ab_env_mid.py): such banks change kernels with their state (both families read and write the same

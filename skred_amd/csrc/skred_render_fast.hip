@@ -777,7 +777,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (SK_WIN * 64);   // global-table banks: table windows
+  // per wave behind the chunk sums: LDS-table banks -- the reduction tile xt[8][SK_XT]; global-table banks -- the table window
+  // (SK_WIN * 64 floats), the tiles behind all four windows
+  float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (TAB_LDS ? 8 * SK_XT : SK_WIN * 64);
   // the reduction tile of the 8-frame blocks (8 * SK_XT floats): LDS-table banks keep it in the same per-wave region
   // (no windows there), global-table banks behind the four windows
   float *xt = TAB_LDS ? win : reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + 4 * (SK_WIN * 64) + wave * (8 * SK_XT);
@@ -1126,8 +1128,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
 extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
                                      hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
-  lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);   // per wave: one table window, or the reduction tiles of SK_FAST_LDS_BLOCK
-  if (args->lds_table_floats == 0) lds_bytes += (size_t)4 * (8 * SK_XT) * sizeof(float);   // global-table banks: window AND tile
+  // per wave: the reduction tile of the block paths; global-table banks: a table window too (LDS-table banks used to get the
+  // window's 5 KB per wave as well: 12 KB per workgroup that cost banks with 32 KB of tables their third workgroup per CU)
+  lds_bytes += (size_t)4 * (8 * SK_XT) * sizeof(float);
+  if (args->lds_table_floats == 0) lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);
   dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block(SK_GROUP);
   const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp != 0 ? 1 : 0);

@@ -762,11 +762,13 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
   const char *lds_tab = reinterpret_cast<const char *>(lds);                                         \
   const char *glb_tab = reinterpret_cast<const char *>(a.tables);                                    \
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                     \
-  float2 *xp = wsum0 + 2 * NW * SK_CHUNK + wave * (8 * 65 + 64);  /* wave-private: tile [8][65] then xq [64] */ \
-  float2 *xq = xp + 8 * 65;                                                                          \
+  /* wave-private: the reduction tile [8 frames][SK_XT2] of folded (L | R) pair sums (it used to be a float2 tile [8][65] and a \
+     second stage xq[64]: 4.7 KB per wave, of which 2.2 are in use since the fold -- 20 KB per workgroup that kept banks with \
+     more than 31 KB of tables at one workgroup per CU) */                                            \
+  float2 *xp = reinterpret_cast<float2 *>(reinterpret_cast<float *>(wsum0 + 2 * NW * SK_CHUNK) + wave * (8 * SK_XT2)); \
   /* global-table banks: the same LDS holds the wave's table windows instead (2 voices x SK_WIN x 64 lanes) */ \
   float *win = reinterpret_cast<float *>(wsum0 + 2 * NW * SK_CHUNK) + wave * (2 * SK_WIN * 64);      \
-  (void)xp; (void)xq; (void)win;                                                                     \
+  (void)xp; (void)win;                                                                               \
   const int bid = (int)blockIdx.x - ((GAIN_WG) ? a.wg_shift : 0);   /* row of the partial mix; -1: the gain workgroup */ \
   if ((GAIN_WG) && bid < 0) { sk_finish_block(a, bid, tid, NW * 64, reinterpret_cast<int *>(lds)); return; } \
   const int n_flags = a.n_groups * 2;      /* 128-voice wave slices; env_off[n_flags] = the length of the motion list */ \
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
   (void)n_flags;
   // GT: per wave, behind the tiles: gtile[8][SK_GT_RANKS] (the listed voices' gains of one 8-frame block) and
   // srank[SK_GT_RANKS] (rank -> where that voice's row starts in a.env_gain)
-  float *const gtile = reinterpret_cast<float *>(wsum0 + 2 * NW * SK_CHUNK + NW * (8 * 65 + 64)) + wave * SK_GT_LDS_FLOATS;
+  float *const gtile = reinterpret_cast<float *>(wsum0 + 2 * NW * SK_CHUNK) + NW * (8 * SK_XT2) + wave * SK_GT_LDS_FLOATS;
   int *const srank = reinterpret_cast<int *>(gtile + 8 * SK_GT_RANKS);
   (void)gtile; (void)srank;
   bool first_pass = true;
@@ -1262,7 +1264,7 @@ static inline size_t sk_fast2_lds(const sk_render_args_t *args, int nw, bool gt 
   // windows (global-table banks)
   const bool tab_lds = args->lds_table_floats > 0;
   const size_t tab_bytes = (size_t)(tab_lds ? args->lds_table_floats : 0) * sizeof(float);
-  const size_t per_wave = tab_lds ? (size_t)(8 * 65 + 64) * sizeof(float2) : (size_t)(2 * SK_WIN * 64) * sizeof(float);
+  const size_t per_wave = tab_lds ? (size_t)(8 * SK_XT2) * sizeof(float) : (size_t)(2 * SK_WIN * 64) * sizeof(float);
   return tab_bytes + (size_t)nw * (2 * SK_CHUNK * sizeof(float2) + per_wave + (gt ? (size_t)SK_GT_LDS_FLOATS * sizeof(float) : 0));
 }
 static inline int sk_fast2_key(const sk_render_args_t *args) {

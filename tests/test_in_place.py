@@ -283,6 +283,58 @@ def test_sum_only_form_in_place(dev):
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
 
 
+@pytest.mark.parametrize("mode", [2, 1, 0])
+def test_blocks_queued_far_ahead_of_the_device(dev, mode):
+    """A host that never waits: 120 blocks with notes starting and ending in every one of them are queued back to back, so the
+    device's reports lag the host by many blocks (the proven bound on the list's length has to live with stale reports), the
+    update path's staging ring wraps many times (its slots come back through the kernels' done words) and the report ring is
+    re-used.  Afterwards every state field of every voice must equal the oracle's after the same 120 blocks."""
+    import torch
+    D = dev
+    n, F, blocks = 6000, 512, 120
+    bank, tables, g = banks.bank_c2(n)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    db.fast2_min_voices(0)
+    db.in_place(mode)
+    mirror, truth, gl = bank.copy(), bank.copy(), g.copy()
+    out = torch.zeros(F, 2, device="cuda")
+    rng = np.random.default_rng(3)
+    actions, taken = [], []
+    for k in range(blocks):
+        vs = rng.choice(n, 10, replace=False).astype(np.int32)
+        acts = [(vs[:5], D.STAMP_RELEASE), (vs[5:], D.STAMP_TRIGGER | D.DIRTY_PHASE)]
+        if k == 60:
+            acts.append((np.arange(0, n, 3, dtype=np.int32), D.STAMP_RELEASE))          # a burst: a third of the bank
+        for part, dirty in acts:
+            if dirty & D.DIRTY_PHASE:
+                mirror["voice_phase"][part] = 0.0
+                mirror["voice_finished"][part] = 0
+            db.update(mirror, part, dirty, 0)
+        actions.append(acts)
+        db.render_mix(F, out.data_ptr(), 2, 0, 0)
+        taken.append(db.last_in_place())
+    torch.cuda.synchronize()
+    last = out.cpu().numpy().copy()
+    got = bank.copy()
+    db.download(got)
+    assert db.list_violations() == 0
+    db.close()
+    for k in range(blocks):
+        for part, dirty in actions[k]:
+            stamp(truth, part, dirty, gl.synth_sample_count, D)
+        r = cpuref.render(truth, gl, tables, F, 0)
+        ref = cpuref.master(gl, r["sum64"].astype(np.float32))
+    assert not got.rw_equal(truth), got.rw_equal(truth)
+    assert rel_rms(last, ref) <= 1e-5
+    if mode == 2:
+        assert sum(taken) > blocks // 3, taken
+    if mode == 0:
+        assert not any(taken)
+
+
 def test_default_rule_takes_the_path_on_a_full_machine_only_when_sparse(dev):
     """SKRED_OPT_IN_PLACE 1 (default) on a 2^19-voice bank (its 512 workgroup passes fill a 256-CU device exactly once): sparse
     traffic is rendered in place, the mix stays within tolerance of the envelope-kernel form of the same blocks."""

@@ -373,10 +373,13 @@ int  skred_shard_init_rccl(skred_shard_t *shard, const void *unique_id128);
 int  skred_shard_render_mix(skred_shard_t *shard, int num_frames, int interp, float *partial, float *out, int num_channels, void *stream);
 
 /* The same block with the collective of block k overlapped with the render of block k + 1 (two partial buffers, the
- * collective and the root's master stage on a stream of the shard's own, chained by events): throughput is bounded by
- * max(render, reduce + master) instead of their sum.  `out` of call k is complete on `stream` once call k + 1 -- or
- * skred_shard_flush -- has returned (one block of latency): alternate between two output buffers.  Same samples as
- * skred_shard_render_mix, bit for bit.  Custom steps (host memory) run synchronously, in order. */
+ * collective and the root's master stage on a stream of the shard's own): throughput is bounded by max(render,
+ * reduce + master) instead of their sum.  Host-paced: call k first waits (on the host) until block k - 2 has left the
+ * collective's stream, so `out` of call k is complete -- for the host and for every stream -- once call k + 2 has
+ * returned: alternate between two output buffers.  `stream` itself never waits for the collective's stream; to have
+ * everything issued so far complete ON `stream` (e.g. to consume the latest block with a kernel or a copy queued
+ * there) call skred_shard_flush(shard, stream).  Same samples as skred_shard_render_mix, bit for bit.  Custom steps
+ * (host memory) run synchronously, in order. */
 int  skred_shard_render_mix_pipelined(skred_shard_t *shard, int num_frames, int interp, float *out, int num_channels, void *stream);
 int  skred_shard_flush(skred_shard_t *shard, void *stream);
 

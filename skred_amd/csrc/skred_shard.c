@@ -323,7 +323,11 @@ static int pp_setup(skred_shard_t *s, size_t need) {
   }
   s->pp_cap = need;
   if (s->bank && !s->pp_comm) {
-    HIP_TRY(hipStreamCreateWithFlags(&s->pp_comm, hipStreamNonBlocking));
+    /* high priority: the collective and the few workgroups of the master stage must not queue behind the next block's render --
+     * and HIP keeps streams of different priorities on different hardware queues, which a second normal-priority stream is not
+     * promised (sharing the caller's hardware queue, block k's master stage waited for block k + 1's render: 156 instead of
+     * 87 us per block on a 2^18-voice shard inside bench.py, where several streams exist) */
+    HIP_TRY(hipStreamCreateWithPriority(&s->pp_comm, hipStreamNonBlocking, -1));
     for (int i = 0; i < 2; i++) {
       HIP_TRY(hipEventCreateWithFlags(&s->pp_rendered[i], hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&s->pp_done[i], hipEventDisableTiming));
@@ -352,20 +356,24 @@ int skred_shard_render_mix_pipelined(skred_shard_t *s, int num_frames, int inter
   }
   HIP_TRY(hipSetDevice(s->device));
   hipStream_t main_s = (hipStream_t)stream;
-  /* (buffer p was last read by the collective of block k - 2: `main_s` waited for that at the end of call k - 1) */
+  /* Host-paced: before block k is issued the HOST waits until block k - 2 has left the collective's stream -- its partial
+   * sum, its gain row and the caller's output buffer of that parity are free again, and that output is complete.  The
+   * caller's stream itself never waits for the collective's stream: an event wait in front of every render kernel cost it
+   * ~6 us of gap per block (2^17-voice shard: 65.2 -> 59.6 us per block), and a host two blocks ahead of the device
+   * keeps it busy. */
+  if (s->pp_k >= 2) HIP_TRY(hipEventSynchronize(s->pp_done[p]));
   if ((rc = sk_bank_render_sum_pp(s->bank, num_frames, interp, s->pp_buf[p], p, main_s))) return rc;
   HIP_TRY(hipEventRecord(s->pp_rendered[p], main_s));
   HIP_TRY(hipStreamWaitEvent(s->pp_comm, s->pp_rendered[p], 0));
   if (collective && (rc = s->ops.reduce(s->ops.reduce_ctx, s->pp_buf[p], (size_t)num_frames * 2, s->root, s->pp_comm))) return rc;
   if (s->rank == s->root && (rc = sk_bank_master_pp(s->bank, s->pp_buf[p], num_frames, num_channels, out, p, s->pp_comm))) return rc;
   HIP_TRY(hipEventRecord(s->pp_done[p], s->pp_comm));
-  /* the block before this one is complete on `main_s` from here on (its collective ran beside this block's render) */
-  if (s->pp_k >= 1) HIP_TRY(hipStreamWaitEvent(main_s, s->pp_done[p ^ 1], 0));
   s->pp_k++;
   return SKRED_OK;
 }
 
-/* `stream` waits for everything the pipelined calls have issued: the last block's output is complete on it afterwards */
+/* `stream` waits for everything the pipelined calls have issued: every block's output is complete on it afterwards (the
+ * collective's stream runs its blocks in order, so the last block's event covers them all) */
 int skred_shard_flush(skred_shard_t *s, void *stream) {
   if (!s) return fail(SKRED_E_BAD_ARG, "shard_flush");
   if (s->pp_k >= 1 && s->pp_comm) {

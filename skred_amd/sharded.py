@@ -120,8 +120,8 @@ class Shard:
                "skred_shard_render_mix")
 
     def render_mix_pipelined(self, frames: int, d_out: int, channels: int = 2, interp: int = 0, stream: int = 0):
-        """The collective of this block runs beside the render of the next one; `d_out` is complete on `stream` after the next
-        call or flush(): alternate between two output buffers."""
+        """The collective of this block runs beside the render of the next one.  Host-paced: `d_out` of call k is complete once
+        call k + 2 has returned (alternate between two output buffers), or on `stream` after flush(stream)."""
         _check(self.L.skred_shard_render_mix_pipelined(self.h, frames, interp, d_out or None, channels, stream or None),
                "skred_shard_render_mix_pipelined")
 

@@ -116,32 +116,42 @@ int main(void) {
   }
   skred_shard_destroy(s);
   /* (d) the PIPELINED form (the collective of block k beside the render of block k + 1) through the same one-rank RCCL
-   * communicator: two output buffers in alternation, block k's output complete after call k + 1 (or the flush); same bytes */
+   * communicator: two output buffers in alternation, block k's output complete once call k + 2 has returned (host-paced) or
+   * on the stream after a flush; same bytes */
   CHECK(skred_shard_create(0, 0, 1, 0, N, &s) == SKRED_OK);
   CHECK(skred_bank_set_tables_f32(skred_shard_bank(s), table, T) == SKRED_OK);
   CHECK(skred_shard_upload(s, &v) == SKRED_OK);
   CHECK(skred_shard_rccl_unique_id(id) == SKRED_OK);
   CHECK(skred_shard_init_rccl(s, id) == SKRED_OK);
   CHECK(skred_shard_set_ops(s, NULL, 1) == SKRED_OK);
-  float *d_out2[2] = {NULL, NULL};
+  float *d_out2[3] = {NULL, NULL, NULL};   /* (three: the test also reads block 0 while block 2 is in flight) */
   hipStream_t st = NULL;
   CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
-  for (int i = 0; i < 2; i++) CHECK(hipMalloc((void **)&d_out2[i], F * 2 * sizeof(float)) == hipSuccess);
+  for (int i = 0; i < 3; i++) CHECK(hipMalloc((void **)&d_out2[i], F * 2 * sizeof(float)) == hipSuccess);
   CHECK(skred_shard_render_mix_pipelined(s, F, SKRED_INTERP_TRUNCATE, NULL, 2, st) == SKRED_E_BAD_ARG);   /* the root needs an output */
+  hipStream_t other = NULL;                 /* (a stream that has nothing to do with the shard: only the host's pacing orders it) */
+  CHECK(hipStreamCreateWithFlags(&other, hipStreamNonBlocking) == hipSuccess);
   for (int k = 0; k < 3; k++) {
-    CHECK(skred_shard_render_mix_pipelined(s, F, SKRED_INTERP_TRUNCATE, d_out2[k & 1], 2, st) == SKRED_OK);
-    if (k >= 1) {            /* block k - 1 is complete on `st` now */
-      CHECK(hipMemcpyAsync(got, d_out2[(k - 1) & 1], F * 2 * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess);
+    CHECK(skred_shard_render_mix_pipelined(s, F, SKRED_INTERP_TRUNCATE, d_out2[k], 2, st) == SKRED_OK);
+    if (k == 1) {            /* the latest block on `st` itself: after a flush */
+      CHECK(skred_shard_flush(s, st) == SKRED_OK);
+      CHECK(hipMemcpyAsync(got, d_out2[1], F * 2 * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess);
       CHECK(hipStreamSynchronize(st) == hipSuccess);
-      CHECK(memcmp(got, want + (k - 1) * F * 2, F * 2 * sizeof(float)) == 0);
+      CHECK(memcmp(got, want + 1 * F * 2, F * 2 * sizeof(float)) == 0);
+    }
+    if (k == 2) {            /* call k has waited for block k - 2 on the host: its output is complete for every stream */
+      CHECK(hipMemcpyAsync(got, d_out2[0], F * 2 * sizeof(float), hipMemcpyDeviceToHost, other) == hipSuccess);
+      CHECK(hipStreamSynchronize(other) == hipSuccess);
+      CHECK(memcmp(got, want + 0 * F * 2, F * 2 * sizeof(float)) == 0);
     }
   }
   CHECK(skred_shard_flush(s, st) == SKRED_OK);
-  CHECK(hipMemcpyAsync(got, d_out2[0], F * 2 * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess);
+  CHECK(hipMemcpyAsync(got, d_out2[2], F * 2 * sizeof(float), hipMemcpyDeviceToHost, st) == hipSuccess);
   CHECK(hipStreamSynchronize(st) == hipSuccess);
   CHECK(memcmp(got, want + 2 * F * 2, F * 2 * sizeof(float)) == 0);
+  (void)hipStreamDestroy(other);
   skred_shard_destroy(s);
-  for (int i = 0; i < 2; i++) (void)hipFree(d_out2[i]);
+  for (int i = 0; i < 3; i++) (void)hipFree(d_out2[i]);
   (void)hipStreamDestroy(st);
   (void)hipFree(d_out);
   printf("OK sharded forms equal the single bank, RCCL one-rank reduce and the pipelined form included\n");

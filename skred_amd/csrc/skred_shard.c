@@ -40,6 +40,7 @@ struct skred_shard {
   float *pp_buf[2];                  /* device memory (bank-backed steps) or host memory (custom steps) */
   size_t pp_cap;
   unsigned pp_k;                     /* blocks issued */
+  int pp_in_flight;                  /* a pipelined block was issued since the last serial one */
   hipStream_t pp_comm;
   hipEvent_t pp_rendered[2], pp_done[2];
   /* library-owned RCCL communicator */
@@ -284,6 +285,12 @@ int skred_shard_render_mix(skred_shard_t *s, int num_frames, int interp, float *
     }
     partial = s->d_partial;
   }
+  if (s->pp_comm && s->pp_in_flight) {        /* pipelined calls came before: their last blocks may still be on the shard's stream, */
+    HIP_TRY(hipSetDevice(s->device));         /* reading gain rows and state this block's render is about to write */
+    HIP_TRY(hipEventSynchronize(s->pp_done[0]));
+    HIP_TRY(hipEventSynchronize(s->pp_done[1]));
+    s->pp_in_flight = 0;
+  }
   int rc = s->ops.render(s->ops.ctx, num_frames, interp, partial, stream);
   if (rc) return rc;
   if (s->world > 1 || s->always_reduce) {
@@ -369,6 +376,7 @@ int skred_shard_render_mix_pipelined(skred_shard_t *s, int num_frames, int inter
   if (s->rank == s->root && (rc = sk_bank_master_pp(s->bank, s->pp_buf[p], num_frames, num_channels, out, p, s->pp_comm))) return rc;
   HIP_TRY(hipEventRecord(s->pp_done[p], s->pp_comm));
   s->pp_k++;
+  s->pp_in_flight = 1;
   return SKRED_OK;
 }
 

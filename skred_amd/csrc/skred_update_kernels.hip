@@ -30,7 +30,8 @@ __device__ __forceinline__ void sk_batch_done(uint32_t *cnt, uint32_t *done, uin
   if (threadIdx.x == 0) {
     __threadfence();
     if (atomicAdd(cnt, 1u) == gridDim.x - 1) {
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the slot's next batch
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the slot's next batch ...
+      __threadfence_system();                                                   // ... before the host can know the slot is free
       __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }

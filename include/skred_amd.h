@@ -319,11 +319,18 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
                                  ("in place"), or by the envelope kernel beside the steady one.  1 (default): in place where that
                                  is the faster path (sparse lists; bank sizes at which a second kernel costs the steady one a
                                  whole round of workgroups); 0: never; 2: whenever the rows provably suffice (tests).  Same
-                                 per-voice results either way */ };
+                                 per-voice results either way */,
+       SKRED_OPT_SPLIT = 7 /* small and mid-size clean LDS-table banks, while nothing moves: the one-voice-per-lane kernel with every
+                              frame split between an oscillator wave and a post wave (sk_render_split_kernel), which gives a SIMD that
+                              holds one or two wavefronts of such a bank twice the independent instruction streams.  1 (default): for
+                              banks that fit one round of its workgroups; 0: never; 2: whenever the bank qualifies; 3: even while envelopes
+                              may be moving (tests: the kernel then renders the waves concerned on its general path).  Same
+                              per-voice results either way */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */
 int  skred_bank_last_in_place(const skred_bank_t *bank);  /* 1: the latest block rendered its motion list in place (SKRED_OPT_IN_PLACE) */
+int  skred_bank_last_split(const skred_bank_t *bank);     /* 1: the latest block ran the split form of the one-voice kernel (SKRED_OPT_SPLIT) */
 
 /* Cross-check of the motion list of the two-voices-per-lane path ("The motion list"): voices whose envelope may be
  * in motion are kept on a per-voice list ON THE DEVICE (every control action lists the voices it touches, the envelope kernel

@@ -5,7 +5,7 @@
  * control-path function that the rest of skred links against in place of synth.o
  * (reference Makefile:88-100), and a synth() whose render loop runs on the GPU through
  * libskred_amd.so.  The reference's own wire.c / seq.c / skred.c objects link against it
- * unchanged (tests/test_dropin_link.py does exactly that).
+ * unchanged (tests/test_dropin.py does exactly that).
  *
  * Names, element types and array lengths below ARE the ABI: they restate
  *   synth.h:8-85      function prototypes

@@ -261,12 +261,12 @@ def bank_c4(n: int = 262144, sample_rate: int = 48000, seed: int = SEED) -> Tupl
     return b, pool, g
 
 
-PATCH_DIR = os.path.join(os.path.dirname(_HERE), "tests", "golden")
+PATCH_DIR = os.path.join(_HERE, "data", "patches")    # package data (generated by tests/golden/gen_patch_voices.py where the reference is mounted)
 
 
 def bank_patch(patch: str, n: int, sample_rate: int = 44100) -> Tuple[VoiceBank, np.ndarray, GlobalsC]:
     """A reference PATCH tiled over a large bank: the voice state the unmodified reference holds after loading `patch`
-    (tests/golden/patch_<patch>.npz, written by tests/golden/gen_patch_voices.py from the reference's own wire()) -- its first K
+    (skred_amd/data/patches/patch_<patch>.npz, written by tests/golden/gen_patch_voices.py from the reference's own wire()) -- its first K
     voices, K the smallest power of two that holds every voice in use -- repeated n / K times, every copy with its modulator
     indices moved along (a copy never straddles an aligned 64-voice group) and its start phases spread by the LCG.  The routings
     the shipped patches use: a modulator shared by three carriers (3sk), frequency + pan modulation from two voices and sample &

@@ -129,6 +129,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   b->fast2_min_voices = SK_FAST2_MIN_VOICES;
   b->fm2_min_voices = SK_FM2_MIN_VOICES;
   b->in_place_mode = 1;
+  b->split_mode = 1;
   b->timing_every = 1;
   b->pp_parity = -1;
   b->n_padded = b->n_groups * SK_GROUP;
@@ -155,6 +156,7 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_partial) hipFree(b->d_partial);
   if (b->d_tickets) hipFree(b->d_tickets);
   if (b->d_gain_state) hipFree(b->d_gain_state);
+  if (b->d_pp_gains) hipFree(b->d_pp_gains);
   if (b->d_out) hipFree(b->d_out);
   if (b->d_stems) hipFree(b->d_stems);
   free(b->h_class); free(b->h_mod); free(b->h_level);
@@ -294,12 +296,14 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
     case SKRED_OPT_FM2_MIN_VOICES: b->fm2_min_voices = value; return SKRED_OK;
     case SKRED_OPT_IN_PLACE: b->in_place_mode = value < 0 ? 0 : value > 2 ? 2 : value; return SKRED_OK;
     case SKRED_OPT_KERNEL_TIMING: b->timing_every = value < 0 ? 0 : value; return SKRED_OK;
+    case SKRED_OPT_SPLIT: b->split_mode = value < 0 ? 0 : value > 3 ? 3 : value; return SKRED_OK;
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
 }
 
 int skred_bank_last_kernel(const skred_bank_t *b) { return b ? b->last_kernel : -1; }
 int skred_bank_last_in_place(const skred_bank_t *b) { return b ? b->last_in_place : 0; }
+int skred_bank_last_split(const skred_bank_t *b) { return b ? b->last_split : 0; }
 unsigned skred_bank_list_violations(const skred_bank_t *b) { return b ? b->violations_seen : 0u; }
 
 int skred_bank_download(skred_bank_t *b, skred_voice_bank_t *h, int src_first, int dst_first, int count) {
@@ -403,7 +407,7 @@ static void poll_reports(skred_bank_t *b) {
 /* this launch will report: remember what its ticket means (kind 1: one-voice "moved"; 2: list length; 3: violations only) */
 static int expect_report(skred_bank_t *b, sk_render_args_t *a, int kind) {
   if (!b->h_report) {
-    HIP_TRY(hipHostMalloc((void **)&b->h_report, 2 * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&b->h_report, 2 * sizeof(uint64_t), hipHostMallocCoherent));   /* (polled by the host while kernels run) */
     b->h_report[0] = b->h_report[1] = 0;
   }
   const int slot = (int)(a->launch_ticket % SK_REPORT_RING);
@@ -564,14 +568,27 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   /* rows of the partial mix, the slab sums of the two-level mix-down, the per-frame master gains, and (when the envelope kernel
    * runs beside) its rows and its sum: one allocation */
   const size_t row = (size_t)num_frames * 2;
-  const size_t gains_at = ((size_t)n_wg + SK_FINISH_SLABS) * row;                  /* (two rows of gains: the pipelined sum-only form alternates) */
-  const size_t env_at = (gains_at + 2 * (size_t)num_frames + 3) & ~(size_t)3;      /* 16-byte aligned */
+  const size_t gains_at = ((size_t)n_wg + SK_FINISH_SLABS) * row;
+  const size_t env_at = (gains_at + (size_t)num_frames + 3) & ~(size_t)3;          /* 16-byte aligned */
   if (env_at + ((size_t)n_env + 1) * row > b->partial_cap && b->pp_parity >= 0) HIP_TRY(hipDeviceSynchronize());   /* (a master stage of the pipelined form may still read the old rows) */
   if ((rc = grow(&b->d_partial, &b->partial_cap, env_at + ((size_t)n_env + 1) * row))) return rc;
   const int pp = b->pp_parity >= 0 && !d_out;      /* pipelined sum-only form: skred_shard_render_mix_pipelined */
   a.partial = b->d_partial;
   a.slab_rows = b->d_partial + (size_t)n_wg * row;
-  a.gains = b->d_partial + gains_at + (pp && b->pp_parity ? (size_t)num_frames : 0);
+  a.gains = b->d_partial + gains_at;
+  if (pp) {
+    /* the pipelined form's master stage of block k reads its gain row on another stream while block k + 1 renders: the two rows
+     * live in an allocation of their own, at offsets that depend on nothing but the parity -- not behind the rows of d_partial,
+     * whose number follows the kernel family and whose length follows num_frames, both free to change from block to block */
+    if ((size_t)num_frames > b->pp_gains_cap) {
+      HIP_TRY(hipDeviceSynchronize());               /* (a master stage may still read the old rows) */
+      if (b->d_pp_gains) { hipFree(b->d_pp_gains); b->d_pp_gains = NULL; b->pp_gains_cap = 0; }
+      const size_t cap = ((size_t)num_frames + 1023) & ~(size_t)1023;
+      HIP_TRY(hipMalloc((void **)&b->d_pp_gains, 2 * cap * sizeof(float)));
+      b->pp_gains_cap = cap;
+    }
+    a.gains = b->d_pp_gains + (b->pp_parity ? b->pp_gains_cap : 0);
+  }
   a.env_rows = b->d_partial + env_at;
   a.env_sum = a.env_rows + (size_t)n_env * row;
   a.env_ticket = b->d_tickets + SK_FINISH_SLABS + 1;
@@ -603,6 +620,18 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   const int tslot = b->n_timed % SK_TIMING_RING;
   a.launch_ticket = ++b->launch_ticket;
   a.skip_env2 = two_env ? (uint32_t)b->list_empty : (uint32_t)(one_env && b->env_quiet);
+  /* The one-voice family on a clean LDS-table bank that is believed steady (no envelope: always; envelopes: a launch has reported
+   * that none moved and no control action arrived since): every 64 voices get an oscillator wave AND a post wave
+   * (skred_render_split.hip), which gives the SIMDs of small and mid-size banks twice the instruction streams.  A wave whose
+   * voices are not steady after all renders itself on the general path of the same kernel, so the belief decides speed only.
+   * Sizes (SKRED_OPT_SPLIT 1): banks that fit ONE round of its 512-thread workgroups (two per CU by LDS and registers). */
+  int split = 0;
+  if (!modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_TWO_PER_LANE | SKM_STOPS | SKM_FM | SKM_MIXED)) && a.lds_table_floats > 0 &&
+      !d_stems && b->split_mode && (!one_env || a.skip_env2 || b->split_mode == 3) && sk_split_lds_bytes(&a) <= SK_SPLIT_MAX_LDS) {
+    const int per_cu = (int)(SK_SPLIT_MAX_LDS / sk_split_lds_bytes(&a)) >= 2 ? 2 : 1;
+    if (b->split_mode >= 2 || b->n_groups <= per_cu * b->n_cus) split = 1;
+  }
+  if (split) a.fast_mode |= SKM_SPLIT;
   const int timed = b->timing_every > 0 && (b->launch_ticket % (uint32_t)b->timing_every) == 0;
   if (timed) HIP_TRY(hipEventRecord(b->ev0[tslot], s));
   hipError_t e;
@@ -641,6 +670,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   }
   b->last_family = b->last_kernel;
   b->last_in_place = inplace;
+  b->last_split = split;
 
   /* advance the timeline exactly as synth.c:521,525 do: one count and one LCG draw per frame */
   b->g.synth_sample_count += (uint64_t)num_frames;
@@ -667,9 +697,10 @@ int sk_bank_render_sum_pp(skred_bank_t *b, int num_frames, int interp, float *d_
 }
 
 int sk_bank_master_pp(skred_bank_t *b, const float *d_sum, int num_frames, int num_channels, float *d_out, int parity, void *stream) {
-  if (!b || !d_sum || !d_out || num_frames <= 0 || num_channels < 2 || !b->d_partial) return fail(SKRED_E_BAD_ARG, "master_pp: bad arguments");
+  if (!b || !d_sum || !d_out || num_frames <= 0 || num_channels < 2 || !b->d_pp_gains || (size_t)num_frames > b->pp_gains_cap)
+    return fail(SKRED_E_BAD_ARG, "master_pp: bad arguments");
   HIP_TRY(hipSetDevice(b->device));
-  const float *gains = b->d_partial + b->gains_offset + ((parity & 1) ? (size_t)num_frames : 0);
+  const float *gains = b->d_pp_gains + ((parity & 1) ? b->pp_gains_cap : 0);
   /* (nothing to commit: slots 2 and 3 of the gain state are scratch) */
   const hipError_t e = (hipError_t)sk_launch_master_apply(d_sum, gains, d_out, num_frames, num_channels, b->d_gain_state + 2, b->d_gain_state + 3, (hipStream_t)stream);
   if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "master launch -> %s", hipGetErrorString(e));

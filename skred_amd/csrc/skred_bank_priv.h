@@ -24,6 +24,7 @@ typedef struct {
   uint32_t seq;               /* != 0: a batch read from this slot is in flight; its last kernel stores this number into the bank's
                                  h_upd_done[slot] when it has run (no event: skred_update_kernels.hip, sk_batch_done) */
 } sk_upd_slot_t;
+#define SK_SPLIT_MAX_LDS (160u * 1024u)   /* LDS of a CU: sk_render_split_kernel's workgroup must fit (twice, for two workgroups per CU) */
 #define SK_FM2_MIN_VOICES 1024      /* two-operator FM banks at least this large keep each (carrier, modulator) pair in one lane */
 #define SK_FAST2_MOTION_MIN_VOICES 278528   /* ... while envelopes move: banks smaller than this stay on the one-voice kernel (round 3, the envelope kernel
                                                beside the steady one: 262 144 voices 184 vs 198 us per block, 294 912 voices 214 vs 202; tools/ab_env_mid.py) */
@@ -45,6 +46,9 @@ struct skred_bank {
   uint32_t *d_tickets;        /* [SK_FINISH_SLABS + 1] arrival counters of the in-kernel mix-down */
   int timing_every;           /* SKRED_OPT_KERNEL_TIMING: bracket every n-th launch's render kernels with an event pair (0: none) */
   float *d_gain_state;        /* [0] master smoother gain carried between blocks; [1] the gain a sum-only render prepared for skred_bank_master */
+  float *d_pp_gains;          /* [2][pp_gains_cap]: the per-frame master gains of the pipelined sum-only form's two blocks in flight (fixed rows:
+                                 block k's master stage reads its row while block k + 1 renders, whatever kernel and block length that one has) */
+  size_t pp_gains_cap;        /* floats per row */
   int pp_parity;              /* >= 0 only inside sk_bank_render_sum_pp: which of the two gain rows the sum-only render fills */
   int gains_frames;           /* > 0: the latest skred_bank_render() left the master gains of a block of this many frames in d_partial */
   size_t gains_offset;        /* ... at this float offset */
@@ -76,6 +80,8 @@ struct skred_bank {
   uint32_t bound_len, bound_min_ticket;   /* reports of launches before bound_min_ticket (the last rebuild of the list) do not count */
   int bound_valid;
   int last_in_place;          /* the latest block took that path */
+  int split_mode;             /* SKRED_OPT_SPLIT: 0 never, 1 where it is the faster form (default), 2 whenever the bank qualifies */
+  int last_split;             /* the latest block ran sk_render_split_kernel */
   int in_place_mode;          /* SKRED_OPT_IN_PLACE: 0 never, 1 where it is the faster path (default), 2 wherever the rows provably suffice */
   uint32_t violations_seen;   /* ... as last read back */
   hipStream_t side;           /* the envelope kernel's stream, beside the caller's */

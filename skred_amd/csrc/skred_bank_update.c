@@ -266,7 +266,7 @@ static int staging_slot(skred_bank_t *b, size_t bytes, hipStream_t s, sk_upd_slo
   const int idx = (int)(b->upd_head++ % SK_UPD_RING);
   sk_upd_slot_t *sl = &b->upd[idx];
   if (!b->h_upd_done) {
-    HIP_TRY(hipHostMalloc((void **)&b->h_upd_done, SK_UPD_RING * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&b->h_upd_done, SK_UPD_RING * sizeof(uint32_t), hipHostMallocCoherent));   /* (the host polls words the device stores while kernels run) */
     for (int i = 0; i < SK_UPD_RING; i++) b->h_upd_done[i] = 0;
     HIP_TRY(hipMalloc((void **)&b->d_upd_cnt, SK_UPD_RING * sizeof(uint32_t)));
     HIP_TRY(hipMemset(b->d_upd_cnt, 0, SK_UPD_RING * sizeof(uint32_t)));
@@ -278,7 +278,12 @@ static int staging_slot(skred_bank_t *b, size_t bytes, hipStream_t s, sk_upd_slo
       if ((spins & 63) == 63) {
         sched_yield();
         clock_gettime(CLOCK_MONOTONIC, &t1);
-        if (t1.tv_sec - t0.tv_sec > 5) { HIP_TRY(hipDeviceSynchronize()); break; }   /* (a stream that never ran: everything has now) */
+        /* Five seconds without the batch's kernel having run: its stream is blocked -- e.g. behind an event the caller means to record
+         * only after this call returns.  Waiting for the device here would turn that into a deadlock, so the call fails instead; the
+         * slot stays marked in flight (its buffers are still the batch's), and the ring moves on to the next slot. */
+        if (t1.tv_sec - t0.tv_sec > 5)
+          return fail(SKRED_E_NO_DEVICE, "update: staging slot %d is still in flight after 5 s (batch %u of a stream that has not run): "
+                                         "the bank is %d update batches ahead of the device", idx, sl->seq, SK_UPD_RING);
       }
     }
     sl->seq = 0;

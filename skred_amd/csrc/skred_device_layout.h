@@ -83,6 +83,9 @@ enum {
 #define SKM_FM_PAIR     (1u << 7)  /* SKM_FM and every carrier is an even voice modulated by the next voice only, no SKM_STOPS features:
                                       sk_render_fast2_kernel<FMP> keeps carrier and modulator in one lane (no exchange, no votes) */
 #define SKM_PAIR_AP     (1u << 8)  /* SKM_FM_PAIR and some carrier's amplitude or pan is modulated too (by the voice after it or by itself) */
+#define SKM_SPLIT       (1u << 9)  /* one-voice family, clean LDS-table bank believed steady: sk_render_split_kernel (skred_render_split.hip) --
+                                      every 64 voices get an oscillator wave and a post wave, so that small and mid-size banks give a SIMD
+                                      twice the independent instruction streams */
 #define SKM_STOPS       (1u << 4)  /* some voice is a forward one-shot that finishes at its table end (sk_render_fast_kernel<STOPS>) */
 
 #define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */

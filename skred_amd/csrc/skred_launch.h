@@ -4,6 +4,7 @@
  *
  *   skred_render_generic.hip  sk_launch_render (dispatcher), sk_launch_render_mod
  *   skred_render_fast.hip     sk_launch_render_fast
+ *   skred_render_split.hip    sk_launch_render_split, sk_split_lds_bytes
  *   skred_render_fast2.hip    sk_launch_render_fast2, sk_launch_env_fast2, sk_env2_grid, sk_launch_classify
  *   skred_gain_kernels.hip    sk_launch_gain
  *   skred_mix_kernels.hip     sk_launch_master, sk_launch_master_apply
@@ -36,6 +37,10 @@ int sk_launch_render_mod(const sk_render_args_t *args, int n_workgroups, const i
 /* the two specialised families (called by sk_launch_render only) */
 int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+/* args->fast_mode & SKM_SPLIT: the one-voice family with the frame split between an oscillator wave and a post wave (512-thread
+ * workgroups, 256 voices per pass as sk_launch_render_fast); sk_split_lds_bytes: the LDS one of its workgroups takes */
+int sk_launch_render_split(const sk_render_args_t *args, int n_workgroups, hipStream_t stream);
+size_t sk_split_lds_bytes(const sk_render_args_t *args);
 /* the two-per-lane family's motion list (skred_render_fast2.hip): the list collected from args->mask_cur and rendered by
  * sk_render_env2_kernel on `stream` -- the block's SECOND stream, beside sk_launch_render_fast2 -- with args->n_env_rows
  * workgroups (sk_env2_grid: what the device holds at once); sk_launch_classify rebuilds `mask` from the planes */

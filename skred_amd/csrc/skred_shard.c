@@ -310,16 +310,31 @@ int skred_shard_render_mix(skred_shard_t *s, int num_frames, int interp, float *
  * of a strong-scaling shard is short (2^17 voices: ~56 us) and the 8-rank reduce of 4 KiB is pure latency, so the sum is what
  * kept 8 GPUs at ~3.3x one ("Mid-size banks").
  *
- * Contract: `out` of call k is complete on `stream` once call k + 1 (or skred_shard_flush) has returned -- one block of
- * latency --, so consecutive calls must alternate between (at least) two output buffers.  Same samples as
- * skred_shard_render_mix, bit for bit (tests/c_shard_smoke.c).  With custom steps (host memory, synchronous) the calls simply
- * run in order: the CPU rehearsal exercises the buffer rotation, not the overlap. */
+ * Contract (host-paced, see below): `out` of call k is complete -- for any stream, and for the host -- once call k + 2 has
+ * returned, or on `stream` after skred_shard_flush(shard, stream).  Call k + 1 returning is NOT enough: nothing on `stream`
+ * waits for the shard's own stream, the host only waits (inside call k) for block k - 2.  Consecutive calls must therefore
+ * alternate between (at least) two output buffers.  Same samples as skred_shard_render_mix, bit for bit
+ * (tests/c_shard_smoke.c).  With custom steps (host memory, synchronous) the calls simply run in order: the CPU rehearsal
+ * exercises the buffer rotation, not the overlap. */
 static int pp_setup(skred_shard_t *s, size_t need) {
+  if (s->bank) {
+    /* the collective's stream and the four events, each created once (a call that failed half-way finds the rest on the next one).
+     * High priority: the collective and the few workgroups of the master stage must not queue behind the next block's render --
+     * and HIP keeps streams of different priorities on different hardware queues, which a second normal-priority stream is not
+     * promised (sharing the caller's hardware queue, block k's master stage waited for block k + 1's render: 156 instead of
+     * 87 us per block on a 2^18-voice shard inside bench.py, where several streams exist) */
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->pp_comm) HIP_TRY(hipStreamCreateWithPriority(&s->pp_comm, hipStreamNonBlocking, -1));
+    for (int i = 0; i < 2; i++) {
+      if (!s->pp_rendered[i]) HIP_TRY(hipEventCreateWithFlags(&s->pp_rendered[i], hipEventDisableTiming));
+      if (!s->pp_done[i]) HIP_TRY(hipEventCreateWithFlags(&s->pp_done[i], hipEventDisableTiming));
+    }
+  }
   if (need <= s->pp_cap) return SKRED_OK;
+  s->pp_cap = 0;                       /* nothing is usable until BOTH buffers exist at the new size */
+  if (s->bank) HIP_TRY(hipDeviceSynchronize());
   for (int i = 0; i < 2; i++) {
     if (s->bank) {
-      HIP_TRY(hipSetDevice(s->device));
-      HIP_TRY(hipDeviceSynchronize());
       if (s->pp_buf[i]) { (void)hipFree(s->pp_buf[i]); s->pp_buf[i] = NULL; }
       HIP_TRY(hipMalloc((void **)&s->pp_buf[i], need * sizeof(float)));
     } else {
@@ -329,17 +344,6 @@ static int pp_setup(skred_shard_t *s, size_t need) {
     }
   }
   s->pp_cap = need;
-  if (s->bank && !s->pp_comm) {
-    /* high priority: the collective and the few workgroups of the master stage must not queue behind the next block's render --
-     * and HIP keeps streams of different priorities on different hardware queues, which a second normal-priority stream is not
-     * promised (sharing the caller's hardware queue, block k's master stage waited for block k + 1's render: 156 instead of
-     * 87 us per block on a 2^18-voice shard inside bench.py, where several streams exist) */
-    HIP_TRY(hipStreamCreateWithPriority(&s->pp_comm, hipStreamNonBlocking, -1));
-    for (int i = 0; i < 2; i++) {
-      HIP_TRY(hipEventCreateWithFlags(&s->pp_rendered[i], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&s->pp_done[i], hipEventDisableTiming));
-    }
-  }
   return SKRED_OK;
 }
 

@@ -5,7 +5,7 @@
  *   1. the control path -- the global voice / wave-slot arrays and the setters that wire.c, seq.c
  *      and skred.c call (reference synth.c:96-136,277-339,367-395,632-1169,1199-1307).  Scalar C on
  *      the host, exactly as in the reference: it runs once per user command, not per sample.
- *      tests/test_dropin_link.py links the reference's own wire.o/seq.o/skred.o against this file and
+ *      tests/test_dropin.py (oracle/Makefile: dropin_check) links the reference's own wire.o/seq.o/skred.o against this file and
  *      checks that every patch line leaves bit-identical state to the reference's synth.o.
  *
  *   2. synth() -- the per-sample render loop (synth.c:502-630) is NOT here: the call snapshots the

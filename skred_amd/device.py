@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "skred_bank_set_globals", "skred_bank_get_globals",
     "skred_bank_render", "skred_bank_master", "skred_bank_render_mix", "skred_bank_render_host",
     "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
-    "skred_bank_set_option", "skred_bank_last_kernel", "skred_bank_last_in_place", "skred_bank_list_violations",
+    "skred_bank_set_option", "skred_bank_last_kernel", "skred_bank_last_in_place", "skred_bank_last_split", "skred_bank_list_violations",
     "skred_bank_update", "skred_bank_defer", "skred_bank_run_queue", "skred_bank_queue_pending",
     "skred_shard_partition", "skred_shard_cut_ok", "skred_shard_create", "skred_shard_create_custom", "skred_shard_destroy",
     "skred_shard_bank", "skred_shard_range", "skred_shard_upload", "skred_shard_set_ops", "skred_shard_rccl_unique_id",
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
     L.skred_bank_set_option.argtypes = [vp, i32, i32]
     L.skred_bank_last_kernel.argtypes = [vp]
     L.skred_bank_last_in_place.argtypes = [vp]
+    L.skred_bank_last_split.argtypes = [vp]
     L.skred_bank_list_violations.argtypes = [vp]
     L.skred_bank_list_violations.restype = C.c_uint
     L.skred_bank_timing_reset.argtypes = [vp]
@@ -256,6 +257,14 @@ class DeviceBank:
         """SKRED_OPT_IN_PLACE: 1 short motion lists rendered in the steady kernel's lanes where that is faster (default), 0 never
         (always the envelope kernel beside it), 2 whenever the gain rows provably suffice."""
         _check(self.L.skred_bank_set_option(self.h, 6, int(mode)), "skred_bank_set_option")
+
+    def set_split(self, mode: int) -> None:
+        """SKRED_OPT_SPLIT: 1 the oscillator-wave / post-wave form of the one-voice kernel where it is faster (default), 0 never,
+        2 whenever the bank qualifies."""
+        _check(self.L.skred_bank_set_option(self.h, 7, int(mode)), "skred_bank_set_option")
+
+    def last_split(self) -> bool:
+        return bool(self.L.skred_bank_last_split(self.h))
 
     def last_in_place(self) -> bool:
         return bool(self.L.skred_bank_last_in_place(self.h))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The voice state a reference patch leaves behind, as data: tests/golden/patch_voices.npz.
+"""The voice state a reference patch leaves behind, as data: skred_amd/data/patches/patch_<n>sk.npz (package data: the banks
+skred_amd.banks.bank_patch() builds are used by tools/, bench-side measurements and tests alike).
 
 Feeds the lines of a few reference patches (the modulation routings VERDICT r2 names: 3.sk, 37.sk, 7.sk, 18.sk, 1.sk) to the
 UNMODIFIED reference's wire() (oracle/_ref/libskred_ref.so) and stores the 64 voices' fields plus the tables they reference.
@@ -19,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
+OUT_DIR = os.path.join(ROOT, "skred_amd", "data", "patches")
 PATCHES = [3, 37, 7, 18, 1]
 AMY_SUBST = {108: 1, 105: 4, 110: 2}
 
@@ -47,7 +49,8 @@ def one(n):
     out["tables"] = tables
     out["meta"] = np.array(json.dumps({"patch": f"{n}.sk", "amy_slots_moved": sorted(set(subst)), "sample_rate": 44100,
                                        "generator": "tests/golden/gen_patch_voices.py"}))
-    np.savez_compressed(os.path.join(HERE, f"patch_{n}sk.npz"), **out)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT_DIR, f"patch_{n}sk.npz"), **out)
     used = np.where((bank.a["voice_amp"] != 0) & (bank.a["voice_table_size"] > 0))[0]
     print(f"patch {n}.sk: voices in use {used.tolist()}, tables {tables.size} floats, AMY slots moved {sorted(set(subst))}")
 

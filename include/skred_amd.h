@@ -320,12 +320,13 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
                                  is the faster path (sparse lists; bank sizes at which a second kernel costs the steady one a
                                  whole round of workgroups); 0: never; 2: whenever the rows provably suffice (tests).  Same
                                  per-voice results either way */,
-       SKRED_OPT_SPLIT = 7 /* small and mid-size clean LDS-table banks, while nothing moves: the one-voice-per-lane kernel with every
-                              frame split between an oscillator wave and a post wave (sk_render_split_kernel), which gives a SIMD that
-                              holds one or two wavefronts of such a bank twice the independent instruction streams.  1 (default): for
-                              banks that fit one round of its workgroups; 0: never; 2: whenever the bank qualifies; 3: even while envelopes
-                              may be moving (tests: the kernel then renders the waves concerned on its general path).  Same
-                              per-voice results either way */ };
+       SKRED_OPT_SPLIT = 7 /* small clean LDS-table banks, while nothing moves: the one-voice-per-lane kernel with every frame split
+                              between an oscillator wave and a post wave (sk_render_split_kernel).  0 (default): never -- measured at
+                              best 1.4 % faster than the unsplit kernel; 1: banks of half a 256-voice group to one
+                              group per CU with filters; 2: whenever the bank qualifies; 3: even while envelopes may be moving (tests:
+                              the kernel then renders the waves concerned on its general path).  Same per-voice results either way */,
+       SKRED_OPT_SPLIT_PAIRS = 8 /* (tests) the split form's workgroup shape: 0 (default) four (oscillator wave, post wave)
+                                    pairs per workgroup; 2 / 4: forced (two: 256-thread workgroups whose four waves land on four SIMDs) */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */

@@ -129,7 +129,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   b->fast2_min_voices = SK_FAST2_MIN_VOICES;
   b->fm2_min_voices = SK_FM2_MIN_VOICES;
   b->in_place_mode = 1;
-  b->split_mode = 1;
+  b->split_mode = 0;
   b->timing_every = 1;
   b->pp_parity = -1;
   b->n_padded = b->n_groups * SK_GROUP;
@@ -187,6 +187,16 @@ void skred_bank_destroy(skred_bank_t *b) {
 }
 
 int skred_bank_n_voices(const skred_bank_t *b) { return b ? b->n_voices : 0; }
+
+/* diagnostic builds only (tools/ab_split.py --stamps; not part of the ABI): the words a -DSKS_STAMPS build of
+ * sk_render_split_kernel leaves in the bank's list buffer */
+int sk_debug_env_list(skred_bank_t *b, int32_t *dst, int n) {
+  if (!b || !dst || n <= 0 || n > b->n_groups * SK_GROUP) return SKRED_E_BAD_ARG;
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(dst, b->d_env_list, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return SKRED_OK;
+}
 
 /* ------------------------------------------------------------------ tables */
 
@@ -296,6 +306,7 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
     case SKRED_OPT_FM2_MIN_VOICES: b->fm2_min_voices = value; return SKRED_OK;
     case SKRED_OPT_IN_PLACE: b->in_place_mode = value < 0 ? 0 : value > 2 ? 2 : value; return SKRED_OK;
     case SKRED_OPT_KERNEL_TIMING: b->timing_every = value < 0 ? 0 : value; return SKRED_OK;
+    case SKRED_OPT_SPLIT_PAIRS: b->split_pairs = (value == 2 || value == 4) ? value : 0; return SKRED_OK;
     case SKRED_OPT_SPLIT: b->split_mode = value < 0 ? 0 : value > 3 ? 3 : value; return SKRED_OK;
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
@@ -512,6 +523,25 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
    * envelopes in motion and the lean one (skred_render_fast.hip: RAMPK); both render everything, so a stale answer costs
    * speed, never samples */
   const int one_env = !modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
+  /* SKRED_OPT_SPLIT (off by default): the one-voice family on a clean LDS-table bank that is believed steady (no envelope: always;
+   * envelopes: a launch has reported that none moved and no control action arrived since) with every frame split between an
+   * oscillator wave and a post wave (skred_render_split.hip).  A wave whose voices are not steady after all renders itself on the
+   * general path of the same kernel, so the belief decides speed only.  Built on the previous review's advice to give small and
+   * mid-size banks more instruction streams per SIMD; measured (tools/ab_split.py, tools/issue_mix.hip, profiles/r04_split_*): the
+   * LDS instructions of the hand-over cost a wave about what the moved arithmetic saves, and from two 64-voice groups per SIMD on
+   * the SIMD's own throughput binds -- 1.4 % faster than sk_render_fast_kernel at 65 536 voices, 3 % slower at 4 096, 20 % slower at
+   * 131 072 -- so the library never picks it by itself; values 1 / 2 / 3 keep it reachable (the rule of value 1: banks of 32 768 ..
+   * 65 536 filtered voices on a 256-CU device).  (Decided here, ahead of the row layout: the two-pair form has twice the rows.) */
+  int split = 0;
+  if (!modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_TWO_PER_LANE | SKM_STOPS | SKM_FM | SKM_MIXED)) && a.lds_table_floats > 0 &&
+      !d_stems && b->split_mode && (!one_env || b->env_quiet || b->split_mode == 3) && sk_split_lds_bytes(&a, 4) <= SK_SPLIT_MAX_LDS) {
+    const int per_cu = (int)(SK_SPLIT_MAX_LDS / sk_split_lds_bytes(&a, 4)) >= 2 ? 2 : 1;
+    if (b->split_mode >= 2 || ((a.fast_mode & SKM_FILTER_ALL) && b->n_groups * 2 >= b->n_cus && b->n_groups <= b->n_cus)) split = 4;
+    (void)per_cu;
+    if (split && b->split_pairs && (b->split_pairs == 4 || b->n_groups * 2 <= SK_MAX_WORKGROUPS)) split = b->split_pairs;   /* (tests) */
+  }
+  if (split) a.fast_mode |= SKM_SPLIT | (split == 2 ? SKM_SPLIT2 : 0u);
+  if (split == 2) n_wg = b->n_groups * 2;
   if (two_env) {
     if (b->last_family != SKRED_KERNEL_FAST2) b->mask_dirty = 1;     /* another family rendered meanwhile: it does not keep the list */
     if (b->mask_dirty) {
@@ -620,18 +650,6 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   const int tslot = b->n_timed % SK_TIMING_RING;
   a.launch_ticket = ++b->launch_ticket;
   a.skip_env2 = two_env ? (uint32_t)b->list_empty : (uint32_t)(one_env && b->env_quiet);
-  /* The one-voice family on a clean LDS-table bank that is believed steady (no envelope: always; envelopes: a launch has reported
-   * that none moved and no control action arrived since): every 64 voices get an oscillator wave AND a post wave
-   * (skred_render_split.hip), which gives the SIMDs of small and mid-size banks twice the instruction streams.  A wave whose
-   * voices are not steady after all renders itself on the general path of the same kernel, so the belief decides speed only.
-   * Sizes (SKRED_OPT_SPLIT 1): banks that fit ONE round of its 512-thread workgroups (two per CU by LDS and registers). */
-  int split = 0;
-  if (!modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_TWO_PER_LANE | SKM_STOPS | SKM_FM | SKM_MIXED)) && a.lds_table_floats > 0 &&
-      !d_stems && b->split_mode && (!one_env || a.skip_env2 || b->split_mode == 3) && sk_split_lds_bytes(&a) <= SK_SPLIT_MAX_LDS) {
-    const int per_cu = (int)(SK_SPLIT_MAX_LDS / sk_split_lds_bytes(&a)) >= 2 ? 2 : 1;
-    if (b->split_mode >= 2 || b->n_groups <= per_cu * b->n_cus) split = 1;
-  }
-  if (split) a.fast_mode |= SKM_SPLIT;
   const int timed = b->timing_every > 0 && (b->launch_ticket % (uint32_t)b->timing_every) == 0;
   if (timed) HIP_TRY(hipEventRecord(b->ev0[tslot], s));
   hipError_t e;

@@ -81,6 +81,7 @@ struct skred_bank {
   int bound_valid;
   int last_in_place;          /* the latest block took that path */
   int split_mode;             /* SKRED_OPT_SPLIT: 0 never, 1 where it is the faster form (default), 2 whenever the bank qualifies */
+  int split_pairs;            /* SKRED_OPT_SPLIT_PAIRS: 0 the library's choice, 2 / 4 forced (tests) */
   int last_split;             /* the latest block ran sk_render_split_kernel */
   int in_place_mode;          /* SKRED_OPT_IN_PLACE: 0 never, 1 where it is the faster path (default), 2 wherever the rows provably suffice */
   uint32_t violations_seen;   /* ... as last read back */

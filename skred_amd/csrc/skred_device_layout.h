@@ -86,6 +86,7 @@ enum {
 #define SKM_SPLIT       (1u << 9)  /* one-voice family, clean LDS-table bank believed steady: sk_render_split_kernel (skred_render_split.hip) --
                                       every 64 voices get an oscillator wave and a post wave, so that small and mid-size banks give a SIMD
                                       twice the independent instruction streams */
+#define SKM_SPLIT2      (1u << 10) /* ... with SKM_SPLIT: two pairs per workgroup (256 threads, 128 voices per pass: args->n_rows counts those) */
 #define SKM_STOPS       (1u << 4)  /* some voice is a forward one-shot that finishes at its table end (sk_render_fast_kernel<STOPS>) */
 
 #define SK_GROUP 256               /* voices per workgroup pass (4 wavefronts) */

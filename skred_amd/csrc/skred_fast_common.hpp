@@ -85,13 +85,27 @@ __device__ __forceinline__ float fast_fetch(const char *lds_tab, const char *__r
 // TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
 // by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
 // Oscillator half of a frame (osc_next, synth.c:217-275): advance and wrap the phase.
-template <bool TAME, bool STOPS>
+// LOZ (with TAME, without STOPS): the caller has also proved lo == 0 for every lane of the wave (the plain LUT case: no loop
+// window), so hi == span and the wrapped phase lo + ((ph0 - lo) - span) is ph0 - span, whose SIGN is the reference's test
+// `phase >= loop_end` (exact for span <= ph0 < 2 span, strictly negative below span; ph0 >= 0).  As unsigned integers a negative
+// float is larger than every non-negative one and non-negative floats keep their order: min_u32 picks ph0 - span when it is
+// >= 0 and ph0 otherwise -- the select of synth.c:241-247 in two instructions (sub, min) where the general form takes five.
+template <bool TAME, bool STOPS, bool LOZ>
 __device__ __forceinline__ float fast_advance(FastRegs &r, float inc);
-template <bool TAME, bool STOPS = false>
-__device__ __forceinline__ float fast_advance(FastRegs &r) { return fast_advance<TAME, STOPS>(r, r.inc); }
-
+template <bool TAME, bool STOPS = false, bool LOZ = false>
+__device__ __forceinline__ float fast_advance(FastRegs &r) { return fast_advance<TAME, STOPS, LOZ>(r, r.inc); }
 template <bool TAME, bool STOPS>
+__device__ __forceinline__ float fast_advance(FastRegs &r, float inc) { return fast_advance<TAME, STOPS, false>(r, inc); }
+
+template <bool TAME, bool STOPS, bool LOZ>
 __device__ __forceinline__ float fast_advance(FastRegs &r, float inc) {
+  if (TAME && LOZ && !STOPS) {
+    const float p0 = r.phase + inc;
+    const float d = p0 - r.span;
+    const float p = __uint_as_float(min(__float_as_uint(p0), __float_as_uint(d)));
+    r.phase = p;
+    return p;
+  }
   const float ph0 = r.phase + inc;
   const float x = ph0 - r.lo;
   const bool over = ph0 >= r.hi;
@@ -317,6 +331,38 @@ __device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float 
   const v2f lr = k.pan * (v2f){s, s};
   out_l = lr.x;
   out_r = lr.y;
+}
+
+// The two halves of fast_post_v's biquad, for a kernel that evaluates them in different wavefronts (skred_render_split.hip):
+// the feed-forward partial sum (b0*s + b1*x1) + b2*x2 needs input samples only, the feedback half finishes
+// y = (P - a1*y1) - a2*y2 -- the same products and the same left-to-right sums as fast_post_v (mmf_process, synth.c:349-364),
+// hence the same bits.  NEWEST_X as there: the newest delay-line entry sits in .x, the new one overwrites the older slot.
+template <bool NEWEST_X>
+__device__ __forceinline__ float fast_biquad_ff(float b0, const v2f &b12, const v2f &b21, float s, v2f &xx) {
+  const v2f t = (NEWEST_X ? b12 : b21) * xx;
+  float y = b0 * s;
+  y = y + (NEWEST_X ? t.x : t.y);                 // + b1 * newest x
+  y = y + (NEWEST_X ? t.y : t.x);                 // + b2 * older x
+  if (NEWEST_X) xx.y = s; else xx.x = s;
+  return y;
+}
+template <bool NEWEST_X>
+__device__ __forceinline__ float fast_biquad_fb(const v2f &a12, const v2f &a21, float p, v2f &yy) {
+  const v2f u = (NEWEST_X ? a12 : a21) * yy;
+  float y = p;
+  y = y - (NEWEST_X ? u.x : u.y);                 // - a1 * newest y
+  y = y - (NEWEST_X ? u.y : u.x);                 // - a2 * older y
+  if (NEWEST_X) yy.y = y; else yy.x = y;
+  return y;
+}
+// ... and what follows the biquad in fast_post_v for a clean bank at a constant envelope level: gain, smoother, voice_sample
+template <bool ENV, bool STALL>
+__device__ __forceinline__ float fast_gain_const(FastRegs &r, float s) {
+  const float gain = ENV ? r.gain_sustain : r.amp;
+  if (!STALL) r.sgain += r.k * (gain - r.sgain);
+  s *= r.sgain;
+  r.sample = s;
+  return s;
 }
 
 // Pan and L/R fold of two frames in one go: four plain products (a v_pk_mul_f32 of a splat makes hipcc treat the

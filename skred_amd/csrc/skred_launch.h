@@ -39,8 +39,8 @@ int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t
 int sk_launch_render_fast2(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 /* args->fast_mode & SKM_SPLIT: the one-voice family with the frame split between an oscillator wave and a post wave (512-thread
  * workgroups, 256 voices per pass as sk_launch_render_fast); sk_split_lds_bytes: the LDS one of its workgroups takes */
-int sk_launch_render_split(const sk_render_args_t *args, int n_workgroups, hipStream_t stream);
-size_t sk_split_lds_bytes(const sk_render_args_t *args);
+int sk_launch_render_split(const sk_render_args_t *args, int n_workgroups, int pairs, hipStream_t stream);
+size_t sk_split_lds_bytes(const sk_render_args_t *args, int pairs);
 /* the two-per-lane family's motion list (skred_render_fast2.hip): the list collected from args->mask_cur and rendered by
  * sk_render_env2_kernel on `stream` -- the block's SECOND stream, beside sk_launch_render_fast2 -- with args->n_env_rows
  * workgroups (sk_env2_grid: what the device holds at once); sk_launch_classify rebuilds `mask` from the planes */

@@ -187,7 +187,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // gaps of a single recurrence with.
 #define SK_FAST_OSC8(DST)                                                                                \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                       \
-    DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));
+    DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false, SK_LOZ_>(r));
 #define SK_FAST_POST8_(SRC, STALL_, RAMP_, NOISE_)                                                                      \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
     float f0_, f1_;                                                                                      \
@@ -210,8 +210,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_OSC_POST8(DST, SRC, STALL_)                                                               \
   _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                  \
     float f0_, f1_;                                                                                      \
-    DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));             \
-    DST[q_ + 1] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true>(r));         \
+    DST[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false, SK_LOZ_>(r));             \
+    DST[q_ + 1] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false, SK_LOZ_>(r));         \
     if (FILTER) {              /* two or more waves per SIMD: plain products, swaps spaced by hand */    \
       float s0_, s1_, u_;                                                                                \
       fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SRC[q_], xx, yy, s0_, u_, xf_blk);         \
@@ -399,6 +399,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  constexpr bool SK_LOZ_ = false;      // (the block macros' wrap form: shadowed where a wave has proved lo == 0, see fast_advance<LOZ>)
   // per wave behind the chunk sums: LDS-table banks -- the reduction tile xt[8][SK_XT]; global-table banks -- the table window
   // (SK_WIN * 64 floats), the tiles behind all four windows
   float *win = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + wave * (TAB_LDS ? 8 * SK_XT : SK_WIN * 64);
@@ -550,6 +551,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     const bool fm_only = STOPS && TAB_LDS && tame_geom && (xf & XF_FM) && (xf & ~(XF_FM | XF_HOLDQ | XF_NOSMOOTH)) == 0;
     const float half_span = 0.5f * r.span;
     (void)fm_only; (void)half_span;
+    const bool loz = __all(dead || r.lo == 0.0f);     // (wave-uniform) no lane has a loop window: fast_advance<LOZ>
+    (void)loz;
 
     bool moved = false;                               // (wave-uniform) some chunk of this pass had an envelope in motion
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
@@ -653,7 +656,13 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
           SK_FAST_PACK_OUT()
         } else {
           SK_FAST_PACK_IN()
-          if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
+#ifndef SK_FAST_NO_LOZ
+          if (loz) {                  // plain LUTs (no loop window): the two-instruction wrap
+            constexpr bool SK_LOZ_ = true;
+            if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false)
+          } else
+#endif
+          { if (fast_smoother_stalled<ENV>(r)) SK_FAST_LDS_CHUNK(true) else SK_FAST_LDS_CHUNK(false) }
           for (; j + 1 < cn; j += 2) SK_FAST_PAIR_STEADY(j, true)
           SK_FAST_PACK_OUT()
         }

@@ -210,7 +210,14 @@ __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, cons
   for (int c = 0; c < 2; ++c) {
     const bool over = ph0[c] >= r.hi[c];
     float p;
-    if (TAME) {
+    if (TAME && LOZ) {
+      // lo == 0: hi == span, so `over` is the sign of phw = ph0 - span (exact for span <= ph0 < 2 span, strictly negative below
+      // span), and ph0 >= 0.  As unsigned integers a negative float is larger than every non-negative one and non-negative floats
+      // keep their order, so min_u32 picks phw when it is >= 0 (then phw < ph0) and ph0 otherwise: the reference's select
+      // (synth.c:241-247) in one plain instruction instead of a compare and a v_cndmask (tools/issue_mix.hip: 2.6 against
+      // 2.8 + 2.7 SIMD cycles per voice and frame)
+      p = __uint_as_float(min(__float_as_uint(ph0[c]), __float_as_uint(phw[c])));
+    } else if (TAME) {
       p = over ? phw[c] : ph0[c];
     } else {
       const bool simple = over && (x[c] < r.span2[c]);

@@ -372,7 +372,7 @@ extern "C" int sk_launch_render(const sk_render_args_t *args, int n_workgroups, 
                            (size_t)4 * SK_CHUNK * sizeof(float2);
   // clean banks (skred_bank.c:classify) have specialised kernels; with stems the one-voice kernel (or the generic one)
   if ((args->fast_mode & SKM_FAST) && (args->fast_mode & SKM_SPLIT) && !stems && tab_lds && !(args->fast_mode & SKM_TWO_PER_LANE))
-    return sk_launch_render_split(args, n_workgroups, stream);
+    return sk_launch_render_split(args, n_workgroups, (args->fast_mode & SKM_SPLIT2) ? 2 : 4, stream);
   if ((args->fast_mode & SKM_FAST) && (!stems || !(args->fast_mode & SKM_TWO_PER_LANE)))   // (stems: the one-voice kernel has them)
     return (args->fast_mode & SKM_TWO_PER_LANE) ? sk_launch_render_fast2(args, n_workgroups, lds_bytes, stream)
                                                 : sk_launch_render_fast(args, n_workgroups, lds_bytes, stream);

@@ -263,6 +263,10 @@ class DeviceBank:
         2 whenever the bank qualifies."""
         _check(self.L.skred_bank_set_option(self.h, 7, int(mode)), "skred_bank_set_option")
 
+    def set_split_pairs(self, pairs: int) -> None:
+        """SKRED_OPT_SPLIT_PAIRS (tests): 0 the library's choice, 2 / 4 pairs per workgroup forced."""
+        _check(self.L.skred_bank_set_option(self.h, 8, int(pairs)), "skred_bank_set_option")
+
     def last_split(self) -> bool:
         return bool(self.L.skred_bank_last_split(self.h))
 

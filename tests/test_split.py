@@ -1,5 +1,6 @@
 """GPU tests of sk_render_split_kernel (skred_render_split.hip): the one-voice-per-lane family with every frame split between
-an oscillator wave and a post wave -- the form small and mid-size clean banks take while nothing moves (SKRED_OPT_SPLIT).
+an oscillator wave and a post wave -- an OPTION (SKRED_OPT_SPLIT; off by default) for small clean banks
+while nothing moves.
 
 The checker is the oracle (oracle/cpu_ref.c, pinned bit for bit to the compiled reference by test_oracle_vs_golden.py); every
 call goes through the C ABI.  Bars as everywhere: per-voice read-write state BIT-EXACT, float mix within 1e-5 (tree sum against
@@ -52,7 +53,8 @@ def _render_blocks(dev, bank, tables, g, interp, blocks, split, setup=None):
     db.upload(host)
     db.set_globals(g)
     db.fast2_min_voices(1 << 30)                      # the one-voice family at every size
-    db.set_split(split)
+    if split is not None:
+        db.set_split(split)
     if setup:
         setup(db)
     ref_host, ref_g = bank.copy(), g.copy()
@@ -73,25 +75,29 @@ def _render_blocks(dev, bank, tables, g, interp, blocks, split, setup=None):
     return took
 
 
-@pytest.mark.parametrize("recipe,interp,n", [("c1", 0, 4096), ("c2", 0, 5000), ("c2", 1, 3000), ("c1", 1, 700), ("c2", 0, 65536)])
-def test_split_steady_bank_vs_oracle(dev, recipe, interp, n):
+@pytest.mark.parametrize("recipe,interp,n,pairs", [("c1", 0, 4096, 2), ("c2", 0, 5000, 2), ("c2", 1, 3000, 4), ("c1", 1, 700, 2), ("c2", 0, 65536, 0),
+                                                    ("c1", 0, 4096, 4), ("c2", 1, 20000, 2)])
+def test_split_steady_bank_vs_oracle(dev, recipe, interp, n, pairs):
     """Sustained banks, block lengths that leave every kind of tail: one short block (7), no block at all (1, 3), whole blocks
-    and a ragged chunk (100 = 64 + 36 = 12 blocks + 4), many chunks (777 = 12 chunks + 9 frames, 4800), and the callback size."""
+    and a ragged chunk (100 = 64 + 36 = 12 blocks + 4), many chunks (777 = 12 chunks + 9 frames, 4800), and the callback size.
+    Both workgroup shapes: four pairs (`pairs` 0: the default shape) and two."""
     bank, tables, g = _sustained(recipe, n)
     bank["voice_amp"][::11] = 0.0                     # skipped voices (state frozen, sample = 0)
     blocks = [512, 512, 512, 7, 1, 3, 8, 9, 63, 64, 65, 100, 777, 512, 4800, 16, 512]
-    took = _render_blocks(dev, bank, tables, g, interp, blocks, split=2)
+    took = _render_blocks(dev, bank, tables, g, interp, blocks, split=2, setup=lambda db: db.set_split_pairs(pairs))
     # an enveloped bank waits for a launch to report that nothing moved; from then on every block is the split form
     assert all(took[3:]), took
     assert not took[0], "the first block after an upload must not assume anything about envelopes"
 
 
-def test_split_is_the_default_for_small_quiet_banks(dev):
-    """SKRED_OPT_SPLIT 1 (the default): a 4 096-voice bank that has reported quiet runs the split form, a bank beyond one round of
-    its workgroups does not, and value 0 switches it off."""
-    bank, tables, g = _sustained("c2", 4096)
+def test_split_is_off_by_default_and_value_one_has_a_size_rule(dev):
+    """SKRED_OPT_SPLIT: 0 is the default (the library never picks the split form by itself: it measured at best 1.4 % faster);
+    value 1 takes filtered banks of half a 256-voice group to one group per CU once they have reported quiet, and nothing else."""
+    bank, tables, g = _sustained("c2", 40000)
+    assert not any(_render_blocks(dev, bank, tables, g, 0, [256, 256, 256, 256], split=None))
     assert all(_render_blocks(dev, bank, tables, g, 0, [256, 256, 256, 256, 256], split=1)[3:])
-    assert not any(_render_blocks(dev, bank, tables, g, 0, [256, 256, 256, 256], split=0))
+    small, tables, g = _sustained("c2", 4096)
+    assert not any(_render_blocks(dev, small, tables, g, 0, [256, 256, 256, 256], split=1))
     big, tables, g = _sustained("c2", 150000)
     assert not any(_render_blocks(dev, big, tables, g, 0, [128, 128, 128, 128], split=1))
 
@@ -187,8 +193,9 @@ def test_split_general_path_envelopes_in_motion(dev, recipe, interp):
 
 
 def test_split_equals_the_unsplit_kernel_bit_for_bit(dev):
-    """Same per-voice samples, same order of the wave / workgroup / block sums: the mix of the split form equals the mix of
-    sk_render_fast_kernel BYTE for byte (not only within tolerance)."""
+    """Same per-voice samples, same order of the wave / workgroup / block sums: with four pairs per workgroup (the shape of
+    sk_render_fast_kernel's 256-voice passes; forced here -- a bank this small would get the two-pair shape, whose 128-voice
+    rows add up in another order) the mix of the split form equals the mix of sk_render_fast_kernel BYTE for byte."""
     import torch
     n = 20000
     bank, tables, g = _sustained("c2", n)
@@ -200,6 +207,7 @@ def test_split_equals_the_unsplit_kernel_bit_for_bit(dev):
         db.set_globals(g)
         db.fast2_min_voices(1 << 30)
         db.set_split(split)
+        db.set_split_pairs(4)
         got = []
         for frames in (512, 512, 512, 512, 100, 777):
             out = torch.zeros(frames, 2, device="cuda")

@@ -25,17 +25,37 @@ def run(rec, n, split, interp, F, steps):
         torch.cuda.synchronize()
         res.append((time.perf_counter() - t0) / steps * 1e6)
     took = db.last_split()
+    if STAMPS and split:
+        import ctypes as C, numpy as np
+        n_wg = (db.n + 1023) // 1024 * 4
+        buf = np.zeros(n_wg * 64, np.int32)
+        db.L.sk_debug_env_list.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        rc = db.L.sk_debug_env_list(db.h, buf.ctypes.data, buf.size)
+        w = buf.reshape(n_wg, 8, 8).astype(np.float64)
+        for name, sl in (("post", slice(0, 4)), ("osc ", slice(4, 8))):
+            x = w[:, sl, :].reshape(-1, 8)
+            x = x[x[:, 0] > 0]
+            if len(x):
+                clk = x[:, 0].sum() / max(x[:, 4].sum(), 1) * 100.0
+                print(f"   stamps {name}: waves {len(x)}  loop cycles {x[:,0].mean():9.0f} ({x[:,0].mean()/F:6.1f} per frame)  waiting {x[:,1].mean():9.0f} ({100*x[:,1].sum()/x[:,0].sum():4.1f} %) in {x[:,2].mean():6.1f} waits"
+                      f"  chunk ends {x[:,3].mean():8.0f} ({100*x[:,3].sum()/x[:,0].sum():4.1f} %)  in-kernel clock {clk:6.0f} MHz", flush=True)
     db.close()
     return min(res), sorted(res)[2], took
 
 
+STAMPS = False
+
+
 def main():
+    global STAMPS
     ap = argparse.ArgumentParser()
+    ap.add_argument("--stamps", action="store_true", help="the library is a -DSKS_STAMPS build: print what its waves recorded")
     ap.add_argument("--f", type=int, default=512)
     ap.add_argument("--interp", type=int, default=0)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--sizes", default="c1:4096,c2:16384,c2:65536,c2:98304,c2:131072,c2:196608,c2:262144")
     a = ap.parse_args()
+    STAMPS = a.stamps
     for item in a.sizes.split(","):
         rec, n = item.split(":"); n = int(n)
         base = run(rec, n, 0, a.interp, a.f, a.steps)

@@ -115,11 +115,15 @@ print("RATE", 64 * 512 * n / (time.perf_counter() - t0))
         return None
 
 
-def pmc_entry(workload):
+def pmc_entry(workload, frames=None):
     """What the committed rocprofv3 PMC passes measured for this workload shape (profiles/pmc_traffic.json: HBM bytes
-    per launch, L2 read requests per launch); bench.py itself cannot collect PMC counters."""
+    per launch, L2 read requests per launch, VALU instructions per launch); bench.py itself cannot collect PMC counters.
+    Block lengths other than 512 frames have entries of their own (`c3@64`, `c3@4800`), shards of config 3 too (`shard17` ...)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[workload]
+        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if frames is not None and f"{workload}@{frames}" in tab:
+            return tab[f"{workload}@{frames}"]
+        return tab[workload]
     except Exception:
         return None
 
@@ -154,7 +158,7 @@ def valu_roofline(workload, voices, frames, k_mean):
     kernel time; peak = SIMDs x the plain-fp32 issue rate tools/issue_rate measures on this box.  A packed instruction
     (v_pk_*_f32: two voices' worth) occupies the VALU about 1.6x as long as a plain one, so a kernel that is half packed
     cannot reach 1.0; `valu_busy_fraction` is the PMC's own SQ_ACTIVE_INST_VALU / cycles figure for the same pass."""
-    pm = pmc_entry(workload)
+    pm = pmc_entry(workload, frames)
     if not pm or not pm.get("valu_insts_per_launch") or pm.get("frames_per_launch") != frames or pm.get("voices") != voices or not ISSUE_PEAK:
         return None
     insts = pm["valu_insts_per_launch"]
@@ -173,7 +177,7 @@ def roofline(workload, voices, frames, gather_bytes, k_mean, k_min, k_cnt, kerne
     k_mean = max(k_mean - EVENT_PAIR_MS, 1e-6)                   # the event pair's own share of the bracket (calibrated per run)
     k_min = max(k_min - EVENT_PAIR_MS, 1e-6)
     achieved = launch_bytes / (k_mean * 1e-3)
-    pm = pmc_entry(workload)
+    pm = pmc_entry(workload, frames)
     traffic = pm["hbm_bytes_per_launch"] if pm and pm.get("frames_per_launch") == frames and pm.get("voices") == voices else None
     out = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
            "frac": achieved / HBM_PEAK, "traffic": traffic,
@@ -647,6 +651,17 @@ def main():
                     spinup(blk, 512)
                     dtp, _, _, _ = timed(blk, sh.bank, 512, steps_p, 20, 0)
                     ent[form + "_ms"] = dtp / steps_p * 1e3
+                    if form == "fused":
+                        # the shard's own kernel time (event pairs around every 8th launch, a run of its own: a pair costs the stream a
+                        # few microseconds) and what it means against the VALU issue peak (instructions per launch: profiles/)
+                        _, kmp, knp, kcp = timed(blk, sh.bank, 512, steps_p, 10, 8)
+                        ent["kernel"] = KERNELS.get(sh.bank.last_kernel(), "?")
+                        ent["kernel_ms"] = max(kmp - EVENT_PAIR_MS, 1e-6)
+                        ent["kernel_ms_min"] = max(knp - EVENT_PAIR_MS, 1e-6)
+                        ent["launches_timed"] = kcp
+                        vr_s = valu_roofline(f"shard{n_sh.bit_length() - 1}", n_sh, 512, ent["kernel_ms"])
+                        if vr_s:
+                            ent["roofline_valu"] = vr_s
                     sh.close()
                 del whole
             except Exception as ex:       # (a box without RCCL: the fused number stands alone)

@@ -39,6 +39,11 @@ def _run(dev, n, recipe, plan, notes_at=()):
     """plan: list of (frames, 'p' | 's').  Returns the blocks' outputs in order (host arrays) and the kernels that rendered them."""
     import torch
     bank, tables, g = banks.RECIPES[recipe](n)
+    if notes_at:                                       # every note long in its sustain stage: the bank reports "quiet" after its first block,
+        e = bank["voice_amp_envelope"]                 # moves to the two-voices-per-lane kernel, and comes back with every note-on
+        e["sample_start"][:] = np.uint64(g.synth_sample_count - 30000)
+        e["sample_release"][:] = 0
+        e["is_active"][:] = 1
     sh = _shard(n, bank, tables, g)
     st = torch.cuda.Stream()
     outs = [torch.zeros(max(f for f, _ in plan), 2, device="cuda") for _ in plan]     # one buffer per block: nothing is reused

@@ -217,6 +217,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 struct FastPk {
   v2f b12, b21, a12, a21;       // (b1,b2) (b2,b1) (a1,a2) (a2,a1)
   v2f pan;                      // (pan_left, pan_right)
+  // fast_pan_fold2p: the pan gains of the lane's own voice and of its partner 32 lanes away, arranged so that ONE lane-half swap
+  // of two frames' samples feeds both channels (lanes 0..31: A = own, B = the voice 32 lanes up; lanes 32..63: A = the voice 32
+  // lanes down, B = own)
+  float plA, plB, prA, prB;
 };
 
 // sample & hold and bit-crush of a lane (synth.c:560-574), for the block paths of extended banks
@@ -385,6 +389,30 @@ __device__ __forceinline__ void fast_pan_fold2(float s0, float s1, float pan_l, 
       : "v"(s0), "v"(s1), "v"(pan_l), "v"(pan_r));
   f0 = a0;
   f1 = a1;
+}
+
+// the partner's pan gains for fast_pan_fold2p (once per chunk; the pan of a clean bank does not move inside a launch)
+__device__ __forceinline__ void fast_pk_partner(FastPk &k, float pan_l, float pan_r) {
+  const auto pl = __builtin_amdgcn_permlane32_swap(__float_as_uint(pan_l), __float_as_uint(pan_l), false, false);
+  const auto pr = __builtin_amdgcn_permlane32_swap(__float_as_uint(pan_r), __float_as_uint(pan_r), false, false);
+  k.plA = __uint_as_float(pl[0]); k.plB = __uint_as_float(pl[1]);   // (pl[0]: pan_left of lanes 0..31 in both halves; pl[1]: of lanes 32..63)
+  k.prA = __uint_as_float(pr[0]); k.prB = __uint_as_float(pr[1]);
+}
+
+// The same pan + fold for two frames with ONE swap instead of two: v_permlane32_swap(s0, s1) leaves (s0 of lanes 0..31 | s1 of
+// lanes 0..31) in one register and (s0 of lanes 32..63 | s1 of lanes 32..63) in the other, so with the partner's pan gains at
+// hand (FastPk::plA ...) every lane forms a pair sum directly: lanes 0..31 the pair sums of FRAME 0 (u: left, v: right), lanes
+// 32..63 those of FRAME 1 -- the products s * pan_left, s * pan_right of both lanes of a pair and their sum, exactly what
+// fast_pan_fold2 adds, one v_permlane32_swap (8.8 cycles of a lone wave, tools/issue_mix.hip) and a wait state fewer per frame
+// pair.  The tile rows then hold (L of frame q | L of frame q + 1) and (R of frame q | R of frame q + 1): the reduction's
+// last step stores accordingly (SK_PAIRED_ in skred_render_fast.hip).
+__device__ __forceinline__ void fast_pan_fold2p(float s0, float s1, float plA, float plB, float prA, float prB, float &u, float &v) {
+  // (the builtin, not an asm island: hipcc spaces the swap behind the products it reads by itself and fills the wait states
+  // with the other strand's instructions -- a lone wave has nothing else to fill them with)
+  const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
+  const float a = __uint_as_float(p[0]), b = __uint_as_float(p[1]);
+  u = a * plA + b * plB;
+  v = a * prA + b * prB;
 }
 
 // A one-pole smoother towards a constant gain stops moving once k*(gain - g) rounds away (see

@@ -195,7 +195,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       float s0_, s1_, u_;                                                                                \
       fast_post_v<FILTER, ENV, STALL_, STOPS, true, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_], NOISE_), xx, yy, s0_, u_, xf_blk, &ev_);         \
       fast_post_v<FILTER, ENV, STALL_, STOPS, false, false, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_ + 1], NOISE_), xx, yy, s1_, u_, xf_blk, &ev_);    \
-      fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
+      if (SK_PAIRED_) fast_pan_fold2p(s0_, s1_, pk.plA, pk.plB, pk.prA, pk.prB, f0_, f1_);               \
+      else fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                       \
     } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
       float l0_, r0_, l1_, r1_;                                                                          \
       fast_post_v<FILTER, ENV, STALL_, STOPS, true, true, RAMP_>(r, pk, SK_FAST_BLOCK_SAMPLE(SRC[q_], NOISE_), xx, yy, l0_, r0_, xf_blk, &ev_);               \
@@ -216,7 +217,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       float s0_, s1_, u_;                                                                                \
       fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, SRC[q_], xx, yy, s0_, u_, xf_blk);         \
       fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, SRC[q_ + 1], xx, yy, s1_, u_, xf_blk);    \
-      fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                            \
+      if (SK_PAIRED_) fast_pan_fold2p(s0_, s1_, pk.plA, pk.plB, pk.prA, pk.prB, f0_, f1_);               \
+      else fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                       \
     } else {                   /* a bare oscillator bank: hipcc weaves the fold into the oscillator steps */     \
       float l0_, r0_, l1_, r1_;                                                                          \
       fast_post_v<FILTER, ENV, STALL_, STOPS, true>(r, pk, SRC[q_], xx, yy, l0_, r0_, xf_blk);               \
@@ -233,14 +235,22 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     TA = src_[0]; TB = src_[1];                                                                          \
     SK_FAST_WAVE_SYNC()                                                                                  \
   }
+/* (SK_PAIRED_: tile row q holds (L of frame q | L of frame q + 1), row q + 1 the R's -- fast_pan_fold2p --, so the total of row
+   `lane & 7`, half `lane >> 5` belongs to frame (row & 6) + half, channel row & 1) */                   \
 #define SK_FAST_TILE_FINISH(TA, TB, JP)                                                                  \
   {                                                                                                      \
     float t_ = ((((((TA.x + TA.y) + TA.z) + TA.w) + TB.x) + TB.y) + TB.z) + TB.w;                        \
     t_ = row_pair_add(row_ror8_add(t_));                                                                 \
-    if ((lane & 24) == 0) reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (JP) + (lane & 7)])[lane >> 5] = t_; \
+    if ((lane & 24) == 0) reinterpret_cast<float *>(&wsum[wave * SK_CHUNK + (JP) + (SK_PAIRED_ ? (lane & 6) + (lane >> 5) : (lane & 7))])[SK_PAIRED_ ? (lane & 1) : (lane >> 5)] = t_; \
   }
+#ifndef SK_FAST_NO_PAIRED
+#define SK_FAST_PAIRED_OK true
+#else
+#define SK_FAST_PAIRED_OK false
+#endif
 #define SK_FAST_LDS_CHUNK(STALL_)                                                                        \
   {                                                                                                      \
+    constexpr bool SK_PAIRED_ = FILTER && INTERP == 0 && SK_FAST_PAIRED_OK;   /* (these blocks: one swap per frame pair; with the linear lookup's registers the form measured slower) */ \
     const int nblk_ = cn >> 3;                                                                           \
     if (nblk_ > 0) {                                                                                     \
       float sa_[8], sb_[8];                                                                              \
@@ -278,14 +288,15 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
   FastPk pk;   /* (built per chunk: a lane that finished meanwhile carries inert numbers in r) */ \
   pk.b12 = (v2f){r.b1, r.b2}; pk.b21 = (v2f){r.b2, r.b1};                                 \
   pk.a12 = (v2f){r.a1, r.a2}; pk.a21 = (v2f){r.a2, r.a1};                                 \
-  pk.pan = (v2f){r.pan_l, r.pan_r};   /* (the block paths run only in waves without pan modulation) */
+  pk.pan = (v2f){r.pan_l, r.pan_r};   /* (the block paths run only in waves without pan modulation) */ \
+  fast_pk_partner(pk, r.pan_l, r.pan_r);
 #define SK_FAST_PACK_OUT() { r.x1 = xx.x; r.x2 = xx.y; r.y1 = yy.x; r.y2 = yy.y; }
 /* after fast_finish rewrote a finishing lane's numbers (rare): the pairs again */
 #define SK_FAST_REPACK()                                                                  \
   { xx = (v2f){r.x1, r.x2}; yy = (v2f){r.y1, r.y2};                                       \
     pk.b12 = (v2f){r.b1, r.b2}; pk.b21 = (v2f){r.b2, r.b1};                               \
     pk.a12 = (v2f){r.a1, r.a2}; pk.a21 = (v2f){r.a2, r.a1};                               \
-    pk.pan = (v2f){r.pan_l, r.pan_r}; }
+    pk.pan = (v2f){r.pan_l, r.pan_r}; fast_pk_partner(pk, r.pan_l, r.pan_r); }
 // Eight steady frames of the extended frame loop (modulation exchange, finish test, sample & hold ... per frame) with
 // the same tile reduction instead of 12 v_add_dpp per frame; the per-wave LDS region is free here (no table windows
 // in such a wave).
@@ -399,6 +410,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  constexpr bool SK_PAIRED_ = false;   // (the tile layout of the block macros: see SK_FAST_LDS_CHUNK)
   constexpr bool SK_LOZ_ = false;      // (the block macros' wrap form: shadowed where a wave has proved lo == 0, see fast_advance<LOZ>)
   // per wave behind the chunk sums: LDS-table banks -- the reduction tile xt[8][SK_XT]; global-table banks -- the table window
   // (SK_WIN * 64 floats), the tiles behind all four windows

@@ -1,4 +1,4 @@
-"""Where the envelope kernel sits in time relative to the steady kernel: reads a rocprofv3 kernel trace (csv) of tools/ab_env.py
+"""Where the envelope kernel sits in time relative to the steady kernel: reads a rocprofv3 kernel trace (csv) of `tools/ab.py live`
 and prints, for a sample of blocks, start / end of collect, envelope and steady kernels relative to the steady kernel's start."""
 import csv, glob, sys
 path = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]

@@ -333,6 +333,16 @@ int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of th
 int  skred_bank_last_in_place(const skred_bank_t *bank);  /* 1: the latest block rendered its motion list in place (SKRED_OPT_IN_PLACE) */
 int  skred_bank_last_split(const skred_bank_t *bank);     /* 1: the latest block ran the split form of the one-voice kernel (SKRED_OPT_SPLIT) */
 
+/* Per-frame evidence from INSIDE the fast paths (tests).  A launch with the full stem buffer takes the kernels' frame-by-frame
+ * paths, so the 8-frame block paths the benchmarks time were only ever seen through end-of-block state and the mix.  A probe names
+ * up to SKRED_PROBE_MAX voices; every later block writes, for each frame, what the reference stores into its stem buffer for them
+ * (synth.c:607-611: voice_sample x pan_left, x pan_right; exact zeros for a skipped or muted voice) into
+ * d_probe[frame][i][2] (device memory, num_frames x n x 2 floats per block, overwritten block by block) -- from the same launch,
+ * on the same kernel paths, that render the block without it (probe instantiations of the one-voice-per-lane, two-voices-per-lane,
+ * in-place and envelope kernels; other kernel families return SKRED_E_UNSUPPORTED while a probe is set).  n = 0 ends it. */
+#define SKRED_PROBE_MAX 64
+int  skred_bank_set_probe(skred_bank_t *bank, const int32_t *voices, int n, float *d_probe);
+
 /* Cross-check of the motion list of the two-voices-per-lane path ("The motion list"): voices whose envelope may be
  * in motion are kept on a per-voice list ON THE DEVICE (every control action lists the voices it touches, the envelope kernel
  * keeps its voices listed until they rest) and rendered by the envelope kernel beside the steady kernel, which never has to be

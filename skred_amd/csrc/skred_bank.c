@@ -157,6 +157,7 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_tickets) hipFree(b->d_tickets);
   if (b->d_gain_state) hipFree(b->d_gain_state);
   if (b->d_pp_gains) hipFree(b->d_pp_gains);
+  if (b->d_probe_ids) hipFree(b->d_probe_ids);
   if (b->d_out) hipFree(b->d_out);
   if (b->d_stems) hipFree(b->d_stems);
   free(b->h_class); free(b->h_mod); free(b->h_level);
@@ -310,6 +311,21 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
     case SKRED_OPT_SPLIT: b->split_mode = value < 0 ? 0 : value > 3 ? 3 : value; return SKRED_OK;
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
+}
+
+int skred_bank_set_probe(skred_bank_t *b, const int32_t *voices, int n, float *d_probe) {
+  if (!b || n < 0 || n > SK_PROBE_MAX || (n > 0 && (!voices || !d_probe))) return fail(SKRED_E_BAD_ARG, "set_probe: bad arguments");
+  for (int i = 0; i < n; i++)
+    if (voices[i] < 0 || voices[i] >= b->n_voices) return fail(SKRED_E_RANGE, "set_probe: voice %d outside the bank", voices[i]);
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipDeviceSynchronize());                   /* (a block in flight may still read the old list) */
+  if (n > 0) {
+    if (!b->d_probe_ids) HIP_TRY(hipMalloc((void **)&b->d_probe_ids, SK_PROBE_MAX * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(b->d_probe_ids, voices, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  b->n_probe = n;
+  b->d_probe_out = n > 0 ? d_probe : NULL;
+  return SKRED_OK;
 }
 
 int skred_bank_last_kernel(const skred_bank_t *b) { return b ? b->last_kernel : -1; }
@@ -540,6 +556,17 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     (void)per_cu;
     if (split && b->split_pairs && (b->split_pairs == 4 || b->n_groups * 2 <= SK_MAX_WORKGROUPS)) split = b->split_pairs;   /* (tests) */
   }
+  if (b->n_probe > 0) {
+    /* probes are written by the probe instantiations of the specialised kernels only */
+    if (modulated || !(a.fast_mode & SKM_FAST) || (a.fast_mode & SKM_FM_PAIR) || d_stems)
+      return fail(SKRED_E_UNSUPPORTED, "a probe is set, but this block would run a kernel without probe instantiations "
+                                       "(generic / modulated / two-operator FM pairs, or a launch with the full stem buffer)");
+    split = 0;
+    a.probe_ids = b->d_probe_ids;
+    a.n_probe = b->n_probe;
+    a.probe_out = b->d_probe_out;
+    HIP_TRY(hipMemsetAsync(b->d_probe_out, 0, (size_t)num_frames * (size_t)b->n_probe * 2 * sizeof(float), s));   /* (a skipped / muted voice writes nothing) */
+  }
   if (split) a.fast_mode |= SKM_SPLIT | (split == 2 ? SKM_SPLIT2 : 0u);
   if (split == 2) n_wg = b->n_groups * 2;
   if (two_env) {
@@ -662,7 +689,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "collect launch -> %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(b->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(b->side, b->ev_fork, 0));
-    e = (hipError_t)sk_launch_env_fast2(&a, b->side);
+    e = (hipError_t)sk_launch_env_fast2(&a, b->side);   /* (with a probe set it forwards to the probe instantiations) */
     if (e != hipSuccess) return fail(SKRED_E_NO_DEVICE, "envelope kernel launch -> %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(b->ev_join, b->side));
   }

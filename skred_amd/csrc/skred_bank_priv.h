@@ -80,6 +80,9 @@ struct skred_bank {
   uint32_t bound_len, bound_min_ticket;   /* reports of launches before bound_min_ticket (the last rebuild of the list) do not count */
   int bound_valid;
   int last_in_place;          /* the latest block took that path */
+  int32_t *d_probe_ids;       /* skred_bank_set_probe: the probed voices on the device, their number, the caller's buffer */
+  int n_probe;
+  float *d_probe_out;
   int split_mode;             /* SKRED_OPT_SPLIT: 0 never, 1 where it is the faster form (default), 2 whenever the bank qualifies */
   int split_pairs;            /* SKRED_OPT_SPLIT_PAIRS: 0 the library's choice, 2 / 4 forced (tests) */
   int last_split;             /* the latest block ran sk_render_split_kernel */

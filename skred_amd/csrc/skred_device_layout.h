@@ -207,7 +207,14 @@ typedef struct {
                               commits it */
   uint32_t *tickets;       /* [SK_FINISH_SLABS + 1] arrival counters; the last arriver re-arms its counter to 0 */
   float vol_target, vol_k; /* volume_final, volume_smoother_smoothing */
+  /* ---- per-frame probes (tests; skred_bank_set_probe): the (L, R) of every frame of up to SK_PROBE_MAX voices, written from INSIDE
+   * the kernels' block paths by their probe instantiations (translation units compiled with -DSK_PROBE_TU; the ordinary
+   * instantiations contain none of this) ---- */
+  const int32_t *probe_ids; /* [n_probe] voice numbers */
+  float *probe_out;         /* [num_frames][n_probe][2], zeroed by the host before the launch (a skipped / muted voice writes nothing) */
+  int32_t n_probe;
 } sk_render_args_t;
+#define SK_PROBE_MAX 64
 
 #define SK_FINISH_SLABS 32     /* slabs of the two-level mix-down (a multiple of 8: the workgroups of a slab share an XCD's L2
                                   under round-robin placement -- speed only) */

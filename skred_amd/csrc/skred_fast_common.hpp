@@ -43,6 +43,11 @@ struct FastRegs {
   // banks in which only some voices run the biquad / the envelope
   bool filt, use_env;
   float ox1, ox2, oy1, oy2;     // delay line of an UNfiltered voice as loaded: it is stored back untouched
+#ifdef SK_PROBE_TU
+  float2 *probe;                // this frame's probe row of the voice (nullptr: not probed / skipped / muted); skred_bank_set_probe
+  int probe_stride;             // float2 per frame
+  bool probe_any;               // (wave-uniform) some lane of the wave writes probes
+#endif
 };
 
 // NOCLAMP: the caller guarantees 0 <= lo <= pos < hi <= table_size (TAME loops), so the reference's
@@ -206,6 +211,9 @@ __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float
   }
   out_l = s * r.pan_l;
   out_r = s * r.pan_r;
+#ifdef SK_PROBE_TU
+  if (r.probe_any && r.probe) { *r.probe = make_float2(out_l, out_r); r.probe += r.probe_stride; }   // synth.c:603-608
+#endif
 }
 
 // The same rest-of-frame for the steady block paths, with the delay line and its coefficients held as register PAIRS so
@@ -331,6 +339,9 @@ __device__ __forceinline__ void fast_post_v(FastRegs &r, const FastPk &k, float 
     s *= r.sgain;
   }
   r.sample = s;
+#ifdef SK_PROBE_TU
+  if (r.probe_any && r.probe) { *r.probe = make_float2(s * k.pan.x, s * k.pan.y); r.probe += r.probe_stride; }   // synth.c:603-608: the same products the mix takes
+#endif
   if (!PAN) { out_l = s; return; }                     // the caller pans and folds two frames at once (fast_pan_fold2)
   const v2f lr = k.pan * (v2f){s, s};
   out_l = lr.x;

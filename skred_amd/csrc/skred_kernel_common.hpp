@@ -301,6 +301,17 @@ __device__ __forceinline__ void sk_finish_env(const sk_render_args_t &a, int n_u
   else sk_finish_env_cols<float2>(a, n_used, tid, nthreads, flag_lds);
 }
 
+// ---------------------------------------------------------------- per-frame probes (translation units built with -DSK_PROBE_TU)
+#ifdef SK_PROBE_TU
+// where voice v's (L, R) of the block's first frame go (or nullptr: not probed, or `off`: a skipped / muted voice, whose rows
+// keep the zeros the host put there, as the reference's stems do, synth.c:533-534,609-611); rows are a.n_probe float2 apart
+__device__ __forceinline__ float2 *sk_probe_row(const sk_render_args_t &a, int v, bool off) {
+  int slot = -1;
+  for (int i = 0; i < a.n_probe; ++i) slot = a.probe_ids[i] == v ? i : slot;
+  return (slot < 0 || off) ? nullptr : reinterpret_cast<float2 *>(a.probe_out) + slot;
+}
+#endif
+
 // ---------------------------------------------------------------- small exact helpers
 
 // fmodf for x >= 0, y > 0, exact.  x - y is exact for y <= x < 2y (Sterbenz), which is the

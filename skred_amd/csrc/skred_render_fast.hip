@@ -95,6 +95,9 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;
     *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;
     dead = true; silent = true; sample_final = true;
+#ifdef SK_PROBE_TU
+    r.probe = nullptr;                                   // (from the next frame on the reference skips it: zeros, which the host put there)
+#endif
     r.inc = 0.0f; r.lo = 0.0f; r.hi = 1.0f; r.span = 1.0f; r.span2 = 2.0f; r.phase = 0.0f;
     r.toff4 = 0; r.tsize_m1 = 0;
     r.k = 0.0f; r.sgain = 0.0f; r.amp = 0.0f; r.gain_sustain = 0.0f;
@@ -400,7 +403,9 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // instantiation because its registers perturb the allocation of the steady loops (+4..6 % per frame on C1 / C2 / the
 // 2^17-voice shard when both lived in one kernel): the host launches it while envelopes may be moving and the lean one
 // once a launch has reported that none did (the general frames are in both, so the choice only decides speed).
-template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS, bool RAMPK = false>
+// PROBE: the same kernel compiled with -DSK_PROBE_TU (fast_post / fast_post_v then also write the probe rows of
+// skred_bank_set_probe): a template parameter only so that those instantiations are symbols of their own.
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS, bool RAMPK = false, bool PROBE = false>
 __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES : SK_FAST_MIN_WAVES) : (STOPS ? SK_FAST_WIN_EXT_MIN_WAVES : SK_FAST_WIN_MIN_WAVES)) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
@@ -499,6 +504,11 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       r.noise = STOPS && (flags & SKF_NOISE);
       r.ophase = r.phase;
       muted = (flags & SKF_MUTED) != 0;
+#ifdef SK_PROBE_TU
+      r.probe_stride = a.n_probe;
+      r.probe = sk_probe_row(a, v, silent || v >= a.n_voices);
+      r.probe_any = __any(r.probe != nullptr);
+#endif
       if (STOPS && (a.fast_mode & SKM_FM)) {
         const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
         const uint4 mf = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODF][v]);
@@ -768,8 +778,19 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
 // ---------------------------------------------------------------- launcher (C linkage)
 
 // specialisation key: table residency x filter x envelope x interpolation
-extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
-                                     hipStream_t stream) {
+#ifdef SK_PROBE_TU
+#define SK_FAST_LAUNCHER sk_launch_render_fastp
+#define SK_PROBE_FLAG true
+#else
+#define SK_FAST_LAUNCHER sk_launch_render_fast
+#define SK_PROBE_FLAG false
+extern "C" int sk_launch_render_fastp(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+#endif
+extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
+                                hipStream_t stream) {
+#ifndef SK_PROBE_TU
+  if (args->probe_out) return sk_launch_render_fastp(args, n_workgroups, lds_bytes, stream);
+#endif
   const bool tab_lds = args->lds_table_floats > 0;
   // per wave: the reduction tile of the block paths; global-table banks: a table window too (LDS-table banks used to get the
   // window's 5 KB per wave as well: 12 KB per workgroup that cost banks with 32 KB of tables their third workgroup per CU)
@@ -781,8 +802,8 @@ extern "C" int sk_launch_render_fast(const sk_render_args_t *args, int n_workgro
   const bool rampk = !args->skip_env2;   /* envelopes may be moving (skip_env2: a launch has reported that none did) */
   const bool guard = args->interp == 2;  /* linear lookup, every live voice on a guarded whole-table loop (SKF_GUARD; the host counts) */
 #define SK_FAST_LAUNCH_(T, F, E, I, X)                                                                                      \
-  { if (E && rampk) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, E>), grid, block, lds_bytes, stream, *args);   \
-    else hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, false>), grid, block, lds_bytes, stream, *args); }
+  { if (E && rampk) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, E, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args);   \
+    else hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, false, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args); }
 #define SK_FAST_CASE(K, T, F, E, I)                                                                                        \
   case K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), false) else SK_FAST_LAUNCH_(T, F, E, I, false) break;      \
   case 16 + K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), true) else SK_FAST_LAUNCH_(T, F, E, I, true) break;

@@ -59,6 +59,11 @@ struct Fast2Regs {
   // sk_gain_kernel left for it (skred_device_layout.h: env_gain)
   bool lst[2];                             // this voice is listed
   v2f gt;                                  // the current frame's gains of the lane's listed voices (set by the caller)
+#ifdef SK_PROBE_TU
+  float2 *probe[2];                        // this frame's probe row of the lane's voices (nullptr: not probed / silent / rendered elsewhere)
+  int probe_stride;                        // float2 per frame
+  bool probe_any;                          // (wave-uniform) some lane of the wave writes probes
+#endif
 };
 
 struct Env2Regs {                 // sk_render_env2_kernel only
@@ -326,6 +331,12 @@ __device__ __forceinline__ void fast2_post(Fast2Regs &r, Env2Regs &e, v2f s, v2f
   // (L, R) of the lane's two voices with the pan gains packed by channel: two packed multiplies by a broadcast
   // sample and one packed add give (out_l, out_r) ready for the tile store -- the same products and the same
   // single add per channel as l = s0*pl0 + s1*pl1, r = s0*pr0 + s1*pr1
+#ifdef SK_PROBE_TU
+  if (r.probe_any) {                                   // what the reference stores into its stem buffer: sample x pan (synth.c:603-608)
+    if (r.probe[0]) { *r.probe[0] = make_float2(s.x * r.pan_lr[0].x, s.x * r.pan_lr[0].y); r.probe[0] += r.probe_stride; }
+    if (r.probe[1]) { *r.probe[1] = make_float2(s.y * r.pan_lr[1].x, s.y * r.pan_lr[1].y); r.probe[1] += r.probe_stride; }
+  }
+#endif
   const v2f lr = r.pan_lr[0] * (v2f){so.x, so.x} + r.pan_lr[1] * (v2f){so.y, so.y};
   out_l = lr.x;
   out_r = lr.y;
@@ -812,7 +823,9 @@ template <bool TAB_LDS> struct Fast2Shape { static constexpr int NW = TAB_LDS ? 
 // GT: the in-place instantiation (LDS-table banks with envelopes; a.env_gain set): listed voices stay in their lanes, their
 // gains come from the rows sk_gain_kernel wrote just before on this stream.  A kernel of its own so that the steady
 // instantiation keeps its registers (it sits at 126 of 128).
-template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED, int FMP = 0, bool GT = false>
+// PROBE: the same kernel compiled in a translation unit with -DSK_PROBE_TU (fast2_post then also writes the probe rows of
+// skred_bank_set_probe): a template parameter only so that its instantiations are symbols of their own.
+template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool MIXED, int FMP = 0, bool GT = false, bool PROBE = false>
 __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) void sk_render_fast2_kernel(const sk_render_args_t a) {
   constexpr int NW = Fast2Shape<TAB_LDS>::NW;
   SK_FAST2_PROLOGUE()
@@ -838,6 +851,12 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
     const bool tame = fast2_load<FILTER, ENV, MIXED, FMP>(a, vidx, absent, lane, r, e, dead, silent, released, t_start, t_release, tame_m);
     const bool loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
     (void)loz;
+#ifdef SK_PROBE_TU
+    r.probe_stride = a.n_probe;
+    r.probe[0] = sk_probe_row(a, vidx[0], silent[0]);
+    r.probe[1] = sk_probe_row(a, vidx[1], silent[1]);
+    r.probe_any = __any(r.probe[0] != nullptr || r.probe[1] != nullptr);
+#endif
     bool wave_ok = true;
     r.lst[0] = r.lst[1] = false; r.gt = (v2f){0.0f, 0.0f};
     int grank[2] = {0, 0};            // GT: the lane's listed voices' numbers within the wave (ascending voice order)
@@ -904,9 +923,15 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
         for (int c = 0; c < 2; ++c)
           if (((c ? m1 : m0) >> lane) & 1) {   // (two numbers, not fast2_make_inert's twenty-five: the kernel sits at its register budget)
             r.pan_lr[c] = (v2f){0.0f, 0.0f};           // it walks its oscillator for nothing and adds exact zeros
+#ifdef SK_PROBE_TU
+            r.probe[c] = nullptr;                      // (its probe rows are the envelope kernel's)
+#endif
             r.k[c] = 0.0f;                             // its smoother counts as stalled (fast2_smoother_stalled is a wave vote)
             if (FMP == 2) r.am_on = r.pm_on = false;   // (and its pan stays at zero)
           }
+#ifdef SK_PROBE_TU
+        r.probe_any = __any(r.probe[0] != nullptr || r.probe[1] != nullptr);
+#endif
         wave_ok = __any((!dead[0] && !((m0 >> lane) & 1)) || (!dead[1] && !((m1 >> lane) & 1)));   // (nothing left to render: zeros to the chunk sums)
       }
       if (!GT && !__syncthreads_or(wave_ok ? 1 : 0)) {       // nothing of this pass is rendered here
@@ -946,7 +971,7 @@ __global__ __launch_bounds__(Fast2Shape<TAB_LDS>::NW * 64, SK_FAST2_MIN_WAVES) v
 #ifndef SK_ENV2_MIN_WAVES
 #define SK_ENV2_MIN_WAVES 3      /* the envelope machinery wants ~170 VGPRs: 3 waves per SIMD measured best (2: no spills, 4: 220 B of scratch) */
 #endif
-template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED, int FMP = 0>
+template <bool TAB_LDS, bool FILTER, int INTERP, bool MIXED, int FMP = 0, bool PROBE = false>
 __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_kernel(const sk_render_args_t a) {
   constexpr int NW = 4;              // always 512 voices per pass: its register budget allows 3 waves per SIMD anyway
   // the listed voices in ascending order (sk_collect_scan_kernel + sk_collect_expand_kernel, just before on this stream):
@@ -979,6 +1004,12 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
       }
       tame = fast2_load<FILTER, true, MIXED, FMP>(a, vidx, absent, lane, r, e, dead, silent, released, t_start, t_release, tame_m);
       loz = __all(r.lo.x == 0.0f && r.lo.y == 0.0f);
+#ifdef SK_PROBE_TU
+      r.probe_stride = a.n_probe;
+      r.probe[0] = sk_probe_row(a, vidx[0], silent[0] || absent[0]);
+      r.probe[1] = sk_probe_row(a, vidx[1], silent[1] || absent[1]);
+      r.probe_any = __any(r.probe[0] != nullptr || r.probe[1] != nullptr);
+#endif
     }
     (void)loz; (void)tame; (void)tame_m;
     bool all_const_from_here = false;
@@ -1108,7 +1139,7 @@ __global__ __launch_bounds__(SK_GROUP, SK_ENV2_MIN_WAVES) void sk_render_env2_ke
 
 // ---------------------------------------------------------------- the motion list: collect, classify (plain TU only)
 
-#if !defined(SK_FAST2_FMP_TU) && !defined(SK_FAST2_GT_TU)
+#if !defined(SK_FAST2_FMP_TU) && !defined(SK_FAST2_GT_TU) && !defined(SK_PROBE_TU)
 #define SK_FAST2_PLAIN_TU 1
 #endif
 #ifdef SK_FAST2_PLAIN_TU
@@ -1248,8 +1279,19 @@ extern "C" int sk_launch_classify(const sk_render_args_t *args, uint64_t *mask, 
 
 // sk_launch_render_fast2: the steady kernel (args->skip_env2: alone; otherwise the host has put sk_launch_render_env2 on
 // its second stream first -- skred_bank.c: render_block).  sk_launch_render_env2: collect + the envelope kernel.
-#if defined(SK_FAST2_GT_TU)
+#ifdef SK_PROBE_TU
+#define SK_PROBE_FLAG true
+#else
+#define SK_PROBE_FLAG false
+#endif
+#if defined(SK_FAST2_GT_TU) && defined(SK_PROBE_TU)
+#define SK_FAST2_LAUNCHER sk_launch_render_fast2gp
+#elif defined(SK_FAST2_GT_TU)
 #define SK_FAST2_LAUNCHER sk_launch_render_fast2g
+#elif defined(SK_PROBE_TU)
+#define SK_FAST2_LAUNCHER sk_launch_render_fast2p
+#define SK_ENV2_LAUNCHER sk_launch_env_fast2p
+extern "C" int sk_launch_render_fast2gp(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 #elif defined(SK_FAST2_FMP_TU) && SK_FAST2_FMP_TU == 2
 #define SK_FAST2_LAUNCHER sk_launch_render_fm2ap
 #define SK_ENV2_LAUNCHER sk_launch_env_fm2ap
@@ -1264,6 +1306,8 @@ extern "C" int sk_launch_render_fm2ap(const sk_render_args_t *args, int n_workgr
 extern "C" int sk_launch_env_fm2(const sk_render_args_t *args, hipStream_t stream);
 extern "C" int sk_launch_env_fm2ap(const sk_render_args_t *args, hipStream_t stream);
 extern "C" int sk_launch_render_fast2g(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+extern "C" int sk_launch_render_fast2p(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
+extern "C" int sk_launch_env_fast2p(const sk_render_args_t *args, hipStream_t stream);
 #endif
 
 static inline size_t sk_fast2_lds(const sk_render_args_t *args, int nw, bool gt = false) {
@@ -1321,10 +1365,14 @@ extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups,
                                  hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
 #ifdef SK_FAST2_PLAIN_TU
+  if (args->probe_out) return sk_launch_render_fast2p(args, n_workgroups, lds_bytes, stream);   // (the host has ruled FM pairs out)
   if ((args->fast_mode & SKM_FM_PAIR) && tab_lds)
     return (args->fast_mode & SKM_PAIR_AP) ? sk_launch_render_fm2ap(args, n_workgroups, lds_bytes, stream)
                                            : sk_launch_render_fm2(args, n_workgroups, lds_bytes, stream);
   if (args->env_gain) return sk_launch_render_fast2g(args, n_workgroups, lds_bytes, stream);
+#endif
+#if defined(SK_PROBE_TU) && !defined(SK_FAST2_GT_TU)
+  if (args->env_gain) return sk_launch_render_fast2gp(args, n_workgroups, lds_bytes, stream);
 #endif
   (void)lds_bytes;
   const int nw = tab_lds ? Fast2Shape<true>::NW : Fast2Shape<false>::NW;
@@ -1337,9 +1385,9 @@ extern "C" int SK_FAST2_LAUNCHER(const sk_render_args_t *args, int n_workgroups,
   const bool mixed = (args->fast_mode & SKM_MIXED) != 0;     // filter / envelope on some voices only: per-lane flags
   const int key = sk_fast2_key(args);
 #ifdef SK_FAST2_GT_TU
-#define SK_FAST2_LAUNCH(T, F, E, I, M, P) { hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, M, P, true>), grid, block, lds_fast2, stream, *args); }
+#define SK_FAST2_LAUNCH(T, F, E, I, M, P) { hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, M, P, true, SK_PROBE_FLAG>), grid, block, lds_fast2, stream, *args); }
 #else
-#define SK_FAST2_LAUNCH(T, F, E, I, M, P) { hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, M, P>), grid, block, lds_fast2, stream, *args); }
+#define SK_FAST2_LAUNCH(T, F, E, I, M, P) { hipLaunchKernelGGL((sk_render_fast2_kernel<T, F, E, I, M, P, false, SK_PROBE_FLAG>), grid, block, lds_fast2, stream, *args); }
 #endif
   SK_FAST2_SWITCH()
 #undef SK_FAST2_LAUNCH
@@ -1381,6 +1429,7 @@ extern "C" int sk_launch_collect(const sk_render_args_t *args, hipStream_t strea
 extern "C" int SK_ENV2_LAUNCHER(const sk_render_args_t *args, hipStream_t stream) {
   const bool tab_lds = args->lds_table_floats > 0;
 #ifdef SK_FAST2_PLAIN_TU
+  if (args->probe_out) return sk_launch_env_fast2p(args, stream);
   if ((args->fast_mode & SKM_FM_PAIR) != 0 && tab_lds)
     return (args->fast_mode & SKM_PAIR_AP) ? sk_launch_env_fm2ap(args, stream) : sk_launch_env_fm2(args, stream);
 #endif
@@ -1389,7 +1438,7 @@ extern "C" int SK_ENV2_LAUNCHER(const sk_render_args_t *args, hipStream_t stream
   const bool mixed = (args->fast_mode & SKM_MIXED) != 0;
   const int key = sk_fast2_key(args) | 2;                    // (the envelope kernel exists for enveloped banks only)
   (void)tab_lds;
-#define SK_FAST2_LAUNCH(T, F, E, I, M, P) { if (E) hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, M, P>), grid, block_env, lds_env2, stream, *args); }
+#define SK_FAST2_LAUNCH(T, F, E, I, M, P) { if (E) hipLaunchKernelGGL((sk_render_env2_kernel<T, F, I, M, P, SK_PROBE_FLAG>), grid, block_env, lds_env2, stream, *args); }
   SK_FAST2_SWITCH()
 #undef SK_FAST2_LAUNCH
   return (int)hipGetLastError();

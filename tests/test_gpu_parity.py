@@ -1158,13 +1158,24 @@ def test_headline_block_at_full_size(dev):
     for _ in range(11):
         db.render_mix(F, out.data_ptr(), 2, 0, 0)
     torch.cuda.synchronize()
+    # ... and, for 64 of its voices, EVERY FRAME of that block from inside the steady kernel's 8-frame tile blocks
+    # (skred_bank_set_probe; tests/test_probe.py has the other regimes): bit for bit against the oracle's stems of those voices
+    ids = np.unique(np.concatenate([[0, 63, 64, 127, n - 1], np.random.default_rng(1).choice(n, 59, replace=False)])).astype(np.int32)
+    sub, sub_g = bank.take(ids), g.copy()
+    cpuref.render(sub, sub_g, tables, 11 * F, 0)                        # (a clean bank: voices do not depend on their neighbours)
+    want = cpuref.render(sub, sub_g, tables, F, 0, want_stems=True)["stems"]
+    probe = torch.zeros(F * len(ids) * 2, device="cuda")
+    db.set_probe(ids, probe.data_ptr())
     db.render_mix(F, out.data_ptr(), 2, 0, 0)
     torch.cuda.synchronize()
     assert db.last_kernel() == 3
+    seen = probe.cpu().numpy().reshape(F, len(ids), 2)
+    db.set_probe([], 0)
     got = bank.copy()
     db.download(got)
     assert db.list_violations() == 0
     db.close()
+    assert gio.bits_equal(seen, want), "a probed voice-sample of the headline block differs from the oracle's stem"
     assert not got.rw_equal(ref_bank), got.rw_equal(ref_bank)
     assert rel_rms(out.cpu().numpy(), ref_mix) <= 1e-5
 

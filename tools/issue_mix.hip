@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void spin(int iters, float *out, unsigned long
   v2 pa = {a, b}, pb = {c, d};
   typedef float v4 __attribute__((ext_vector_type(4)));
   v4 q4 = {a, b, c, d};
+  long long w0 = threadIdx.x, w1 = threadIdx.x + 5;
   const float k = 1.0f;
   lds[threadIdx.x] = a; lds[threadIdx.x + 256] = b;
   __syncthreads();
@@ -50,11 +51,21 @@ __global__ __launch_bounds__(256) void spin(int iters, float *out, unsigned long
     if (MODE == 24) { REP16(asm volatile("v_ashrrev_i32 %0, 31, %0\n v_and_b32 %1, %1, %0\n v_ashrrev_i32 %0, 31, %0\n v_and_b32 %1, %1, %0" : "+v"(i0), "+v"(i1));) }
     if (MODE == 25) { REP16(asm volatile("ds_read_b128 %0, %1\n ds_read_b128 %0, %1 offset:1024\n ds_read_b128 %0, %1 offset:2048\n ds_read_b128 %0, %1 offset:3072\n s_waitcnt lgkmcnt(0)" : "=v"(q4) : "v"(addr * 4));) }
     if (MODE == 26) { REP16(asm volatile("ds_write_b128 %1, %0\n ds_write_b128 %1, %0 offset:1024\n ds_write_b128 %1, %0 offset:2048\n ds_write_b128 %1, %0 offset:3072" : : "v"(q4), "v"(addr * 4));) }
+    if (MODE == 27) { REP16(asm volatile("v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %3, %2, %1\n v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %3, %2, %1" : "+v"(w0), "+v"(w1) : "v"(i0), "v"(i1) : "vcc");) }
+    if (MODE == 28) { REP16(asm volatile("v_mul_lo_u32 %0, %0, %2\n v_mul_lo_u32 %1, %1, %2\n v_mul_lo_u32 %0, %0, %2\n v_mul_lo_u32 %1, %1, %2" : "+v"(i0), "+v"(i1) : "v"(i0));) }
+    if (MODE == 29) { REP16(asm volatile("v_mul_hi_i32 %0, %0, %2\n v_mul_hi_i32 %1, %1, %2\n v_mul_hi_i32 %0, %0, %2\n v_mul_hi_i32 %1, %1, %2" : "+v"(i0), "+v"(i1) : "v"(i0));) }
+    if (MODE == 30) { REP16(asm volatile("v_mul_i32_i24 %0, %0, %2\n v_mul_i32_i24 %1, %1, %2\n v_mul_i32_i24 %0, %0, %2\n v_mul_i32_i24 %1, %1, %2" : "+v"(i0), "+v"(i1) : "v"(i0));) }
+    if (MODE == 31) { REP16(asm volatile("v_mad_i32_i24 %0, %0, %2, %1\n v_mad_i32_i24 %1, %1, %2, %0\n v_mad_i32_i24 %0, %0, %2, %1\n v_mad_i32_i24 %1, %1, %2, %0" : "+v"(i0), "+v"(i1) : "v"(i0));) }
+    if (MODE == 32) { REP16(asm volatile("v_ashrrev_i64 %0, 30, %0\n v_ashrrev_i64 %1, 30, %1\n v_ashrrev_i64 %0, 30, %0\n v_ashrrev_i64 %1, 30, %1" : "+v"(w0), "+v"(w1));) }
+    if (MODE == 33) { REP16(asm volatile("v_cmp_lt_i64 vcc, %0, %1\n v_cmp_lt_i64 vcc, %1, %0\n v_cmp_lt_i64 vcc, %0, %1\n v_cmp_lt_i64 vcc, %1, %0" : : "v"(w0), "v"(w1) : "vcc");) }
+    if (MODE == 34) { REP16(asm volatile("v_mul_hi_i32_i24 %0, %0, %2\n v_mul_hi_i32_i24 %1, %1, %2\n v_mul_hi_i32_i24 %0, %0, %2\n v_mul_hi_i32_i24 %1, %1, %2" : "+v"(i0), "+v"(i1) : "v"(i0));) }
+    if (MODE == 35) { REP16(asm volatile("v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %2, vcc\n v_add_co_u32 %0, vcc, %0, %2\n v_addc_co_u32 %1, vcc, %1, %2, vcc" : "+v"(i0), "+v"(i1) : "v"(i0) : "vcc");) }
+    if (MODE == 36) { REP16(asm volatile("v_med3_i32 %0, %0, %2, %3\n v_med3_i32 %1, %1, %2, %3\n v_med3_i32 %0, %0, %2, %3\n v_med3_i32 %1, %1, %2, %3" : "+v"(i0), "+v"(i1) : "v"(i0), "v"(i1));) }
     if (MODE == 15) { REP16(asm volatile("v_sub_f32 %0, %0, %2\n v_sub_f32 %1, %1, %2\n v_sub_f32 %0, %0, %2\n v_sub_f32 %1, %1, %2" : "+v"(a), "+v"(b) : "v"(k));) }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
-  out[blockIdx.x * 256 + threadIdx.x] = q4.x + q4.w + a + b + c + d + pa.x + pa.y + pb.x + pb.y + (float)i0 + (float)i1 + lds[(threadIdx.x * 7) & 4095];
+  out[blockIdx.x * 256 + threadIdx.x] = (float)(w0 + w1) + q4.x + q4.w + a + b + c + d + pa.x + pa.y + pb.x + pb.y + (float)i0 + (float)i1 + lds[(threadIdx.x * 7) & 4095];
 }
 
 template <int MODE>
@@ -110,5 +121,15 @@ int main() {
   run<24>("v_ashrrev_i32 / v_and_b32", 4, out, clk, cus);
   run<25>("ds_read_b128 x4 + s_waitcnt (per read)", 4, out, clk, cus);
   run<26>("ds_write_b128", 4, out, clk, cus);
+  run<27>("v_mad_i64_i32", 4, out, clk, cus);
+  run<28>("v_mul_lo_u32", 4, out, clk, cus);
+  run<29>("v_mul_hi_i32", 4, out, clk, cus);
+  run<30>("v_mul_i32_i24", 4, out, clk, cus);
+  run<34>("v_mul_hi_i32_i24", 4, out, clk, cus);
+  run<31>("v_mad_i32_i24", 4, out, clk, cus);
+  run<32>("v_ashrrev_i64", 4, out, clk, cus);
+  run<33>("v_cmp_lt_i64 -> vcc", 4, out, clk, cus);
+  run<35>("v_add_co_u32 / v_addc_co_u32 (per instr)", 4, out, clk, cus);
+  run<36>("v_med3_i32", 4, out, clk, cus);
   return 0;
 }

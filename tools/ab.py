@@ -31,6 +31,17 @@ def timed(block, steps, reps=5):
 
 def open_bank(rec, n, a, bank=None):
     b, t, g = bank if bank else banks.RECIPES[rec](n)
+    if a.mixed:        # half of the voices filtered: SKM_MIXED, the extended instantiation of the family
+        import numpy as np
+        mode = np.asarray(b["voice_filter_mode"]).copy()
+        if mode.any(): mode[1::2] = 0
+        else:
+            mode[0::2] = 1
+            co = banks.biquad_coeffs(mode, np.full(b.n, 1000.0, np.float32), np.full(b.n, 1.0, np.float32), 48000)
+            flt = b["voice_filter"]
+            for k, v in co.items(): flt[k] = v
+            flt["last_freq"], flt["last_resonance"], flt["last_mode"] = 1000.0, 1.0, mode
+        b["voice_filter_mode"] = mode
     db = device.DeviceBank(b.n); db.set_tables(t); db.upload(b); db.set_globals(g); db.kernel_timing(0)
     if a.one_voice: db.fast2_min_voices(1 << 30)
     if a.split is not None: db.set_split(a.split)
@@ -140,6 +151,7 @@ def main():
     ap.add_argument("--one-voice", action="store_true")
     ap.add_argument("--voices", type=int, default=1 << 20)
     ap.add_argument("--notes", default="104,524,5242")
+    ap.add_argument("--mixed", action="store_true")
     ap.add_argument("--patches", default="3sk,37sk,7sk,1sk,18sk")
     a = ap.parse_args()
     {"steady": steady, "stamps": steady, "frames": frames, "live": live, "patch": patch}[a.scenario](a)

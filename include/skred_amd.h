@@ -326,11 +326,20 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
                               group per CU with filters; 2: whenever the bank qualifies; 3: even while envelopes may be moving (tests:
                               the kernel then renders the waves concerned on its general path).  Same per-voice results either way */,
        SKRED_OPT_SPLIT_PAIRS = 8 /* (tests) the split form's workgroup shape: 0 (default) four (oscillator wave, post wave)
-                                    pairs per workgroup; 2 / 4: forced (two: 256-thread workgroups whose four waves land on four SIMDs) */ };
+                                    pairs per workgroup; 2 / 4: forced (two: 256-thread workgroups whose four waves land on four SIMDs) */,
+       SKRED_OPT_PACK = 9 /* sparse banks -- most voices skipped by the reference's own rule, voice_amp == 0 (synth.c:537), as in every
+                             shipped patch (3 to 6 voices of 64 in use): the one-voice-per-lane kernel with the lanes PACKED, a
+                             wavefront holding the voices that can sound of several aligned 64-voice groups (and the modulators
+                             they name) instead of all 64 voices of one.  1 (default): where at least half of the wavefronts
+                             disappear (a quarter for banks the two-voices-per-lane kernel would take); 0: never; 2: whenever any
+                             disappear (tests).  Launches with the full stem buffer and banks on the generic / modulated / FM-pair
+                             kernels are never packed.  Per-voice state is bit-identical either way; the mix differs by
+                             summation order only */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */
 int  skred_bank_last_in_place(const skred_bank_t *bank);  /* 1: the latest block rendered its motion list in place (SKRED_OPT_IN_PLACE) */
+int  skred_bank_last_pack(const skred_bank_t *bank);      /* lanes per 64-voice group in the latest block (SKRED_OPT_PACK), 0: not packed */
 int  skred_bank_last_split(const skred_bank_t *bank);     /* 1: the latest block ran the split form of the one-voice kernel (SKRED_OPT_SPLIT) */
 
 /* Per-frame evidence from INSIDE the fast paths (tests).  A launch with the full stem buffer takes the kernels' frame-by-frame

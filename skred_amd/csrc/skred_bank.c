@@ -72,6 +72,15 @@ static int bank_build(skred_bank_t *b) {
   b->h_level = (int *)calloc((size_t)b->n_padded, sizeof(int));
   if (!b->h_class || !b->h_mod || !b->h_level) return fail(SKRED_E_NO_MEM, "calloc");
   memset(b->h_mod, -1, (size_t)b->n_padded * 4);
+  {
+    const size_t g64 = (size_t)b->n_padded / 64;
+    b->h_pack_mask = (uint64_t *)calloc(g64, sizeof(uint64_t));
+    b->h_pack_dirty = (uint8_t *)calloc(g64, 1);
+    if (!b->h_pack_mask || !b->h_pack_dirty) return fail(SKRED_E_NO_MEM, "calloc");
+    b->pack_hist[0] = (int)g64;
+    HIP_TRY(hipMalloc((void **)&b->d_pack_mask, g64 * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(b->d_pack_mask, 0, g64 * sizeof(uint64_t)));
+  }
   HIP_TRY(hipMalloc((void **)&b->d_level, (size_t)b->n_padded * sizeof(int)));
   HIP_TRY(hipMemset(b->d_level, 0, (size_t)b->n_padded * sizeof(int)));
   /* per 128-voice wave slice of the two-per-lane kernels: listed voices; one more slot: the one-voice family's ticket */
@@ -130,6 +139,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   b->fm2_min_voices = SK_FM2_MIN_VOICES;
   b->in_place_mode = 1;
   b->split_mode = 0;
+  b->pack_mode = 1;
   b->timing_every = 1;
   b->pp_parity = -1;
   b->n_padded = b->n_groups * SK_GROUP;
@@ -161,6 +171,8 @@ void skred_bank_destroy(skred_bank_t *b) {
   if (b->d_out) hipFree(b->d_out);
   if (b->d_stems) hipFree(b->d_stems);
   free(b->h_class); free(b->h_mod); free(b->h_level);
+  free(b->h_pack_mask); free(b->h_pack_dirty);
+  if (b->d_pack_mask) hipFree(b->d_pack_mask);
   sk_queue_free(b);
   sk_patterns_free(b);
   for (int i = 0; i < SK_UPD_RING; i++) {
@@ -254,7 +266,42 @@ int skred_bank_upload(skred_bank_t *b, const skred_voice_bank_t *h, int src_firs
   free(meta);
   sk_control_changed(b);
   b->mask_dirty = 1;                    /* the motion list is rebuilt from the planes before the next two-per-lane block */
+  b->pack_zero = 1;                     /* (uploaded state may hold a voice_sample on a voice that is skipped) */
   return SKRED_OK;
+}
+
+/* Packed lanes: the words of the groups whose voices changed, and the histogram that sizes the lane slots.  A group's word
+ * holds the voices that can sound (SKC_LIVE) and the voices those name as modulators (they keep a lane so that the exchange of
+ * the one-voice kernel finds them; at run time they are skipped like any dead voice).  Returns the most lanes a group needs. */
+static int pack_refresh(skred_bank_t *b) {
+  if (b->pack_any_dirty) {
+    const int g64 = b->n_padded / 64;
+    for (int g = 0; g < g64; g++) {
+      if (!b->h_pack_dirty[g]) continue;
+      b->h_pack_dirty[g] = 0;
+      uint64_t w = 0;
+      for (int l = 0; l < 64; l++) {
+        const int v = g * 64 + l;
+        if (!(b->h_class[v] & SKC_LIVE)) continue;
+        w |= (uint64_t)1 << l;
+        for (int k = 0; k < 4; k++) {
+          const int m = b->h_mod[(size_t)k * b->n_padded + v];
+          if (m >= 0) w |= (uint64_t)1 << m;
+        }
+      }
+      const uint64_t old = b->h_pack_mask[g];
+      if (w == old) continue;
+      b->pack_hist[__builtin_popcountll(old)]--;
+      b->pack_hist[__builtin_popcountll(w)]++;
+      b->h_pack_mask[g] = w;
+      b->pack_upload = 1;
+      if (old & ~w) b->pack_zero = 1;     /* a voice lost its lane: the reference would clear its voice_sample on the next frame */
+    }
+    b->pack_any_dirty = 0;
+  }
+  int most = 64;
+  while (most > 0 && b->pack_hist[most] == 0) most--;
+  return most;
 }
 
 /* Pick the kernel.  The fast kernel (skred_render_fast.hip: sk_render_fast_kernel) is valid when, over
@@ -309,6 +356,7 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
     case SKRED_OPT_KERNEL_TIMING: b->timing_every = value < 0 ? 0 : value; return SKRED_OK;
     case SKRED_OPT_SPLIT_PAIRS: b->split_pairs = (value == 2 || value == 4) ? value : 0; return SKRED_OK;
     case SKRED_OPT_SPLIT: b->split_mode = value < 0 ? 0 : value > 3 ? 3 : value; return SKRED_OK;
+    case SKRED_OPT_PACK: b->pack_mode = value < 0 ? 0 : value > 2 ? 2 : value; return SKRED_OK;
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
 }
@@ -331,6 +379,7 @@ int skred_bank_set_probe(skred_bank_t *b, const int32_t *voices, int n, float *d
 int skred_bank_last_kernel(const skred_bank_t *b) { return b ? b->last_kernel : -1; }
 int skred_bank_last_in_place(const skred_bank_t *b) { return b ? b->last_in_place : 0; }
 int skred_bank_last_split(const skred_bank_t *b) { return b ? b->last_split : 0; }
+int skred_bank_last_pack(const skred_bank_t *b) { return b ? b->last_pack : 0; }
 unsigned skred_bank_list_violations(const skred_bank_t *b) { return b ? b->violations_seen : 0u; }
 
 int skred_bank_download(skred_bank_t *b, skred_voice_bank_t *h, int src_first, int dst_first, int count) {
@@ -524,6 +573,27 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   if (interp == SKRED_INTERP_LINEAR && (a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_FM_PAIR) && !modulated && b->cnt_real > 0 &&
       b->cnt_guard == b->cnt_real && b->guard_epoch == b->tables_epoch)
     a.interp = 2;
+  /* Sparse banks (most voices skipped by the reference's own rule, synth.c:537 -- the shipped patches use 3 to 6 voices of 64):
+   * the one-voice family with the lanes PACKED -- a wave takes the voices that can sound of 64 / S aligned 64-voice groups, S = the
+   * most lanes any group needs, rounded up to a power of two (skred_device_layout.h: pack_mask).  The extended instantiation
+   * renders them (it holds every per-lane feature test), so the rule asks for at least half the waves to disappear; a bank the
+   * two-per-lane kernel would take, for a quarter of them. */
+  a.pack_shift = 6;
+  int pack_s = 0;
+  if (b->pack_mode && !modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_FM_PAIR) && !d_stems) {
+    const int most = pack_refresh(b);
+    int sh = 0;
+    while ((1 << sh) < most) sh++;
+    if ((1 << sh) <= ((a.fast_mode & SKM_TWO_PER_LANE) ? 16 : 32) || (b->pack_mode == 2 && sh < 6)) {
+      a.fast_mode &= ~SKM_TWO_PER_LANE;
+      a.pack_shift = sh;
+      a.pack_groups = b->n_padded / 64;
+      const int per_pass = 4 << (6 - sh);               /* groups per 4-wave workgroup pass */
+      a.pack_passes = (a.pack_groups + per_pass - 1) / per_pass;
+      a.pack_mask = b->d_pack_mask;
+      pack_s = 1 << sh;
+    }
+  }
   b->last_kernel = !(a.fast_mode & SKM_FAST) ? SKRED_KERNEL_GENERIC
                    : (a.fast_mode & SKM_TWO_PER_LANE) ? SKRED_KERNEL_FAST2 : SKRED_KERNEL_FAST;
   if (modulated) b->last_kernel = SKRED_KERNEL_MODULATED;
@@ -532,6 +602,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
     const int passes = a.lds_table_floats > 0 ? b->n_groups * 2 / SK_FAST2_NW_LDS : b->n_groups / 2;
     n_wg = passes < SK_MAX_WORKGROUPS ? passes : SK_MAX_WORKGROUPS;
   }
+  if (pack_s) n_wg = a.pack_passes < SK_MAX_WORKGROUPS ? a.pack_passes : SK_MAX_WORKGROUPS;
   /* two-per-lane banks with envelopes: the voices on the motion list are rendered by sk_render_env2_kernel BESIDE the steady
    * kernel, on the bank's second stream (its own rows, its own ticket; skred_kernel_common.hpp: sk_finish_env) */
   const int two_env = !modulated && (a.fast_mode & SKM_TWO_PER_LANE) && (a.fast_mode & SKM_ENV_ALL);
@@ -550,7 +621,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
    * 65 536 filtered voices on a 256-CU device).  (Decided here, ahead of the row layout: the two-pair form has twice the rows.) */
   int split = 0;
   if (!modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & (SKM_TWO_PER_LANE | SKM_STOPS | SKM_FM | SKM_MIXED)) && a.lds_table_floats > 0 &&
-      !d_stems && b->split_mode && (!one_env || b->env_quiet || b->split_mode == 3) && sk_split_lds_bytes(&a, 4) <= SK_SPLIT_MAX_LDS) {
+      !d_stems && !pack_s && b->split_mode && (!one_env || b->env_quiet || b->split_mode == 3) && sk_split_lds_bytes(&a, 4) <= SK_SPLIT_MAX_LDS) {
     const int per_cu = (int)(SK_SPLIT_MAX_LDS / sk_split_lds_bytes(&a, 4)) >= 2 ? 2 : 1;
     if (b->split_mode >= 2 || ((a.fast_mode & SKM_FILTER_ALL) && b->n_groups * 2 >= b->n_cus && b->n_groups <= b->n_cus)) split = 4;
     (void)per_cu;
@@ -674,6 +745,18 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   a.finish = 0; a.wg_shift = 0; b->gains_frames = 0;
 #endif
 
+  if (pack_s) {
+    /* the words the kernel reads, and voice_sample = 0 where the reference's skip rule would have left it and no lane does */
+    if (b->pack_upload) {
+      HIP_TRY(hipMemcpyAsync(b->d_pack_mask, b->h_pack_mask, (size_t)(b->n_padded / 64) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+      b->pack_upload = 0;
+    }
+    if (b->pack_zero) {
+      const hipError_t ez = (hipError_t)sk_launch_pack_zero(b->d_pack_mask, b->d_rw[SKS_FILT], b->n_padded, s);
+      if (ez != hipSuccess) return fail(SKRED_E_NO_DEVICE, "pack_zero launch -> %s", hipGetErrorString(ez));
+      b->pack_zero = 0;
+    }
+  }
   const int tslot = b->n_timed % SK_TIMING_RING;
   a.launch_ticket = ++b->launch_ticket;
   a.skip_env2 = two_env ? (uint32_t)b->list_empty : (uint32_t)(one_env && b->env_quiet);
@@ -716,6 +799,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
   b->last_family = b->last_kernel;
   b->last_in_place = inplace;
   b->last_split = split;
+  b->last_pack = pack_s;
 
   /* advance the timeline exactly as synth.c:521,525 do: one count and one LCG draw per frame */
   b->g.synth_sample_count += (uint64_t)num_frames;

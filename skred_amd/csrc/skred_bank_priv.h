@@ -86,6 +86,16 @@ struct skred_bank {
   int split_mode;             /* SKRED_OPT_SPLIT: 0 never, 1 where it is the faster form (default), 2 whenever the bank qualifies */
   int split_pairs;            /* SKRED_OPT_SPLIT_PAIRS: 0 the library's choice, 2 / 4 forced (tests) */
   int last_split;             /* the latest block ran sk_render_split_kernel */
+  /* packed lanes of sparse banks (skred_device_layout.h: pack_mask; skred_bank.c: pack_refresh, render_block) */
+  int pack_mode;              /* SKRED_OPT_PACK: 0 never, 1 where it pays (default) */
+  uint64_t *h_pack_mask;      /* [n_padded / 64] per aligned 64-voice group: voices that can sound, and the modulators they name */
+  uint64_t *d_pack_mask;
+  uint8_t *h_pack_dirty;      /* [n_padded / 64] a voice of the group changed class or modulator: its word is recomputed */
+  int pack_any_dirty;
+  int pack_hist[65];          /* groups per number of set bits in their word (the highest non-empty bin sizes the lane slots) */
+  int pack_upload;            /* the device copy of the words is stale */
+  int pack_zero;              /* a voice without a lane may hold a voice_sample the reference's skip rule would have cleared */
+  int last_pack;              /* lanes per 64-voice group in the latest block (0: not packed) */
   int in_place_mode;          /* SKRED_OPT_IN_PLACE: 0 never, 1 where it is the faster path (default), 2 wherever the rows provably suffice */
   uint32_t violations_seen;   /* ... as last read back */
   hipStream_t side;           /* the envelope kernel's stream, beside the caller's */
@@ -150,6 +160,8 @@ struct skred_bank {
 #define SKC_PAIR_AP 512u /* a pair-shaped carrier whose amplitude or pan is modulated (by the voice after it or by itself) */
 #define SKC_GUARD 64u   /* loops over its whole table with a guard sample behind it (SKF_GUARD): when every real voice does, the
                            linear lookup runs the instantiations without the fold test */
+#define SKC_LIVE 1024u  /* can sound as far as its parameters say: a usable table and voice_amp != 0 (synth.c:537; a voice that has
+                           finished is a matter of state, not of class) */
 #define SKC_ESCAPES 128u /* names a modulator outside its aligned 64-voice group: the bank cannot be rendered until that is fixed */
 
 

@@ -86,6 +86,7 @@ int sk_pack_voice(const skred_bank_t *b, const skred_voice_bank_t *h, int v, int
   {
     uint16_t c = 0;
     if (usable || noise) c |= SKC_REAL;
+    if ((usable || noise) && !(h->voice_amp[v] == 0.0f)) c |= SKC_LIVE;
     if (flags & SKF_GUARD) c |= SKC_GUARD;
     if (h->voice_filter_mode[v]) c |= SKC_FILTER;
     if (h->voice_use_amp_envelope[v]) c |= SKC_ENV;
@@ -171,10 +172,11 @@ void sk_apply_meta(skred_bank_t *b, int dst, const sk_voice_meta_t *m, int param
     b->cnt_escapes += ((now & SKC_ESCAPES) != 0) - ((old & SKC_ESCAPES) != 0);
     b->h_class[dst] = now;
     b->class_dirty = 1;
+    if ((old ^ now) & SKC_LIVE) { b->h_pack_dirty[dst >> 6] = 1; b->pack_any_dirty = 1; }
   }
   for (int k = 0; k < 4; k++) {
     int8_t *slot = &b->h_mod[(size_t)k * b->n_padded + dst];
-    if (*slot != m->mod_lane[k]) { *slot = m->mod_lane[k]; b->mod_dirty = 1; b->class_dirty = 1; }
+    if (*slot != m->mod_lane[k]) { *slot = m->mod_lane[k]; b->mod_dirty = 1; b->class_dirty = 1; b->h_pack_dirty[dst >> 6] = 1; b->pack_any_dirty = 1; }
   }
   if ((b->features | m->features) != b->features) { b->features |= m->features; b->class_dirty = 1; b->mod_dirty = 1; }
 }
@@ -371,6 +373,7 @@ static int apply_batch(skred_bank_t *b, const sk_update_t *rec, const sk_voice_m
     start = end;
   }
   if (meta && (dirty & SKRED_DIRTY_PARAMS)) for (int i = 0; i < n; i++) sk_apply_meta(b, rec[i].voice, &meta[i], 1);
+  if (dirty & SKRED_DIRTY_SAMPLE) b->pack_zero = 1;    /* (a voice_sample written onto a skipped voice: cleared again before a packed block) */
   b->touched_total += (uint64_t)n;
   sk_control_changed(b);
   return SKRED_OK;

@@ -213,6 +213,16 @@ typedef struct {
   const int32_t *probe_ids; /* [n_probe] voice numbers */
   float *probe_out;         /* [num_frames][n_probe][2], zeroed by the host before the launch (a skipped / muted voice writes nothing) */
   int32_t n_probe;
+  /* ---- packed lanes (sparse banks; skred_bank.c: render_block decides): most voices of the bank are skipped by the reference's own
+   * rule (voice_amp == 0, synth.c:537) for as long as nobody changes them, so a wave of the one-voice family takes the voices
+   * that CAN sound of 2^(6 - pack_shift) aligned 64-voice groups instead of all 64 voices of one -- group j of the wave owns lanes
+   * [j << pack_shift, (j + 1) << pack_shift), the k-th set bit of pack_mask[group] is the voice in its k-th lane.  A bit is set for
+   * every voice that can sound and for every voice a voice that can sound names as a modulator (those keep a lane so that the
+   * exchange finds them: skipped at run time like any dead voice).  pack_shift == 6: off. ---- */
+  const uint64_t *pack_mask; /* [pack_groups] */
+  int32_t pack_shift;        /* log2 of the lanes per group */
+  int32_t pack_groups;       /* aligned 64-voice groups of the bank */
+  int32_t pack_passes;       /* workgroup passes: ceil(pack_groups / (4 << (6 - pack_shift))) */
 } sk_render_args_t;
 #define SK_PROBE_MAX 64
 

@@ -124,6 +124,30 @@ __device__ __forceinline__ bool sk_arrive_last(uint32_t *ticket, uint32_t expect
   return *flag_lds != 0;
 }
 
+// Packed lanes (sk_render_args_t: pack_mask): the voice of `lane` of packed wave `wave_g`, -1 when the lane is empty.
+// `mask`: the lane's group word; `pos`: the voice's lane in its own 64-voice group (what the MODI plane's modulator lanes
+// are numbered in).  Once per pass and lane.
+__device__ __forceinline__ int sk_packed_voice(const sk_render_args_t &a, int wave_g, int lane, uint64_t &mask, int &pos) {
+  const int sh = a.pack_shift;
+  const int grp = (wave_g << (6 - sh)) + (lane >> sh);
+  const int rank = lane & ((1 << sh) - 1);
+  mask = grp < a.pack_groups ? a.pack_mask[grp] : 0ull;
+  if (rank == 0 && __popcll(mask) > (1 << sh)) __hip_atomic_fetch_add((sk_gu32 *)a.violations, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the host sized the slots from these very words)
+  pos = -1;
+  if (rank < __popcll(mask)) {
+    uint64_t t = mask;
+    for (int i = 0; i < rank; ++i) t &= t - 1;
+    pos = __builtin_ctzll(t);
+  }
+  return pos < 0 ? -1 : grp * 64 + pos;
+}
+// a modulator's lane in its 64-voice group -> its lane in the packed wave (the host gave every modulator of a voice that can
+// sound a lane: a missing one is counted and reads the carrier itself)
+__device__ __forceinline__ int sk_packed_lane(const sk_render_args_t &a, uint64_t mask, int lane, int mod_lane) {
+  if (!((mask >> mod_lane) & 1)) { __hip_atomic_fetch_add((sk_gu32 *)a.violations, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return lane; }
+  return (lane & ~((1 << a.pack_shift) - 1)) + __popcll(mask & (((uint64_t)1 << mod_lane) - 1));
+}
+
 // One float of the workgroup's own row, at the end of a chunk: overwritten in the workgroup's first pass over the bank,
 // accumulated in later ones (plain accesses: this CU's own lines); in the pass that completes the row (`publish`) the
 // value leaves as a write-through store -- that is the copy another workgroup may read (sk_finish_block).

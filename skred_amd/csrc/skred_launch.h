@@ -8,7 +8,7 @@
  *   skred_render_fast2.hip    sk_launch_render_fast2, sk_launch_env_fast2, sk_env2_grid, sk_launch_classify
  *   skred_gain_kernels.hip    sk_launch_gain
  *   skred_mix_kernels.hip     sk_launch_master, sk_launch_master_apply
- *   skred_update_kernels.hip  sk_launch_update
+ *   skred_update_kernels.hip  sk_launch_update, sk_launch_stamp, sk_launch_pack_zero
  *   skred_rec_kernels.hip     sk_launch_rec_minmax, sk_rec_partial_floats, sk_launch_rec_convert
  *
  * Every launcher returns the hipError_t of the launch as an int.
@@ -69,6 +69,9 @@ int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t *const ro[S
 /* note-on / note-off stamps only: a list of voice ids */
 int sk_launch_stamp(const int32_t *d_ids, int n, uint32_t dirty, sk_plane_t *const ro[SKP_COUNT], sk_plane_t *const rw[SKS_COUNT],
                     uint64_t now, uint64_t *mask, uint32_t *cnt, uint32_t *done, uint32_t seq, hipStream_t stream);
+
+/* packed lanes: voice_sample = 0 for every voice without a bit in d_mask (one bit per voice of the padded bank) */
+int sk_launch_pack_zero(const uint64_t *d_mask, sk_plane_t *filt, int n_voices_padded, hipStream_t stream);
 
 /* stem recorder (skred_recorder.c): min/max partials of rec[n_floats]; selected voices -> int16 pairs */
 int sk_rec_partial_floats(void);

@@ -59,7 +59,11 @@ __device__ __forceinline__ float fast_fetch_win(const FastRegs &r, const FastWin
                                                 const char *__restrict__ glb_tab, float p) {
   const int idx = (int)p;
   const int rel = w.direct ? 0 : idx - w.base;
-  const float *src = win + rel * 64 + lane;
+  // (an LDS-address-space pointer: left generic, the compiler merges this read and the direct gather below into ONE load
+  // through a selected pointer -- a FLAT load -- and with packed lanes hipcc 7.2 then dies in instruction selection on one
+  // instantiation: "Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base")
+  typedef __attribute__((address_space(3))) const float lds_cf;
+  const lds_cf *src = (const lds_cf *)(win + rel * 64 + lane);
   const float ta = src[0];
   float s = ta;
   if (INTERP != 0) {
@@ -439,9 +443,17 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
   bool first_pass = true;
   const bool stems_on = a.stems != nullptr;          // (launch-uniform: one scalar branch per frame)
 
-  for (int g = bid; g < a.n_groups; g += a.n_rows) {
-    const int v = g * SK_GROUP + tid;
-    const bool publish = a.finish && g + a.n_rows >= a.n_groups;   // the pass that completes this workgroup's row
+  // packed lanes (sparse banks, extended instantiations only: sk_render_args_t, pack_mask): a wave holds the voices that can
+  // sound of several 64-voice groups (an empty lane -- `absent` -- is a dead voice that loads voice 0 and stores nothing)
+  const bool packed = STOPS && a.pack_shift < 6;
+  const int n_pass = packed ? a.pack_passes : a.n_groups;
+  for (int g = bid; g < n_pass; g += a.n_rows) {
+    int v = g * SK_GROUP + tid;
+    uint64_t pmask = 0;                                // (packed) the lane's group word, and the voice's lane in its own group
+    int ppos = lane;
+    bool absent = false;
+    if (packed) { v = sk_packed_voice(a, g * (SK_GROUP / 64) + wave, lane, pmask, ppos); absent = v < 0; if (absent) { v = 0; ppos = 0; } }
+    const bool publish = a.finish && g + a.n_rows >= n_pass;   // the pass that completes this workgroup's row
     FastRegs r;
     bool dead, silent;            // dead: skipped by synth.c:531-542; silent: dead or muted
     bool muted = false;           // voice_disconnect
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         t_release = ((uint64_t)es.w << 32) | es.z;
         released = t_release != 0;                   // synth.c:417
       }
-      dead = (r.rw & SKR_FINISHED) || r.amp == 0.0f || (flags & SKF_INERT);
+      dead = absent || (r.rw & SKR_FINISHED) || r.amp == 0.0f || (flags & SKF_INERT);
       silent = dead || (flags & SKF_MUTED);
       r.stop = STOPS && (flags & SKF_ONE_SHOT) && !(flags & SKF_LOOPING);
       r.fin = false;
@@ -512,8 +524,14 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       if (STOPS && (a.fast_mode & SKM_FM)) {
         const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
         const uint4 mf = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODF][v]);
-        const int fm_lane = (int)mi.x;
-        const int am_lane = (int)mi.y, pm_lane = (int)mi.z;
+        int fm_lane = (int)mi.x;
+        int am_lane = (int)mi.y, pm_lane = (int)mi.z;
+        if (absent) fm_lane = am_lane = pm_lane = -1;
+        if (packed) {                                      // the planes number modulators by their lane in the 64-voice group
+          if (fm_lane >= 0) fm_lane = sk_packed_lane(a, pmask, lane, fm_lane);
+          if (am_lane >= 0) am_lane = am_lane == ppos ? lane : sk_packed_lane(a, pmask, lane, am_lane);
+          if (pm_lane >= 0) pm_lane = pm_lane == ppos ? lane : sk_packed_lane(a, pmask, lane, pm_lane);
+        }
         if (am_lane >= 0) { r.am_addr = am_lane == lane ? -2 : am_lane << 2; r.am_depth = __uint_as_float(mf.z); }
         if (pm_lane >= 0) { r.pm_addr = pm_lane == lane ? -2 : pm_lane << 2; r.pm_depth = __uint_as_float(mf.w); }
         misc_xy = make_uint2(s2.x, s2.y);
@@ -754,7 +772,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     // only, and every control action sends the host back to RAMPK by itself)
     if (RAMPK && moved && lane == 0) sk_note_moved(a, bid);
     // store the recurrences; skipped voices keep their state and get voice_sample = 0 (synth.c:532,538)
-    if (!dead) {
+    if (absent) {
+    } else if (!dead) {
       uint4 s0, s1;
       if (STOPS && !r.filt) { r.x1 = r.ox1; r.x2 = r.ox2; r.y1 = r.oy1; r.y2 = r.oy2; }
       s0.x = __float_as_uint(STOPS && r.noise ? r.ophase : r.phase); s0.y = __float_as_uint(r.sgain);
@@ -766,7 +785,8 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     } else if (!sample_final) {
       reinterpret_cast<uint32_t *>(&a.rw[SKS_FILT][v])[2] = 0u;
     }
-    if (STOPS && !dead && r.hold_max)   // sample & hold state (and the pan next to it)
+    if (absent) {
+    } else if (STOPS && !dead && r.hold_max)   // sample & hold state (and the pan next to it)
       *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = make_uint4(__float_as_uint(r.hold), (uint32_t)r.hold_count, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r));
     else if (STOPS && r.pan_dirty)      // pan modulation rewrote voice_pan_left / _right (synth.c:600-601)
       *reinterpret_cast<uint4 *>(&a.rw[SKS_MISC][v]) = make_uint4(misc_xy.x, misc_xy.y, __float_as_uint(r.pan_l), __float_as_uint(r.pan_r));
@@ -797,7 +817,7 @@ extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, 
   lds_bytes += (size_t)4 * (8 * SK_XT) * sizeof(float);
   if (args->lds_table_floats == 0) lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);
   dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block(SK_GROUP);
-  const int key = ((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
+  const int key = (((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) || args->pack_shift < 6) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp != 0 ? 1 : 0);
   const bool rampk = !args->skip_env2;   /* envelopes may be moving (skip_env2: a launch has reported that none did) */
   const bool guard = args->interp == 2;  /* linear lookup, every live voice on a guarded whole-table loop (SKF_GUARD; the host counts) */
@@ -808,6 +828,10 @@ extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, 
   case K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), false) else SK_FAST_LAUNCH_(T, F, E, I, false) break;      \
   case 16 + K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), true) else SK_FAST_LAUNCH_(T, F, E, I, true) break;
   switch (key) {
+#ifdef SK_FAST_ONE_CASE   /* (compile-time experiments: one instantiation pair) */
+#define SK_FAST_CASE_X(...) SK_FAST_CASE(__VA_ARGS__)
+    SK_FAST_CASE_X(SK_FAST_ONE_CASE)
+#else
     SK_FAST_CASE(0, false, false, false, 0) SK_FAST_CASE(1, false, false, false, 1)
     SK_FAST_CASE(2, false, false, true, 0)  SK_FAST_CASE(3, false, false, true, 1)
     SK_FAST_CASE(4, false, true, false, 0)  SK_FAST_CASE(5, false, true, false, 1)
@@ -816,6 +840,7 @@ extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, 
     SK_FAST_CASE(10, true, false, true, 0)  SK_FAST_CASE(11, true, false, true, 1)
     SK_FAST_CASE(12, true, true, false, 0)  SK_FAST_CASE(13, true, true, false, 1)
     SK_FAST_CASE(14, true, true, true, 0)   SK_FAST_CASE(15, true, true, true, 1)
+#endif
   }
 #undef SK_FAST_CASE
 #undef SK_FAST_LAUNCH_

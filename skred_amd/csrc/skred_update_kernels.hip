@@ -123,3 +123,19 @@ extern "C" int sk_launch_update(const sk_update_t *d_updates, int n, sk_plane_t 
   hipLaunchKernelGGL(sk_update_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_updates, n, p, now, mask, cnt, done, seq);
   return (int)hipGetLastError();
 }
+
+// Packed lanes (skred_device_layout.h: pack_mask): the reference sets voice_sample = 0 on every frame for a voice it skips
+// (synth.c:531-542).  A skipped voice with a lane gets that from the render kernel; one WITHOUT a lane -- it cannot sound and no
+// voice that can sound reads it -- gets it here, once, whenever the words changed or state was written from outside.
+__global__ __launch_bounds__(256) void sk_pack_zero_kernel(const uint64_t *__restrict__ mask, sk_plane_t *filt, int n_voices_padded) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= n_voices_padded) return;
+  if ((mask[v >> 6] >> (v & 63)) & 1) return;
+  uint32_t *smp = reinterpret_cast<uint32_t *>(&filt[v]) + 2;
+  if (*smp != 0u) *smp = 0u;
+}
+
+extern "C" int sk_launch_pack_zero(const uint64_t *d_mask, sk_plane_t *filt, int n_voices_padded, hipStream_t stream) {
+  hipLaunchKernelGGL(sk_pack_zero_kernel, dim3((unsigned)((n_voices_padded + 255) / 256)), dim3(256), 0, stream, d_mask, filt, n_voices_padded);
+  return (int)hipGetLastError();
+}

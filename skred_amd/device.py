@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "skred_bank_set_globals", "skred_bank_get_globals",
     "skred_bank_render", "skred_bank_master", "skred_bank_render_mix", "skred_bank_render_host",
     "skred_bank_last_render_ms", "skred_bank_timing_reset", "skred_bank_timing_summary",
-    "skred_bank_set_option", "skred_bank_last_kernel", "skred_bank_last_in_place", "skred_bank_last_split", "skred_bank_list_violations", "skred_bank_set_probe",
+    "skred_bank_set_option", "skred_bank_last_kernel", "skred_bank_last_in_place", "skred_bank_last_split", "skred_bank_last_pack", "skred_bank_list_violations", "skred_bank_set_probe",
     "skred_bank_update", "skred_bank_defer", "skred_bank_run_queue", "skred_bank_queue_pending",
     "skred_shard_partition", "skred_shard_cut_ok", "skred_shard_create", "skred_shard_create_custom", "skred_shard_destroy",
     "skred_shard_bank", "skred_shard_range", "skred_shard_upload", "skred_shard_set_ops", "skred_shard_rccl_unique_id",
@@ -87,6 +87,7 @@ def load() -> C.CDLL:
     L.skred_bank_last_kernel.argtypes = [vp]
     L.skred_bank_last_in_place.argtypes = [vp]
     L.skred_bank_last_split.argtypes = [vp]
+    L.skred_bank_last_pack.argtypes = [vp]
     L.skred_bank_set_probe.argtypes = [vp, vp, i32, vp]
     L.skred_bank_list_violations.argtypes = [vp]
     L.skred_bank_list_violations.restype = C.c_uint
@@ -269,6 +270,14 @@ class DeviceBank:
         inside the kernels' fast paths; an empty list ends it."""
         v = np.ascontiguousarray(voices, np.int32)
         _check(self.L.skred_bank_set_probe(self.h, v.ctypes.data if len(v) else None, len(v), d_probe or None), "skred_bank_set_probe")
+
+    def set_pack(self, mode: int) -> None:
+        """SKRED_OPT_PACK: 1 sparse banks rendered with packed lanes where it pays (default), 0 never, 2 whenever a wavefront disappears."""
+        _check(self.L.skred_bank_set_option(self.h, 9, int(mode)), "skred_bank_set_option")
+
+    def last_pack(self) -> int:
+        """Lanes per 64-voice group in the latest block, 0: not packed."""
+        return int(self.L.skred_bank_last_pack(self.h))
 
     def set_split_pairs(self, pairs: int) -> None:
         """SKRED_OPT_SPLIT_PAIRS (tests): 0 the library's choice, 2 / 4 pairs per workgroup forced."""

@@ -31,6 +31,11 @@ def timed(block, steps, reps=5):
 
 def open_bank(rec, n, a, bank=None):
     b, t, g = bank if bank else banks.RECIPES[rec](n)
+    if a.sparse > 0:   # this fraction of the voices cannot sound (voice_amp 0): SKRED_OPT_PACK's case
+        import numpy as np
+        amp = np.asarray(b["voice_amp"]).copy()
+        amp[np.random.default_rng(1).random(b.n) < a.sparse] = 0.0
+        b["voice_amp"] = amp
     if a.mixed:        # half of the voices filtered: SKM_MIXED, the extended instantiation of the family
         import numpy as np
         mode = np.asarray(b["voice_filter_mode"]).copy()
@@ -46,6 +51,7 @@ def open_bank(rec, n, a, bank=None):
     if a.one_voice: db.fast2_min_voices(1 << 30)
     if a.split is not None: db.set_split(a.split)
     if a.in_place is not None: db.in_place(a.in_place)
+    if a.pack is not None: db.set_pack(a.pack)
     return db, b
 
 
@@ -65,7 +71,7 @@ def steady(a):
         db, _ = open_bank(rec, n, a)
         settle(db, out, a.f, a.interp)
         best, med = timed(lambda: db.render_mix(a.f, out.data_ptr(), 2, 0, a.interp), a.steps)
-        print(f"steady {rec} {n:8d} voices F={a.f} interp={a.interp} kernel={db.last_kernel()} split={int(db.last_split())}: {best:8.2f} us (med {med:8.2f})  lib={LIB}", flush=True)
+        print(f"steady {rec} {n:8d} voices F={a.f} interp={a.interp} kernel={db.last_kernel()} split={int(db.last_split())} pack={db.last_pack()}: {best:8.2f} us (med {med:8.2f})  lib={LIB}", flush=True)
         if a.scenario == "stamps" and db.last_split():
             import ctypes as C
             n_wg = (n + 1023) // 1024 * 4
@@ -133,7 +139,7 @@ def patch(a):
         out = torch.zeros(512, 2, device="cuda")
         settle(db, out, 512, 0, blocks=12)
         best, med = timed(lambda: db.render_mix(512, out.data_ptr(), 2, 0, 0), 40, 3)
-        print(f"patch {p:5s} tiled over {a.voices} voices: {best / 1e3:7.3f} ms per block (med {med / 1e3:7.3f}) kernel={db.last_kernel()}  lib={LIB}", flush=True)
+        print(f"patch {p:5s} tiled over {a.voices} voices: {best / 1e3:7.3f} ms per block (med {med / 1e3:7.3f}) kernel={db.last_kernel()} pack={db.last_pack()}  lib={LIB}", flush=True)
         db.close()
 
 
@@ -152,6 +158,8 @@ def main():
     ap.add_argument("--voices", type=int, default=1 << 20)
     ap.add_argument("--notes", default="104,524,5242")
     ap.add_argument("--mixed", action="store_true")
+    ap.add_argument("--sparse", type=float, default=0.0)
+    ap.add_argument("--pack", type=int, default=None)
     ap.add_argument("--patches", default="3sk,37sk,7sk,1sk,18sk")
     a = ap.parse_args()
     {"steady": steady, "stamps": steady, "frames": frames, "live": live, "patch": patch}[a.scenario](a)

@@ -330,9 +330,9 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
        SKRED_OPT_PACK = 9 /* sparse banks -- most voices skipped by the reference's own rule, voice_amp == 0 (synth.c:537), as in every
                              shipped patch (3 to 6 voices of 64 in use): the one-voice-per-lane kernel with the lanes PACKED, a
                              wavefront holding the voices that can sound of several aligned 64-voice groups (and the modulators
-                             they name) instead of all 64 voices of one.  1 (default): where at least half of the wavefronts
-                             disappear (a quarter for banks the two-voices-per-lane kernel would take); 0: never; 2: whenever any
-                             disappear (tests).  Launches with the full stem buffer and banks on the generic / modulated / FM-pair
+                             they name) instead of all 64 voices of one.  1 (default): on banks of at least 768 voices per CU, where at least half of
+                             the wavefronts disappear (three quarters for banks the two-voices-per-lane kernel would take); 0: never;
+                             2: whenever any disappear (tests, small banks).  The modulated kernel packs the same way.  Launches with the full stem buffer and banks on the generic / modulated / FM-pair
                              kernels are never packed.  Per-voice state is bit-identical either way; the mix differs by
                              summation order only */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };

@@ -580,12 +580,16 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
    * two-per-lane kernel would take, for a quarter of them. */
   a.pack_shift = 6;
   int pack_s = 0;
-  if (b->pack_mode && !modulated && (a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_FM_PAIR) && !d_stems) {
+  if (b->pack_mode && (modulated || ((a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_FM_PAIR))) && !d_stems) {   /* (the modulated kernel packs the same way) */
     const int most = pack_refresh(b);
     int sh = 0;
     while ((1 << sh) < most) sh++;
-    if ((1 << sh) <= ((a.fast_mode & SKM_TWO_PER_LANE) ? 16 : 32) || (b->pack_mode == 2 && sh < 6)) {
-      a.fast_mode &= ~SKM_TWO_PER_LANE;
+    /* ... on a bank that fills the machine several times over: up to two 256-voice passes per CU the block's time is one pass's
+     * latency whatever the waves hold, and the extended instantiation's is the longer one (131 072 voices, 5 % in use: 54 us
+     * packed, 50 not; 2^20 voices: 117 against 228) */
+    const int big = b->n_groups >= 3 * b->n_cus;        /* (196 608 voices: 55 us packed, 63 not; 262 144: 55 against 79) */
+    if ((big && (1 << sh) <= ((!modulated && (a.fast_mode & SKM_TWO_PER_LANE)) ? 16 : 32)) || (b->pack_mode == 2 && sh < 6)) {
+      if (!modulated) a.fast_mode &= ~SKM_TWO_PER_LANE;
       a.pack_shift = sh;
       a.pack_groups = b->n_padded / 64;
       const int per_pass = 4 << (6 - sh);               /* groups per 4-wave workgroup pass */

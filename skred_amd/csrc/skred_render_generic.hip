@@ -293,13 +293,22 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render
     __syncthreads();
   }
   const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;
-  const int n_pass = a.n_groups;                       // passes of 256 voices = 4 groups of 64
+  // packed lanes (sparse banks; sk_render_args_t: pack_mask): a wave holds the voices that can sound, and the modulators they
+  // name, of several 64-voice groups -- the exchange arrays are indexed by wave lane either way, a modulator's lane is translated
+  // once per pass, and lanes keep the order of their voices, so "below the carrier" (same frame) stays "a lower lane"
+  const bool packed = !STEMS && a.pack_shift < 6;
+  const int n_pass = packed ? a.pack_passes : a.n_groups;   // passes of 256 voices = 4 groups of 64 (packed: 4 waves of several groups)
   bool first_pass = true;
   for (int g = bid; g < n_pass; g += a.n_rows) {
-    const int v = g * SK_GROUP + tid;
+    int v = g * SK_GROUP + tid;
+    uint64_t pmask = 0;
+    int ppos = lane;
+    bool absent = false;
+    if (packed) { v = sk_packed_voice(a, g * (SK_GROUP / 64) + wave, lane, pmask, ppos); absent = v < 0; if (absent) v = 0; }
     const bool publish = a.finish && g + a.n_rows >= n_pass;       // the pass that completes this workgroup's row
     VoiceRegs r;
     load_voice(a, v, r);
+    if (absent) r.flags |= SKF_INERT;                          // an empty lane: skipped on every frame, nothing stored
     ModRegs m;
     {
       const uint4 mi = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODI][v]);
@@ -307,6 +316,12 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render
       const uint4 mx = *reinterpret_cast<const uint4 *>(&a.ro[SKP_MODX][v]);
       const uint4 fl = *reinterpret_cast<const uint4 *>(&a.ro[SKP_FILT][v]);
       m.fm = (int)mi.x; m.am = (int)mi.y; m.pm = (int)mi.z; m.cz = (int)mi.w;
+      if (packed && !absent) {                                 // (the planes number modulators by their lane in the 64-voice group)
+        if (m.fm >= 0) m.fm = sk_packed_lane(a, pmask, lane, m.fm);
+        if (m.am >= 0) m.am = sk_packed_lane(a, pmask, lane, m.am);
+        if (m.pm >= 0) m.pm = sk_packed_lane(a, pmask, lane, m.pm);
+        if (m.cz >= 0) m.cz = sk_packed_lane(a, pmask, lane, m.cz);
+      }
       m.fm_depth = __uint_as_float(mf.x); m.freq_scale = __uint_as_float(mf.y);
       m.am_depth = __uint_as_float(mf.z); m.pm_depth = __uint_as_float(mf.w);
       m.cz_depth = __uint_as_float(mx.x); m.cz_mode = (int)mx.y;
@@ -358,7 +373,7 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render
       }
       __syncthreads();
     }
-    store_voice(a, v, r);
+    if (!absent) store_voice(a, v, r);
     first_pass = false;
   }
   if (a.finish) sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds), true);

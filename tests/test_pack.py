@@ -133,6 +133,24 @@ def expected_slots(bank, limit=32):
     return s if s <= limit else 0
 
 
+def expected_slots_mod(bank, limit=32):
+    """expected_slots with the CZ source of voices whose CZ mode is on, and without a frequency modulator that is the voice itself."""
+    b2 = bank.copy()
+    fm = np.asarray(b2["voice_freq_mod_osc"]).copy()
+    fm[fm == np.arange(bank.n)] = -1
+    b2["voice_freq_mod_osc"] = fm
+    cz = np.where(np.asarray(b2["voice_cz_mode"]) != 0, np.asarray(b2["voice_cz_mod_osc"]), -1)
+    n = bank.n
+    need = np.asarray(b2["voice_amp"]) != 0
+    live = np.flatnonzero(need)
+    for src in (fm[live], np.asarray(b2["voice_amp_mod_osc"])[live], np.asarray(b2["voice_pan_mod_osc"])[live], cz[live]):
+        need[src[src >= 0]] = True
+    most = int(need.reshape(n // 64, 64).sum(1).max())
+    s = 1
+    while s < most: s *= 2
+    return s if s <= limit else 0
+
+
 def run_blocks(dev, bank, tables, g, blocks, pack, probe_ids=None, actions=None):
     """Render `blocks` (frame counts) on a fresh device bank; actions[k](db, host_bank) runs before block k.  Returns the device
     bank's downloaded state, the mixes, the probe rows, (last_kernel, last_pack) per block, violations."""
@@ -185,7 +203,7 @@ def test_sparse_banks_packed_against_the_oracle(dev, seed, n, live):
     rng = np.random.default_rng(seed)
     cand = np.flatnonzero(bank["voice_amp"] != 0)
     ids = np.unique(np.concatenate([rng.choice(cand, 48, replace=False), rng.choice(n, 12, replace=False)])).astype(np.int32)
-    for pack in (1, 0):
+    for pack in (2, 0):
         got, mixes, probes, kinds, viol = run_blocks(dev, bank, tables, g, blocks, pack, probe_ids=ids)
         assert viol == 0
         assert all(k[0] == 1 for k in kinds), kinds
@@ -208,13 +226,14 @@ def test_sparse_banks_packed_against_the_oracle(dev, seed, n, live):
 def test_tiled_patches(dev, patch):
     """The shipped patches tiled over a bank (banks.bank_patch: what tools/ab.py patch times).  banks.bank_patch tiles the voices a
     patch USES, so most of these banks are dense; 37.sk's unit (voices 0..4 and 10) leaves every other lane empty and runs packed
-    by the library's own rule, 3.sk stays as it is.  Voices of a few groups probed, bit for bit; state of the whole bank."""
+    (forced here: the library's own rule wants a bank that fills the machine -- tests/test_patch_banks.py renders these banks at
+    2^20 voices), 3.sk has nothing to pack.  Voices of a few groups probed, bit for bit; state of the whole bank."""
     n = 1 << 14
     bank, tables, g = banks.bank_patch(patch, n)
     blocks = [512, 512, 100]
     ref, ref_mixes, ref_stems = oracle_blocks(bank, tables, g, blocks, want_stems=True)
     ids = np.concatenate([np.arange(12), 64 * 100 + np.arange(12), n - 64 + np.arange(12)]).astype(np.int32)
-    got, mixes, probes, kinds, viol = run_blocks(dev, bank, tables, g, blocks, 1, probe_ids=ids)
+    got, mixes, probes, kinds, viol = run_blocks(dev, bank, tables, g, blocks, 2, probe_ids=ids)
     assert viol == 0
     assert all(k[0] == 1 and k[1] == k[2] for k in kinds), kinds
     assert (kinds[0][1] > 0) == (patch == "37sk"), kinds
@@ -237,7 +256,7 @@ def test_sparse_global_table_bank_and_a_large_plain_one(dev):
     blocks = [512, 64]
     for interp in (0,):
         ref, ref_mixes, _ = oracle_blocks(bank, tables, g, blocks)
-        got, mixes, _, kinds, viol = run_blocks(dev, bank, tables, g, blocks, 1)
+        got, mixes, _, kinds, viol = run_blocks(dev, bank, tables, g, blocks, 2)
         assert viol == 0 and all(k[0] == 1 and k[1] == k[2] and k[1] > 0 for k in kinds), kinds
         assert not got.rw_equal(ref), got.rw_equal(ref)
         for k in range(len(blocks)):
@@ -252,6 +271,47 @@ def test_sparse_global_table_bank_and_a_large_plain_one(dev):
     exp = expected_slots(bank, 16)
     assert exp == 16, exp
     assert viol == 0 and all(k[0] == 1 and k[1] == 16 for k in kinds), kinds
+    assert not got.rw_equal(ref), got.rw_equal(ref)
+    for k in range(len(blocks)):
+        assert rel_rms(mixes[k], ref_mixes[k]) <= 1e-5
+
+
+@pytest.mark.parametrize("seed,n,live", [(31, 4096, 4), (32, 2048, 10), (33, 8192, 2)])
+def test_sparse_modulated_banks_packed(dev, seed, n, live):
+    """The modulated kernel (modulators anywhere in the group -- below the carrier: same-frame dependencies, dependency levels --
+    and CZ phase distortion) packs the same way: whole-bank state bit for bit after several blocks, packed and not; 18.sk tiled
+    (a modulator below its carrier; 16 voices of 64 in use)."""
+    bank, tables, g = sparse_bank(seed, n, live)
+    rng = np.random.default_rng(seed)
+    base = (np.arange(n) // 64) * 64
+    for key, p in (("voice_freq_mod_osc", 0.3), ("voice_amp_mod_osc", 0.2), ("voice_pan_mod_osc", 0.15), ("voice_cz_mod_osc", 0.3)):
+        bank[key] = np.where(rng.random(n) < p, base + rng.integers(0, 64, n), -1).astype(np.int32)
+    bank["voice_cz_mod_depth"] = (rng.random(n) * 2).astype(np.float32)
+    bank["voice_cz_mode"] = np.where(rng.random(n) < 0.3, rng.integers(1, 8, n), 0).astype(np.int32)
+    bank["voice_cz_distortion"] = rng.random(n).astype(np.float32)
+    blocks = [400, 64, 33]
+    ref, ref_mixes, _ = oracle_blocks(bank, tables, g, blocks)
+    for pack in (2, 0):
+        got, mixes, _, kinds, viol = run_blocks(dev, bank, tables, g, blocks, pack)
+        assert viol == 0
+        assert all(k[0] == 2 for k in kinds), kinds
+        if pack:
+            exp = expected_slots_mod(bank)
+            assert exp > 0 and all(k[1] == exp for k in kinds), (exp, kinds)
+        bad = got.rw_equal(ref)
+        assert not bad, (pack, bad)
+        for k in range(len(blocks)):
+            if np.isfinite(ref_mixes[k]).all():
+                assert rel_rms(mixes[k], ref_mixes[k]) <= 1e-5, (pack, k)
+
+
+def test_tiled_18sk_runs_packed_on_the_modulated_kernel(dev):
+    n = 1 << 14
+    bank, tables, g = banks.bank_patch("18sk", n)
+    blocks = [512, 100]
+    ref, ref_mixes, _ = oracle_blocks(bank, tables, g, blocks)
+    got, mixes, _, kinds, viol = run_blocks(dev, bank, tables, g, blocks, 2)
+    assert viol == 0 and all(k[0] == 2 and k[1] == 16 for k in kinds), kinds
     assert not got.rw_equal(ref), got.rw_equal(ref)
     for k in range(len(blocks)):
         assert rel_rms(mixes[k], ref_mixes[k]) <= 1e-5
@@ -286,7 +346,7 @@ def test_voices_switched_on_and_off_between_blocks(dev):
 
     blocks = [256, 256, 256, 256]
     actions = {1: on, 2: off, 3: poke}
-    got, mixes, _, kinds, viol = run_blocks(dev, bank, tables, g, blocks, 1, actions=actions)
+    got, mixes, _, kinds, viol = run_blocks(dev, bank, tables, g, blocks, 2, actions=actions)
     ref, ref_mixes, _ = oracle_blocks(bank, tables, g, blocks, actions=actions)
     assert viol == 0
     assert all(k[1] > 0 and k[1] == k[2] for k in kinds), kinds
@@ -297,24 +357,25 @@ def test_voices_switched_on_and_off_between_blocks(dev):
 
 
 def test_packing_is_left_alone_where_it_does_not_pay(dev):
-    """A full bank, a half-full one-voice bank, a launch with the stem buffer: not packed; SKRED_OPT_PACK = 2 packs whatever has a
-    wavefront to lose; 0 never packs."""
+    """A full bank, a sparse bank that does not fill the machine (the default rule), a launch with the stem buffer: not packed;
+    SKRED_OPT_PACK = 2 packs whatever has a wavefront to lose; 0 never packs."""
     import torch
     bank, tables, g = banks.bank_c2(4096)
-    _, _, _, kinds, _ = run_blocks(dev, bank, tables, g, [128], 1)
+    _, _, _, kinds, _ = run_blocks(dev, bank, tables, g, [128], 2)
     assert kinds[0][1] == 0
     bank, tables, g = sparse_bank(21, 4096, 40)
     _, _, _, kinds, _ = run_blocks(dev, bank, tables, g, [128], 1)
     assert kinds[0][1] == 0, kinds
     bank, tables, g = sparse_bank(22, 4096, 3)
-    _, _, _, kinds, _ = run_blocks(dev, bank, tables, g, [128], 0)
-    assert kinds[0][1] == 0
+    for mode, want in ((0, 0), (1, 0), (2, expected_slots(bank))):
+        _, _, _, kinds, _ = run_blocks(dev, bank, tables, g, [128], mode)
+        assert kinds[0][1] == want, (mode, kinds)
     db = dev.DeviceBank(bank.n)
-    db.set_tables(tables); db.upload(bank); db.set_globals(g)
+    db.set_tables(tables); db.upload(bank); db.set_globals(g); db.set_pack(2)
     mix, stems = db.render_host(64, 2, 0, want_stems=True)
     assert db.last_pack() == 0
     out = torch.zeros(64, 2, device="cuda")
     db.render_mix(64, out.data_ptr(), 2, 0, 0)
     torch.cuda.synchronize()
-    assert db.last_pack() in (4, 8)
+    assert db.last_pack() == expected_slots(bank)
     db.close()

@@ -132,7 +132,40 @@ __device__ __forceinline__ int fx_biquad(const FxFilt &f, int s, int x1, int x2,
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
   __builtin_amdgcn_wave_barrier();                          \
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#define SKX_TILE (8 * 65 + 64)     /* int2 per wave: transposition tile [8][65] + segment sums [64] */
+#define SKX_XT 68                  /* ints per tile row: 64 + 4 keeps the 16-byte reads aligned and spreads the rows over the banks */
+#define SKX_TILE (8 * SKX_XT)      /* ints per wave: the reduction tile [8 frames][SKX_XT] */
+
+// The pool as a voice reads it: an int16 copy in LDS (pools up to 48 KB; wave-uniform `tm` 1) or gathered from L2 / HBM (0).  The
+// LDS pointer carries its address space: a pointer selected between LDS and global memory compiles to FLAT loads.
+typedef __attribute__((address_space(3))) const int16_t fx_lds_i16;
+struct FxTab { const int16_t *g; fx_lds_i16 *l16; };
+__device__ __forceinline__ int fx_tab(const FxTab &t, const int tm, uint32_t idx) { return tm ? (int)t.l16[idx] : (int)t.g[idx]; }
+
+// (L, R) of a lane folded into one register by a lane-half swap (lanes 0..31: l[i] + l[i+32]; lanes 32..63: r[i-32] + r[i]) and
+// parked in a 4-byte tile row -- one ds_write_b32 per frame --; lane (f = lane & 7, seg = lane >> 3) then adds the 8 values of segment
+// seg of frame f (two ds_read_b128), segments 0..3 (L) and 4..7 (R) meet across lanes (a DPP add inside the 16-lane row, a
+// v_permlane16_swap across the row pair), lanes 0..7 / 32..39 store the frame's L / R total: the float kernels' scheme
+// (skred_render_fast.hip: SK_FAST_TILE_REDUCE) on integers, where any order of the additions is exact.
+__device__ __forceinline__ int fx_fold_lr(int l, int r) {
+  const auto p = __builtin_amdgcn_permlane32_swap((unsigned)l, (unsigned)r, false, false);
+  return (int)(p[0] + p[1]);
+}
+__device__ __forceinline__ int fx_row_ror8_add(int x) {
+  int y;
+  asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "=v"(y) : "v"(x));
+  return y;
+}
+__device__ __forceinline__ int fx_row_pair_add(int x) {       // rows 0+1 and rows 2+3, lane by lane
+  const auto p = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+  return (int)(p[0] + p[1]);
+}
+#define SKX_TILE_LOAD(TA, TB) { SKX_WAVE_SYNC() TA = tsrc[0]; TB = tsrc[1]; SKX_WAVE_SYNC() }
+#define SKX_TILE_FINISH(TA, TB, ROW)                                                                 \
+  {                                                                                                  \
+    int t_ = ((TA.x + TA.y) + (TA.z + TA.w)) + ((TB.x + TB.y) + (TB.z + TB.w));                      \
+    t_ = fx_row_pair_add(fx_row_ror8_add(t_));   /* segments 0..3 -> lanes 0..7 (L), 4..7 -> lanes 32..39 (R) */ \
+    if ((lane & 24) == 0) reinterpret_cast<int *>(&(ROW)[lane & 7])[lane >> 5] = t_;                 \
+  }
 
 // Launch-constant part of a voice, as the frame code wants it
 struct FxVoice {
@@ -144,20 +177,20 @@ struct FxVoice {
   bool filt;               // runs the biquad
 };
 
-// Eight frames of a wave whose envelope levels are constant over the chunk (`target` = (amp * e) >> 15 per lane):
-// oscillator, smoother, output, per-voice (L, R) parked in the wave-private tile xp[8][65]; then the same
-// transposition sum as the float kernels (skred_render_fast2.hip), in integers -- any order is exact.
+// Eight frames of a wave whose envelope levels are constant over the chunk (`target` = (amp * e) >> 15 per lane), the
+// definition's arithmetic spelled out: any pool form, full-width products when !NARROW, the delay line's clamp applied.
+// (The lean blocks below take the common case; what reaches this one is rare.)
 template <bool STEMS, bool NARROW, bool INTERP, bool STALL, bool FILTER>
-__device__ __forceinline__ void fx_block(const skx_args_t &a, const FxVoice &vc, const FxFilt &ff, const int16_t *lut, uint32_t &phase,
-                                         int &sg, int &sample, int &x1, int &x2, int &y1, int &y2, const int target, int2 *xp,
-                                         int2 *xq, int2 *wsum_row, const int lane, const int v, const int frame0) {
+__device__ __forceinline__ void fx_block(const skx_args_t &a, const FxVoice &vc, const FxFilt &ff, const FxTab &tab, const int tm, uint32_t &phase,
+                                         int &sg, int &sample, int &x1, int &x2, int &y1, int &y2, const int target, int *xt,
+                                         int2 *wsum_row, const int lane, const int v, const int frame0) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     phase += vc.inc;
     const uint32_t idx = phase >> (32 - vc.L);
-    int s = lut[idx];
+    int s = fx_tab(tab, tm, idx);
     if (INTERP) {
-      const int nxt = lut[(idx + 1) & vc.mask];
+      const int nxt = fx_tab(tab, tm, (idx + 1) & vc.mask);
       const int frac = (int)((uint32_t)(phase << vc.L) >> 17);
       s = s + (__mul24(nxt - s, frac) >> 15);            // |nxt - s| < 2^17, frac < 2^15: always within 24 bits
     }
@@ -181,34 +214,124 @@ __device__ __forceinline__ void fx_block(const skx_args_t &a, const FxVoice &vc,
       if (v < a.n_voices)
         reinterpret_cast<int2 *>(a.stems)[(size_t)(frame0 + q) * (size_t)a.n_voices + (size_t)v] = make_int2(l, r);
     }
-    xp[q * 65 + lane] = make_int2(l, r);
+    xt[q * SKX_XT + lane] = fx_fold_lr(l, r);
   }
-  SKX_WAVE_SYNC()
-  {
-    const int2 *src = xp + (lane & 7) * 65 + (lane >> 3) * 8;
-    int2 t = src[0];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) { const int2 u = src[i]; t.x += u.x; t.y += u.y; }
-    xq[lane] = t;                                        // == xq[seg * 8 + f]
-  }
-  SKX_WAVE_SYNC()
-  if (lane < 8) {
-    int2 t = xq[lane];
-#pragma unroll
-    for (int g = 1; g < 8; ++g) { const int2 u = xq[g * 8 + lane]; t.x += u.x; t.y += u.y; }
-    wsum_row[lane] = t;                                  // |per-voice| < 2^17, 64 of them: fits int32
-  }
+  const int4 *tsrc = reinterpret_cast<const int4 *>(xt + (lane & 7) * SKX_XT + (lane >> 3) * 8);
+  int4 ta, tb;
+  SKX_TILE_LOAD(ta, tb)
+  SKX_TILE_FINISH(ta, tb, wsum_row)                      // |per-voice| < 2^17, 64 of them: fits int32
   SKX_WAVE_SYNC()
 }
 
+// ---------------------------------------------------------------- the lean steady blocks (round 4)
+//
+// The same eight frames for the common case -- NARROW operands, the pool in LDS -- written the way the float kernels'
+// steady blocks are (skred_render_fast.hip: SK_FAST_LDS_CHUNK), every result bit-identical to fx_block / the definition:
+//   * no per-lane branch around the biquad: a lane that does not filter runs the IDENTITY (b0 = 2^30, the rest 0:
+//     (2^30 * (s << 12) + 2^29) >> 30 == s << 12 exactly, back to s) and gets its delay line back behind the block;
+//     the feedback coefficients are negated once, so the five products ADD into one v_mad_i64_i32 chain that starts
+//     from the rounding constant 2^29;
+//   * the delay-line saturation of the definition (clamp to +-2^29) is CHECKED, not applied: (acc >> 30) lies inside the
+//     clamp's range iff the accumulator's high word lies in [-2^27, 2^27), a max and a min per frame pair; a block in which some
+//     lane leaves that range is rolled back and handed to fx_block (rare: a resonance riding the rail);
+//   * a silent lane carries pan gains of 0 instead of two selects per frame;
+//   * the tile of block b - 1 is added up while block b runs.
+
+// a * b + c, int32 x int32 + int64: v_mad_i64_i32, spelled out (left to itself hipcc widens the loop-carried delay line to
+// 64 bits and multiplies 64 x 64: v_mad_u64_u32 + two v_mul_lo_u32 + the adds, per product)
+__device__ __forceinline__ long long fx_mad64(int a, int b, long long c) {
+  long long d;
+  unsigned long long carry;                                  // (the instruction's carry-out pair: unused)
+  asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// Up to `nblk` blocks of 8 frames; returns how many were rendered (fewer: the next one saturates its delay line and is
+// the caller's, state as the last rendered block left it).  wrow = the wave's row of wsum for this chunk.
+template <bool STEMS, bool INTERP, bool STALL, bool FILTER>
+__device__ __forceinline__ int fx_chunk_lean(const skx_args_t &a, const FxVoice &vc, const FxFilt &ff, const FxTab &tab, uint32_t &phase,
+                                             int &sg, int &sample, int &x1, int &x2, int &y1, int &y2, const int target, int *xt,
+                                             int2 *wrow, const int lane, const int v, const int frame0, const int nblk) {
+  const int pl = vc.silent ? 0 : vc.pan_l, pr = vc.silent ? 0 : vc.pan_r;
+  const int kk = vc.smooth ? vc.k : 0;                       // a lane without the smoother leaves its state alone
+  const int fb0 = vc.filt ? ff.b0 : (1 << 30), fb1 = vc.filt ? ff.b1 : 0, fb2 = vc.filt ? ff.b2 : 0;
+  const int na1 = vc.filt ? -ff.a1 : 0, na2 = vc.filt ? -ff.a2 : 0;
+  const uint32_t sh_idx = 32u - (uint32_t)vc.L, sh_frac = 17u - (uint32_t)vc.L;
+  const int4 *tsrc = reinterpret_cast<const int4 *>(xt + (lane & 7) * SKX_XT + (lane >> 3) * 8);
+  int4 ta = make_int4(0, 0, 0, 0), tb = ta;
+  int pend = -1, b = 0;
+  const int gain_c = vc.smooth ? sg : target;                // (STALL: the smoother rests, the gain is one constant)
+  const long long half_ = 1ll << 29;                         // the rounding constant the accumulation starts from
+#define SKX_LEAN_FRAME(Q, XN, XO, YN, YO)                                                            \
+  {                                                                                                  \
+    phase += vc.inc;                                                                                 \
+    const uint32_t idx_ = phase >> sh_idx;                                                           \
+    int s_ = tab.l16[idx_];                                                                          \
+    if (INTERP) {                                                                                    \
+      const int nxt_ = tab.l16[(idx_ + 1u) & vc.mask];                                               \
+      const int frac_ = (int)__builtin_amdgcn_ubfe(phase, sh_frac, 15u);   /* == (phase << L) >> 17 */ \
+      s_ = s_ + (__mul24(nxt_ - s_, frac_) >> 15);                                                   \
+    }                                                                                                \
+    if (FILTER) {                                                                                    \
+      const int x0_ = s_ * 4096;                                                                     \
+      long long acc_ = fx_mad64(fb0, x0_, half_);                                                    \
+      acc_ = fx_mad64(fb1, XN, acc_);                                                                \
+      acc_ = fx_mad64(fb2, XO, acc_);                                                                \
+      acc_ = fx_mad64(na1, YN, acc_);                                                                \
+      acc_ = fx_mad64(na2, YO, acc_);                                                                \
+      const int hi_ = (int)(acc_ >> 32);                                                             \
+      const int y0_ = (int)(acc_ >> 30);              /* the definition's y0 while it does not clamp */ \
+      hi_max = max(hi_max, hi_); hi_min = min(hi_min, hi_);                                          \
+      XO = x0_; YO = y0_;                                                                            \
+      const int o_ = y0_ >> 12;                                                                      \
+      s_ = o_ < -32768 ? -32768 : (o_ > 32767 ? 32767 : o_);                                         \
+    }                                                                                                \
+    int gain_ = gain_c;                                                                              \
+    if (!STALL) { sg += __mul24(target - sg, kk) >> 15; gain_ = vc.smooth ? sg : target; }           \
+    smp = __mul24(s_, gain_) >> 15;                                                                  \
+    const int l_ = __mul24(smp, pl) >> 15, r_ = __mul24(smp, pr) >> 15;                              \
+    if (STEMS) {                                                                                     \
+      if (v < a.n_voices)                                                                            \
+        reinterpret_cast<int2 *>(a.stems)[(size_t)(frame0 + b * 8 + (Q)) * (size_t)a.n_voices + (size_t)v] = make_int2(l_, r_); \
+    }                                                                                                \
+    xt[(Q) * SKX_XT + lane] = fx_fold_lr(l_, r_);                                                    \
+  }
+  for (; b < nblk; ++b) {
+    const uint32_t s_phase = phase;
+    const int s_sg = sg, s_x1 = x1, s_x2 = x2, s_y1 = y1, s_y2 = y2;
+    int hi_max = 0, hi_min = 0;                              // (v_max3_i32 / v_min3_i32: one instruction per frame for the pair)
+    int smp = sample;
+    if (pend >= 0) SKX_TILE_LOAD(ta, tb)
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+      SKX_LEAN_FRAME(q, x1, x2, y1, y2)
+      SKX_LEAN_FRAME(q + 1, x2, x1, y2, y1)
+    }
+    if (pend >= 0) { SKX_TILE_FINISH(ta, tb, wrow + pend) pend = -1; }
+    if (FILTER) {
+      if (__any(hi_max >= (1 << 27) || hi_min < -(1 << 27))) {   // some delay line left +-2^29: this block is fx_block's
+        phase = s_phase; sg = s_sg; x1 = s_x1; x2 = s_x2; y1 = s_y1; y2 = s_y2;
+        break;
+      }
+      if (!vc.filt) { x1 = s_x1; x2 = s_x2; y1 = s_y1; y2 = s_y2; }
+    }
+    sample = smp;
+    pend = b * 8;
+  }
+  if (pend >= 0) { SKX_TILE_LOAD(ta, tb) SKX_TILE_FINISH(ta, tb, wrow + pend) }
+  SKX_WAVE_SYNC()
+#undef SKX_LEAN_FRAME
+  return b;
+}
+
 template <bool STEMS>
-__global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_t a) {
-  extern __shared__ int16_t lut_lds[];                 // [lds_entries] | int2 wsum[4][SKX_CHUNK] | int2 tile[4][SKX_TILE]
+__global__ __launch_bounds__(SKX_GROUP, 4) void sk_fx_render_kernel(const skx_args_t a) {
+  extern __shared__ int16_t lut_lds[];                 // [the pool] | int2 wsum[4][SKX_CHUNK] | int tile[4][SKX_TILE]
   int2 *wsum = reinterpret_cast<int2 *>(reinterpret_cast<char *>(lut_lds) + a.lds_bytes_tables);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int2 *xp = wsum + 4 * SKX_CHUNK + wave * SKX_TILE;
-  int2 *xq = xp + 8 * 65;
+  int *xt = reinterpret_cast<int *>(wsum + 4 * SKX_CHUNK) + wave * SKX_TILE;
   const bool lut_in_lds = a.lds_bytes_tables > 0;
+  const int tm = lut_in_lds ? 1 : 0;                   // the pool's form (FxTab)
   const int bid = (int)blockIdx.x - 1;                 // row of the partial mix; -1: the gain workgroup
   if (bid < 0) { skx_finish_block(a, bid, tid, SKX_GROUP, reinterpret_cast<int *>(lut_lds)); return; }
   if (lut_in_lds) {
@@ -257,7 +380,10 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
     }
     const bool dead = amp == 0 || (flags & SKXF_INERT) || finished;
     // (a skipped lane runs the block code on inert numbers: entries 0..1 of the pool, whatever its own table fields say)
-    const int16_t *lut = (lut_in_lds ? lut_lds : a.tables) + (dead ? 0 : toff);
+    const int tbase = dead ? 0 : toff;
+    FxTab tab;
+    tab.g = a.tables + tbase;
+    tab.l16 = (fx_lds_i16 *)lut_lds + tbase;
     const uint32_t mask = (1u << L) - 1u;
     const bool uses_env = (flags & SKXF_USE_ENV) != 0;
 
@@ -271,6 +397,9 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
     // itself and its target), and |smoother state|, |target| <= 65535, so that s * gain fits 32 bits like the int16
     // sample times a Q16 gain it is meant to be; anything else takes the blocks with the definition's full-width products
     const bool narrow = __all(dead || (fits24(pan_l) && fits24(pan_r) && k >= 0 && k <= 32768 && sg >= -65535 && sg <= 65535));
+    // the lean blocks also want the pool in LDS, table sizes the definition allows (the fraction is a bit field of the phase) and
+    // feedback coefficients that can be negated
+    const bool lean_ok = lut_in_lds && __all(dead || (L >= 1 && L <= 15 && (!filt || (ff.a1 != INT32_MIN && ff.a2 != INT32_MIN))));
 
     for (int c0 = 0; c0 < a.num_frames; c0 += SKX_CHUNK) {
       const int cn = min(SKX_CHUNK, a.num_frames - c0);
@@ -291,9 +420,24 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
         const bool stalled = __all(dead || !vc.smooth || (((target - sg) * vc.k) >> 15) == 0);
         const bool narrow_c = narrow && __all(dead || (target >= -65535 && target <= 65535));
         int2 *row = wsum + wave * SKX_CHUNK;
+        if (narrow_c && lean_ok) {       // the lean blocks (fx_chunk_lean); what they leave -- a block that rides the rail -- follows below
+          const int nblk = cn >> 3;
+          int done;
+#define SKX_LEAN(INTERP_, STALL_, FILTER_)                                                                           \
+  done = fx_chunk_lean<STEMS, INTERP_, STALL_, FILTER_>(a, vc, ff, tab, phase, sg, sample, x1, x2, y1, y2, target, xt, row, lane, v, c0, nblk);
+          if (a.any_filter) {
+            if (a.interp) { if (stalled) SKX_LEAN(true, true, true) else SKX_LEAN(true, false, true) }
+            else          { if (stalled) SKX_LEAN(false, true, true) else SKX_LEAN(false, false, true) }
+          } else {
+            if (a.interp) { if (stalled) SKX_LEAN(true, true, false) else SKX_LEAN(true, false, false) }
+            else          { if (stalled) SKX_LEAN(false, true, false) else SKX_LEAN(false, false, false) }
+          }
+#undef SKX_LEAN
+          j = done << 3;
+        }
 #define SKX_BLOCKS(NARROW_, INTERP_, STALL_)                                                                       \
-  if (a.any_filter) { for (; j + 8 <= cn; j += 8) fx_block<STEMS, NARROW_, INTERP_, STALL_, true>(a, vc, ff, lut, phase, sg, sample, x1, x2, y1, y2, target, xp, xq, row + j, lane, v, c0 + j); } \
-  else { for (; j + 8 <= cn; j += 8) fx_block<STEMS, NARROW_, INTERP_, STALL_, false>(a, vc, ff, lut, phase, sg, sample, x1, x2, y1, y2, target, xp, xq, row + j, lane, v, c0 + j); }
+  if (a.any_filter) { for (; j + 8 <= cn; j += 8) fx_block<STEMS, NARROW_, INTERP_, STALL_, true>(a, vc, ff, tab, tm, phase, sg, sample, x1, x2, y1, y2, target, xt, row + j, lane, v, c0 + j); } \
+  else { for (; j + 8 <= cn; j += 8) fx_block<STEMS, NARROW_, INTERP_, STALL_, false>(a, vc, ff, tab, tm, phase, sg, sample, x1, x2, y1, y2, target, xt, row + j, lane, v, c0 + j); }
         if (narrow_c) {
           if (a.interp) { if (stalled) SKX_BLOCKS(true, true, true) else SKX_BLOCKS(true, true, false) }
           else          { if (stalled) SKX_BLOCKS(true, false, true) else SKX_BLOCKS(true, false, false) }
@@ -314,9 +458,9 @@ __global__ __launch_bounds__(SKX_GROUP) void sk_fx_render_kernel(const skx_args_
           if (one_shot && ph < phase) { ph = 0xFFFFFFFFu; finished = true; ends = true; }   // the add carried: the cycle is over
           phase = ph;
           const uint32_t idx = phase >> (32 - L);
-          int s = lut[idx];
+          int s = fx_tab(tab, tm, idx);
           if (a.interp) {
-            const int nxt = ends ? s : lut[(idx + 1) & mask];
+            const int nxt = ends ? s : fx_tab(tab, tm, (idx + 1) & mask);
             const int frac = (int)((uint32_t)(phase << L) >> 17);
             s = s + (((nxt - s) * frac) >> 15);
           }
@@ -430,7 +574,7 @@ extern "C" int skx_launch_stamp(const int32_t *d_ids, int n, int which, skx_plan
 }
 
 extern "C" int skx_launch_render(const skx_args_t *args, int n_workgroups, hipStream_t stream) {
-  const size_t lds = (size_t)args->lds_bytes_tables + (size_t)4 * SKX_CHUNK * sizeof(int2) + (size_t)4 * SKX_TILE * sizeof(int2);
+  const size_t lds = (size_t)args->lds_bytes_tables + (size_t)4 * SKX_CHUNK * sizeof(int2) + (size_t)4 * SKX_TILE * sizeof(int);
   dim3 grid((unsigned)n_workgroups + 1u), block(SKX_GROUP);   /* + the gain workgroup */
   if (args->stems) hipLaunchKernelGGL((sk_fx_render_kernel<true>), grid, block, lds, stream, *args);
   else             hipLaunchKernelGGL((sk_fx_render_kernel<false>), grid, block, lds, stream, *args);

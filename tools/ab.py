@@ -7,6 +7,7 @@ build, `tools/ab_libs.sh ab.py ...` runs it once per build under _ab/).  It repl
   frames   one bank, several block lengths (per-frame + fixed cost):  --bank c2:65536 --lengths 64,256,512,2048
   live     a 2^20-voice C3 bank from its first frame, then under note traffic:  [--notes 104,524,5242] [--in-place M] [--voices N]
   patch    reference patches tiled over a bank (banks.bank_patch):    [--patches 3sk,37sk,7sk,1sk,18sk] [--voices N]
+  fx       the fixed-point bank (fxbank.bank_fx) at several sizes, both lookups, with and without the biquad:  [--fx-sizes 65536,1048576]
   stamps   `steady` on a -DSKS_STAMPS build of the split kernel: what its waves recorded (cycles, waits, in-kernel clock)
 """
 import argparse, os, sys, time
@@ -143,9 +144,28 @@ def patch(a):
         db.close()
 
 
+def fx(a):
+    from skred_amd import fxbank
+    for n in [int(x) for x in a.fx_sizes.split(",")]:
+        for with_filter in ((True, False) if a.fx_filter < 0 else (bool(a.fx_filter),)):
+            b, pool, c0 = fxbank.bank_fx(n, with_filter=with_filter)
+            db = fxbank.DeviceFxBank(n); db.set_tables(pool); db.upload(b); db.set_sample_count(c0)
+            out = torch.zeros(a.f, 2, device="cuda", dtype=torch.int64)
+            for interp in ((1, 0) if a.fx_interp < 0 else (a.fx_interp,)):
+                for _ in range(20): db.render_mix(a.f, out.data_ptr(), interp, 0, 0)
+                torch.cuda.synchronize()
+                best, med = timed(lambda: db.render_mix(a.f, out.data_ptr(), interp, 0, 0), 40, 3)
+                print(f"fx {n:8d} voices filter={int(with_filter)} interp={interp} F={a.f}: {best / 1e3:7.4f} ms per block (med {med / 1e3:7.4f})  "
+                      f"kernel {db.last_render_ms():.4f} ms  lib={LIB}", flush=True)
+            db.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("scenario", choices=["steady", "frames", "live", "patch", "stamps"])
+    ap.add_argument("scenario", choices=["steady", "frames", "live", "patch", "stamps", "fx"])
+    ap.add_argument("--fx-sizes", default="65536,1048576")
+    ap.add_argument("--fx-filter", type=int, default=-1)
+    ap.add_argument("--fx-interp", type=int, default=-1)
     ap.add_argument("--sizes", default="c1:4096,c2:65536,c2:131072,c2:196608")
     ap.add_argument("--bank", default="c2:65536")
     ap.add_argument("--lengths", default="64,256,512,2048")
@@ -162,7 +182,7 @@ def main():
     ap.add_argument("--pack", type=int, default=None)
     ap.add_argument("--patches", default="3sk,37sk,7sk,1sk,18sk")
     a = ap.parse_args()
-    {"steady": steady, "stamps": steady, "frames": frames, "live": live, "patch": patch}[a.scenario](a)
+    {"steady": steady, "stamps": steady, "frames": frames, "live": live, "patch": patch, "fx": fx}[a.scenario](a)
 
 
 if __name__ == "__main__":

@@ -226,6 +226,76 @@ def test_fx_filter_state_saturates_like_the_definition():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("interp", [0, 1])
+def test_fx_pool_beyond_lds_is_gathered_from_memory(interp):
+    """A pool of more than 48 KB does not fit the workgroup's LDS: the kernel gathers the tables from L2 / HBM (its blocks with
+    the definition's arithmetic spelled out, not the lean LDS blocks).  Same voices, the tables moved behind 30 000 entries of
+    padding, some voices on tables that straddle the old LDS limit."""
+    n = 3000
+    b, pool, c0 = fxbank.bank_fx(n)
+    pad = 30000
+    rng = np.random.default_rng(5)
+    big = np.concatenate([rng.integers(-32768, 32767, pad).astype(np.int16), pool])
+    assert big.nbytes > 49152
+    b["table_offset"] = (b["table_offset"] + pad).astype(np.int32)
+    far = np.arange(7, n, 9)                                 # random-noise tables inside the padding, 2^10 entries each
+    b["table_offset"][far] = (far * 13) % (pad - 1024)
+    b["log2_size"][far] = 10
+    b["amp_q15"][::11] = 0
+    b["filter_mode"][::5] = 0
+    segs = [(700, None), (333, _release_odd), (64, None)]
+    rb, count = b.copy(), c0
+    db = fxbank.DeviceFxBank(n)
+    db.set_tables(big)
+    host = b.copy()
+    db.upload(host)
+    db.set_sample_count(c0)
+    for frames, ev in segs:
+        if ev:
+            ev(rb, count)
+            db.download(host)
+            ev(host, db.sample_count())
+            db.upload(host)
+        ref, rst, count = cpuref.fx_render(rb, big, count, frames, interp, want_stems=True)
+        got, gst = db.render_host(frames, interp, want_stems=True)
+        assert (got == ref).all() and (gst == rst).all()
+    db.download(host)
+    db.close()
+    assert not host.rw_mismatch(rb), host.rw_mismatch(rb)
+
+
+@pytest.mark.gpu
+def test_fx_one_lane_on_the_rail_among_steady_lanes():
+    """The lean steady blocks CHECK the delay line's clamp instead of applying it and hand a block in which some lane leaves
+    +-2^29 back to the spelled-out block; the lanes around it and the blocks after it must not notice.  One resonant voice per
+    wave is driven to the rail for a while (its coefficients make it ring, then the ringing decays), every other voice is the
+    ordinary recipe; no stems at 2^16 voices, so the timed blocks themselves run."""
+    n = 1 << 16
+    b, pool, c0 = fxbank.bank_fx(n)
+    hot = np.arange(5, n, 64)
+    co = fxbank.q30_coeffs(np.full(hot.size, 1), np.full(hot.size, 300.0, np.float32), np.full(hot.size, 80.0, np.float32), 48000)
+    for k, v in co.items():
+        b[k][hot] = v
+    b["filter_mode"][hot] = 1
+    b["y1"][hot] = (1 << 29) - 1
+    b["y2"][hot] = -(1 << 29)
+    b["use_envelope"][:] = 0                                  # steady from the first frame
+    rb, count = b.copy(), c0
+    db = fxbank.DeviceFxBank(n)
+    db.set_tables(pool)
+    db.upload(b)
+    db.set_sample_count(c0)
+    for frames in (512, 512, 100):
+        ref, _, count = cpuref.fx_render(rb, pool, count, frames, 1, fast=True)
+        got, _ = db.render_host(frames, 1)
+        assert (got == ref).all()
+    host = b.copy()
+    db.download(host)
+    db.close()
+    assert not host.rw_mismatch(rb), host.rw_mismatch(rb)
+
+
+@pytest.mark.gpu
 def test_fx_mix_is_exactly_additive():
     """Integer path: mix(A u B) == mix(A) + mix(B) EXACTLY -> a multi-GPU sum of partial mixes is bit-exact."""
     n, frames = 8192, 256

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(SKX_GROUP, 4) void sk_fx_render_kernel(const skx_ar
     const int n4 = a.lds_bytes_tables >> 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tables);
     uint4 *dst = reinterpret_cast<uint4 *>(lut_lds);
-    for (int i = tid; i < n4; i += SKX_GROUP) dst[i] = src[i];
+    sk_stage_tables<SKX_GROUP>(src, dst, n4, tid);
     __syncthreads();
   }
   const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;

@@ -96,6 +96,24 @@ __device__ __forceinline__ void half_sum2_to_lanes_31_63(float &x0, float &x1) {
 // drains them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier and ONE lane adds to the ticket -- no release
 // fence, which would write back the XCD's whole L2 (full of voice-state lines here) once per workgroup.  The last
 // arriver acquires at agent scope (its CU's L1 lines dropped), drains, barrier, then plain loads.
+// The workgroup's copy of the table pool into LDS (n16 16-byte words, NTHREADS threads): every thread keeps up to eight loads in
+// flight before it stores the first.  The plain loop `dst[i] = src[i]` compiles to load, wait, store per trip -- seven round trips
+// to L2 for the C2 recipe's 25 KB pool, ~5 us of a block that takes 44 (round 4: tools/ab.py frames, the fixed part of a block).
+template <int NTHREADS>
+__device__ __forceinline__ void sk_stage_tables(const void *__restrict__ src_, void *dst_, int n16, int tid) {
+  const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(src_);
+  uint4 *dst = reinterpret_cast<uint4 *>(dst_);
+  for (int base = 0; base < n16; base += 8 * NTHREADS) {
+    uint4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = src[min(base + k * NTHREADS + tid, n16 - 1)];
+    // (indices clamped, nothing predicated: behind the pool's end a thread copies the last word again -- the same value to the same
+    // place --; a store under `if (i < n16)` makes hipcc sink the load into the branch, and the round trips are back)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[min(base + k * NTHREADS + tid, n16 - 1)] = t[k];
+  }
+}
+
 typedef __attribute__((address_space(1))) unsigned long long sk_gu64;
 typedef __attribute__((address_space(1))) unsigned int sk_gu32;
 __device__ __forceinline__ void sk_store_through(float2 *p, float2 v) {

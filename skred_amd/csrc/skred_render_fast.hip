@@ -435,7 +435,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     const int n4 = a.lds_table_floats >> 2;           // padded to a multiple of 4 by the host
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);
     float4 *dst4 = reinterpret_cast<float4 *>(lds);
-    for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];
+    sk_stage_tables<SK_GROUP>(src4, dst4, n4, tid);
     __syncthreads();
   }
 

@@ -794,7 +794,7 @@ __device__ __forceinline__ void fast2_store(const sk_render_args_t &a, const Fas
     const int n4 = a.lds_table_floats >> 2;                                                          \
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);                                 \
     float4 *dst4 = reinterpret_cast<float4 *>(lds);                                                  \
-    for (int i = tid; i < n4; i += NW * 64) dst4[i] = src4[i];                                       \
+    sk_stage_tables<NW * 64>(src4, dst4, n4, tid);                                                   \
     __syncthreads();                                                                                 \
   }                                                                                                  \
   float *const row_ptr = (ROWS) + (size_t)bid * (size_t)a.num_frames * 2;   /* this workgroup's row */ \

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_kernel(const sk_render_arg
     const int n4 = a.lds_table_floats >> 2;
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);
     float4 *dst4 = reinterpret_cast<float4 *>(lds_tab);
-    for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];
+    sk_stage_tables<SK_GROUP>(src4, dst4, n4, tid);
     for (int i = (n4 << 2) + tid; i < a.lds_table_floats; i += SK_GROUP) lds_tab[i] = a.tables[i];
     __syncthreads();
   }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render
     const int n4 = a.lds_table_floats >> 2;
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);
     float4 *dst4 = reinterpret_cast<float4 *>(lds);
-    for (int i = tid; i < n4; i += SK_GROUP) dst4[i] = src4[i];
+    sk_stage_tables<SK_GROUP>(src4, dst4, n4, tid);
     __syncthreads();
   }
   const size_t part_base = (size_t)bid * (size_t)a.num_frames * 2;

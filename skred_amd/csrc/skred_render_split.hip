@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NP * 128, NP) void sk_render_split_kernel(const sk_
     const int n4 = T >> 2;                             // padded to a multiple of 4 by the host
     const float4 *src4 = reinterpret_cast<const float4 *>(a.tables);
     float4 *dst4 = reinterpret_cast<float4 *>(lds);
-    for (int i = tid; i < n4; i += NTHREADS) dst4[i] = src4[i];
+    sk_stage_tables<NTHREADS>(src4, dst4, n4, tid);
     if (tid < SKS_CTRL_INTS) ctrl[tid] = 0;
     __syncthreads();
   }

@@ -234,6 +234,23 @@ __device__ __forceinline__ v2f fast2_osc(Fast2Regs &r, const char *lds_tab, cons
   }
   r.phase = ph;
   v2f s;
+#ifndef SK_FAST2_NO_PAIRED_TAPS
+  if (INTERP == 2 && TAME && TAB_LDS) {
+    // Linear lookup of both voices with the taps landing where the packed arithmetic wants them: (a0, a1) and (b0, b1) are
+    // FOUR 4-byte gathers into two register pairs, and a + fract(pos) * (b - a) is three packed instructions for the lane's
+    // two voices (the same products and sums per voice as fast2_fetch).  Fetched as one (a, b) pair per voice -- a
+    // ds_read2_b32, which is also what hipcc merges two adjacent 4-byte loads into, hence `volatile` -- the packed operands
+    // cost three v_mov per frame to line up: the VALUs are what binds this kernel, the LDS pipe has room.
+    typedef __attribute__((address_space(3))) const volatile float lds_vf;
+    lds_vf *t0 = (lds_vf *)(lds_tab + (r.toff4[0] + ((int)ph.x << 2)));
+    lds_vf *t1 = (lds_vf *)(lds_tab + (r.toff4[1] + ((int)ph.y << 2)));
+    v2f ta, tb;
+    ta.x = t0[0]; ta.y = t1[0];
+    tb.x = t0[1]; tb.y = t1[1];
+    const v2f fr = {__builtin_amdgcn_fractf(ph.x), __builtin_amdgcn_fractf(ph.y)};
+    return ta + fr * (tb - ta);
+  }
+#endif
   s.x = fast2_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r.toff4[0], r.tsize_m1[0], r.lo.x, r.hi.x, ph.x);
   s.y = fast2_fetch<TAB_LDS, INTERP, TAME>(lds_tab, glb_tab, r.toff4[1], r.tsize_m1[1], r.lo.y, r.hi.y, ph.y);
   return s;

@@ -140,6 +140,7 @@ int skred_bank_create(int device, int n_voices, skred_bank_t **out) {
   b->in_place_mode = 1;
   b->split_mode = 0;
   b->pack_mode = 1;
+  b->fm_skew = 1;
   b->timing_every = 1;
   b->pp_parity = -1;
   b->n_padded = b->n_groups * SK_GROUP;
@@ -357,6 +358,7 @@ int skred_bank_set_option(skred_bank_t *b, int option, int value) {
     case SKRED_OPT_SPLIT_PAIRS: b->split_pairs = (value == 2 || value == 4) ? value : 0; return SKRED_OK;
     case SKRED_OPT_SPLIT: b->split_mode = value < 0 ? 0 : value > 3 ? 3 : value; return SKRED_OK;
     case SKRED_OPT_PACK: b->pack_mode = value < 0 ? 0 : value > 2 ? 2 : value; return SKRED_OK;
+    case SKRED_OPT_FM_SKEW: b->fm_skew = value != 0; return SKRED_OK;
     default: return fail(SKRED_E_BAD_ARG, "unknown option %d", option);
   }
 }
@@ -579,6 +581,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
    * renders them (it holds every per-lane feature test), so the rule asks for at least half the waves to disappear; a bank the
    * two-per-lane kernel would take, for a quarter of them. */
   a.pack_shift = 6;
+  a.fm_skew = b->fm_skew && (a.fast_mode & SKM_FM) && a.lds_table_floats > 0 && !d_stems;   /* (the launcher drops it when the ring does not fit) */
   int pack_s = 0;
   if (b->pack_mode && (modulated || ((a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_FM_PAIR))) && !d_stems) {   /* (the modulated kernel packs the same way) */
     const int most = pack_refresh(b);

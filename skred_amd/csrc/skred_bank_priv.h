@@ -88,6 +88,7 @@ struct skred_bank {
   int last_split;             /* the latest block ran sk_render_split_kernel */
   /* packed lanes of sparse banks (skred_device_layout.h: pack_mask; skred_bank.c: pack_refresh, render_block) */
   int pack_mode;              /* SKRED_OPT_PACK: 0 never, 1 where it pays (default) */
+  int fm_skew;                /* SKRED_OPT_FM_SKEW: modulator lanes a block ahead of their carriers (default 1) */
   uint64_t *h_pack_mask;      /* [n_padded / 64] per aligned 64-voice group: voices that can sound, and the modulators they name */
   uint64_t *d_pack_mask;
   uint8_t *h_pack_dirty;      /* [n_padded / 64] a voice of the group changed class or modulator: its word is recomputed */

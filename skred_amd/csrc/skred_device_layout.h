@@ -223,6 +223,8 @@ typedef struct {
   int32_t pack_shift;        /* log2 of the lanes per group */
   int32_t pack_groups;       /* aligned 64-voice groups of the bank */
   int32_t pack_passes;       /* workgroup passes: ceil(pack_groups / (4 << (6 - pack_shift))) */
+  /* ---- skewed blocks of frequency-modulated wavefronts (one-voice family, extended instantiation; SKRED_OPT_FM_SKEW) ---- */
+  int32_t fm_skew;           /* 1: the launch carries the per-wave sample ring (SK_SKEW_RING floats) behind the reduction tiles */
 } sk_render_args_t;
 #define SK_PROBE_MAX 64
 

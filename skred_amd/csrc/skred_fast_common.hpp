@@ -439,17 +439,20 @@ __device__ __forceinline__ bool fast_smoother_stalled(const FastRegs &r) {
 // caller has set r.tf / r.trf to this frame's envelope clocks.
 // TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
 // by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
-template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false>
+// EXTMS: the caller hands in the frequency modulator's previous sample (`ms_ext`: the skewed blocks of skred_render_fast.hip,
+// whose modulator lanes run a block ahead and leave their samples in an LDS ring) instead of the ds_bpermute exchange.
+template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false, bool EXTMS = false>
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r,
-                                           const int xf = 0, const bool muted = false, const float white = 0.0f) {
+                                           const int xf = 0, const bool muted = false, const float white = 0.0f,
+                                           const float ms_ext = 0.0f) {
   float inc = r.inc;
   if (STOPS && (xf & (XF_FM | XF_AP))) {                // wave-uniform: some lane of the wave is modulated
     // voice_sample[m] as the previous frame left it (a modulator that is skipped this frame holds exact zero)
     const int mine = __float_as_int(r.sample);
     if (xf & XF_FM) {
-      const float ms = __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, mine));
+      const float ms = EXTMS ? ms_ext : __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, mine));
       if (r.fm_addr >= 0) inc = r.inc + r.fm_k * (ms * r.fm_depth);      // synth.c:551-554
     }
     if (xf & XF_AP) {

@@ -357,6 +357,79 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     }                                                                                                    \
     pend_j = (J);                                                                                        \
   }
+// ---- skewed blocks (round 4, SKRED_OPT_FM_SKEW): the same frequency modulation WITHOUT a per-frame exchange ----
+// The modulator of such a patch (`v3 w0 f5 a5 m1`) is itself unmodulated, so nothing it renders depends on its carriers: the
+// per-frame ds_bpermute above only exists because all lanes of a wave walk the frames in lock step.  Here the modulator lanes
+// of the wave run ONE 8-FRAME BLOCK AHEAD of the other lanes: in every step a modulator renders frames J+8 .. J+15 and leaves
+// its eight voice_sample values in the wave's LDS ring (ring[q][lane]), a carrier renders frames J .. J+7 from the eight values
+// the previous step left there (plus `prev7`, the last one of the step before: frame J's increment takes the sample of frame
+// J-1, synth.c:551).  A carrier's eight increments are known at the top of its step, so its oscillator runs eight gathers deep
+// like a clean bank's and the tameness vote is one per block.  Ahead and behind lanes meet again before anything that counts
+// frames for the whole wave: the lead block (modulators alone, EXEC-masked) opens the first skewed step of a pass, the last
+// whole block of the launch is rendered with the modulators' state put back afterwards (they have been there already).
+// Condition (skew_ok, per wave and pass): every modulator lane is silent (its (L, R) are zeros whatever frame it is on: the
+// tile rows stay those of the carriers' frames; no probe row) and is not frequency-modulated itself.  Same products and sums
+// per voice as SK_FAST_FM_FRAME; a step whose vote fails takes the general frame with the ring's samples (fast_frame<EXTMS>).
+#define SK_SKEW_RING (8 * 64)    /* floats per wave */
+#define SK_FAST_SKEW_LEAD()                                                                              \
+  {                                                                                                      \
+    float s_[8];                                                                                         \
+    SK_FAST_OSC8(s_)                                                                                     \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      float u0_, u1_, w_;                                                                                \
+      fast_post_v<FILTER, ENV, false, STOPS, true, false>(r, pk, s_[q_], xx, yy, u0_, w_, xf);           \
+      ring[q_ * 64 + lane] = u0_;                                                                        \
+      fast_post_v<FILTER, ENV, false, STOPS, false, false>(r, pk, s_[q_ + 1], xx, yy, u1_, w_, xf);      \
+      ring[(q_ + 1) * 64 + lane] = u1_;                                                                  \
+    }                                                                                                    \
+  }
+#define SK_FAST_SKEW_FRAME(Q, XN, XO, YN, YO)                                                            \
+  {                                                                                                      \
+    float l, rr;                                                                                         \
+    fast_frame<TAB_LDS, FILTER, ENV, true, false, INTERP, STOPS, true>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, 0.0f, mq_[Q]); \
+    ring[(Q) * 64 + lane] = r.sample;                                                                    \
+    l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
+    xt[(Q) * SK_XT + lane] = fold_lr(l, rr);                                                             \
+  }
+#define SK_FAST_SKEW_STEP(J)                                                                             \
+  {                                                                                                      \
+    if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
+    float mq_[8], inc_[8];          /* per frame of the step: the modulator's previous sample, the increment */ \
+    SK_FAST_WAVE_SYNC()                                                                                  \
+    mq_[0] = prev7;                                                                                      \
+    _Pragma("unroll") for (int q_ = 1; q_ < 8; ++q_) mq_[q_] = ring[(q_ - 1) * 64 + fm_src];             \
+    prev7 = ring[7 * 64 + fm_src];                                                                       \
+    SK_FAST_WAVE_SYNC()                                                                                  \
+    bool ok_ = true;                                                                                     \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                   \
+      inc_[q_] = r.fm_addr >= 0 ? r.inc + r.fm_k * (mq_[q_] * r.fm_depth) : r.inc;      /* synth.c:551-554 */ \
+      ok_ = ok_ && inc_[q_] >= 0.0f && inc_[q_] <= half_span;                                            \
+    }                                                                                                    \
+    if (__all(ok_)) {                                                                                    \
+      float s_[8];                                                                                       \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                   \
+        s_[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false>(r, inc_[q_])); \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
+        float s0_, s1_, u_, f0_, f1_;                                                                    \
+        fast_post_v<FILTER, ENV, false, STOPS, true, false>(r, pk, s_[q_], xx, yy, s0_, u_, xf);         \
+        ring[q_ * 64 + lane] = s0_;                                                                      \
+        fast_post_v<FILTER, ENV, false, STOPS, false, false>(r, pk, s_[q_ + 1], xx, yy, s1_, u_, xf);    \
+        ring[(q_ + 1) * 64 + lane] = s1_;                                                                \
+        s0_ = silent ? 0.0f : s0_; s1_ = silent ? 0.0f : s1_;                                            \
+        fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                          \
+        xt[q_ * SK_XT + lane] = f0_;                                                                     \
+        xt[(q_ + 1) * SK_XT + lane] = f1_;                                                               \
+      }                                                                                                  \
+    } else {                                                                                             \
+      SK_FAST_PACK_OUT()                                                                                 \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
+        SK_FAST_SKEW_FRAME(q_, r.x1, r.x2, r.y1, r.y2)                                                   \
+        SK_FAST_SKEW_FRAME(q_ + 1, r.x2, r.x1, r.y2, r.y1)                                               \
+      }                                                                                                  \
+      SK_FAST_REPACK()                                                                                   \
+    }                                                                                                    \
+    pend_j = (J);                                                                                        \
+  }
 // eight steady frames of a tame wave of a global-table bank through the table window
 #define SK_FAST_WIN_BLOCK_(J, STALL_, RAMP_, NOISE_)                                                                  \
   {                                                                                                      \
@@ -427,7 +500,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
   // the reduction tile of the 8-frame blocks (8 * SK_XT floats): LDS-table banks keep it in the same per-wave region
   // (no windows there), global-table banks behind the four windows
   float *xt = TAB_LDS ? win : reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + 4 * (SK_WIN * 64) + wave * (8 * SK_XT);
-  (void)win; (void)xt;
+  // (extended LDS-table instantiation, a.fm_skew) the wave's sample ring of the skewed blocks, behind the four tiles
+  float *ring = reinterpret_cast<float *>(wsum + 4 * SK_CHUNK) + 4 * (8 * SK_XT) + wave * SK_SKEW_RING;
+  (void)win; (void)xt; (void)ring;
   const int bid = (int)blockIdx.x - a.wg_shift;        // row of the partial mix; -1: the gain workgroup (sk_finish_block)
   if (bid < 0) { sk_finish_block(a, bid, tid, SK_GROUP, reinterpret_cast<int *>(lds)); return; }
 
@@ -593,6 +668,22 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     (void)fm_only; (void)half_span;
     const bool loz = __all(dead || r.lo == 0.0f);     // (wave-uniform) no lane has a loop window: fast_advance<LOZ>
     (void)loz;
+    // skewed blocks (SK_FAST_SKEW_STEP): which lanes are modulators, and whether this wave qualifies
+    bool is_mod = false, skew_ok = false, skewed = false;
+    int fm_src = lane;
+    float prev7 = 0.0f;
+    if (STOPS && TAB_LDS && a.fm_skew && fm_only) {
+      SK_FAST_WAVE_SYNC()
+      ring[lane] = 0.0f;
+      SK_FAST_WAVE_SYNC()
+      if (r.fm_addr >= 0) ring[r.fm_addr >> 2] = 1.0f;
+      SK_FAST_WAVE_SYNC()
+      is_mod = ring[lane] != 0.0f;
+      SK_FAST_WAVE_SYNC()
+      if (r.fm_addr >= 0) fm_src = r.fm_addr >> 2;
+      skew_ok = a.num_frames >= 32 && !__any(is_mod && (!silent || r.fm_addr >= 0));
+    }
+    (void)is_mod; (void)skew_ok; (void)skewed; (void)fm_src; (void)prev7;
 
     bool moved = false;                               // (wave-uniform) some chunk of this pass had an envelope in motion
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
@@ -676,7 +767,28 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         } else if (fm_only && !stems_on) {
           int pend_j = -1;
           SK_FAST_PACK_IN()
-          for (; j + 8 <= cn; j += 8) SK_FAST_FM_BLOCK(j)
+          if (TAB_LDS && skew_ok) {
+            for (; j + 8 <= cn; j += 8) {
+              if (!skewed) {                 // the first skewed step of the pass: the modulators' lead block
+                prev7 = __int_as_float(__builtin_amdgcn_ds_bpermute(fm_src << 2, __float_as_int(r.sample)));   // voice_sample[m] as the frame before left it
+                SK_FAST_WAVE_SYNC()
+                if (is_mod) SK_FAST_SKEW_LEAD()
+                skewed = true;
+              }
+              if (c0 + j + 16 > a.num_frames) {   // the last whole block of the launch: the modulators have rendered it already
+                const float p_ = r.phase, g_ = r.sgain, sm_ = r.sample, h_ = r.hold;
+                const int hc_ = r.hold_count;
+                const v2f xs_ = xx, ys_ = yy;
+                SK_FAST_SKEW_STEP(j)
+                if (is_mod) { r.phase = p_; r.sgain = g_; r.sample = sm_; r.hold = h_; r.hold_count = hc_; xx = xs_; yy = ys_; }
+                skewed = false;
+              } else {
+                SK_FAST_SKEW_STEP(j)
+              }
+            }
+          } else {
+            for (; j + 8 <= cn; j += 8) SK_FAST_FM_BLOCK(j)
+          }
           SK_FAST_LDS_FLUSH()
           SK_FAST_PACK_OUT()
         } else {
@@ -816,6 +928,13 @@ extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, 
   // window's 5 KB per wave as well: 12 KB per workgroup that cost banks with 32 KB of tables their third workgroup per CU)
   lds_bytes += (size_t)4 * (8 * SK_XT) * sizeof(float);
   if (args->lds_table_floats == 0) lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);
+  sk_render_args_t skew_args;    /* the skewed blocks' sample rings, where they fit under the 64 KB a launch may ask for */
+  if (args->fm_skew) {
+    skew_args = *args;
+    if (tab_lds && lds_bytes + (size_t)4 * SK_SKEW_RING * sizeof(float) <= 65536) lds_bytes += (size_t)4 * SK_SKEW_RING * sizeof(float);
+    else skew_args.fm_skew = 0;
+    args = &skew_args;
+  }
   dim3 grid((unsigned)(n_workgroups + args->wg_shift)), block(SK_GROUP);
   const int key = (((args->fast_mode & (SKM_STOPS | SKM_FM | SKM_MIXED)) || args->pack_shift < 6) ? 16 : 0) |   /* the extended instantiation */ (tab_lds ? 8 : 0) | ((args->fast_mode & SKM_FILTER_ALL) ? 4 : 0) |
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp != 0 ? 1 : 0);

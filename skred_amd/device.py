@@ -275,6 +275,10 @@ class DeviceBank:
         """SKRED_OPT_PACK: 1 sparse banks rendered with packed lanes where it pays (default), 0 never, 2 whenever a wavefront disappears."""
         _check(self.L.skred_bank_set_option(self.h, 9, int(mode)), "skred_bank_set_option")
 
+    def set_fm_skew(self, on: int) -> None:
+        """SKRED_OPT_FM_SKEW: 1 (default) modulator lanes of a frequency-modulated wavefront run a block ahead of their carriers, 0 per-frame exchange."""
+        _check(self.L.skred_bank_set_option(self.h, 10, int(on)), "skred_bank_set_option")
+
     def last_pack(self) -> int:
         """Lanes per 64-voice group in the latest block, 0: not packed."""
         return int(self.L.skred_bank_last_pack(self.h))

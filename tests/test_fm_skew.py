@@ -1,0 +1,180 @@
+"""Skewed blocks of frequency-modulated wavefronts (SKRED_OPT_FM_SKEW, skred_render_fast.hip: SK_FAST_SKEW_STEP).
+
+The shipped patches write frequency modulation as `v0 ... F3,1` with the modulator ABOVE its carriers (3.sk, 0.sk): the carrier
+reads voice_sample[m] of the previous frame (synth.c:548-555).  On the one-voice-per-lane kernel the modulator lanes of such a
+wavefront run one 8-frame block ahead of their carriers and hand their samples over through an LDS ring, instead of one
+ds_bpermute exchange per frame.  Checked here, bit for bit:
+
+  * state after every launch and per-voice samples of every frame (probe rows written from inside the blocks) against the oracle,
+    with ragged block lengths (the skew must be taken back before the frames behind the last whole block), launches too short
+    for it, envelopes that only become steady in the middle of a launch (the skew starts there), wild modulation depths (a
+    step whose tameness vote fails takes the general frames with the ring's samples), modulators switched off between launches,
+    sample & hold on carriers and modulators, linear lookup;
+  * wavefronts that must NOT be skewed (an audible modulator, a modulator that is itself modulated) next to ones that are;
+  * the mix of the skewed form equals the mix of the per-frame exchange to the last bit (same products, same tile sums).
+"""
+import numpy as np
+import pytest
+
+import golden_io as gio
+from oracle import cpuref
+from skred_amd import banks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from skred_amd import device
+    assert device.load().skred_amd_device_count() > 0, "no GPU visible"
+    return device
+
+
+def rel_rms(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(np.sqrt(np.mean(b ** 2)), 1e-30))
+
+
+def fm_bank(recipe, n, wild_every=0, hold=False):
+    """3.sk's shape over a recipe bank: voices 4k, 4k+1, 4k+2 are carriers of the muted voice 4k+3."""
+    bank, tables, g = banks.RECIPES[recipe](n)
+    v = np.arange(n)
+    car = v[v % 4 != 3]
+    mod = (car // 4) * 4 + 3
+    bank["voice_freq_mod_osc"][car] = mod
+    bank["voice_freq_mod_depth"][car] = (np.float32(0.02) * (1 + (car % 13))).astype(np.float32)      # tame
+    bank["voice_freq_scale"][car] = (np.float32(0.5) + np.float32(0.01) * (car % 50)).astype(np.float32)
+    bank["voice_disconnect"][v[v % 4 == 3]] = 1                                                      # `m1`
+    if wild_every:                         # whole 64-voice groups with deep modulation: increments negative / beyond half a loop
+        w = car[(car // 64) % wild_every == 0]
+        bank["voice_freq_mod_depth"][w] = (np.float32(1.5) * (1 + (w % 7))).astype(np.float32)
+    if hold:                               # sample & hold / bit-crush on some carriers and some modulators
+        bank["voice_sample_hold_max"][v[v % 24 == 1]] = 5
+        bank["voice_sample_hold_max"][v[v % 40 == 3]] = 3
+        bank["voice_quantize"][v[v % 36 == 2]] = 6
+    return bank, tables, g
+
+
+def run(dev, bank, tables, g, interp, segments, skew, probe_ids=None):
+    import torch
+    db = dev.DeviceBank(bank.n)
+    db.set_tables(tables)
+    host = bank.copy()
+    db.upload(host)
+    db.set_globals(g)
+    db.set_fm_skew(skew)
+    fmax = max(f for f, _ in segments)
+    buf = None
+    if probe_ids is not None:
+        buf = torch.zeros(fmax * len(probe_ids) * 2, device="cuda")
+        db.set_probe(probe_ids, buf.data_ptr())
+    mixes, probes, kernels = [], [], []
+    for frames, event in segments:
+        if event is not None:
+            db.download(host)
+            event(host, db.get_globals().synth_sample_count)
+            db.upload(host)
+        if buf is not None:
+            buf.zero_()
+        out = torch.zeros(frames, 2, device="cuda")
+        db.render_mix(frames, out.data_ptr(), 2, 0, interp)
+        torch.cuda.synchronize()
+        mixes.append(out.cpu().numpy())
+        kernels.append(db.last_kernel())
+        if buf is not None:
+            probes.append(buf[:frames * len(probe_ids) * 2].cpu().numpy().reshape(frames, len(probe_ids), 2).copy())
+    db.download(host)
+    if buf is not None:
+        db.set_probe([], 0)
+    db.close()
+    return np.concatenate(mixes), host, probes, kernels
+
+
+def oracle(bank, tables, g, interp, segments, probe_ids=None):
+    host, gl = bank.copy(), g.copy()
+    mixes, stems = [], []
+    for frames, event in segments:
+        if event is not None:
+            event(host, gl.synth_sample_count)
+        r = cpuref.render(host, gl, tables, frames, interp, want_stems=probe_ids is not None)
+        mixes.append(cpuref.master(gl, r["sum64"].astype(np.float32)))
+        if probe_ids is not None:
+            stems.append(r["stems"][:, probe_ids, :].copy())
+    return np.concatenate(mixes), host, stems
+
+
+def _release_some(host, now):
+    host["voice_amp_envelope"]["sample_release"][2::5] = now          # amp_envelope_release, synth.c:391-395
+
+
+def _kill_some_modulators(host, now):
+    host["voice_amp"][3::28] = 0.0                                      # skipped from now on: voice_sample = 0 (synth.c:537-541)
+
+
+def _probe_ids(n):
+    rng = np.random.default_rng(5)
+    return np.unique(np.concatenate([[0, 1, 2, 4, 62, 64, 65, n - 4, n - 3, n - 2], rng.choice(n, 60, replace=False)]))[:64].astype(np.int32)
+
+
+SEGS = [(300, None), (257, _release_some), (31, None), (40, _kill_some_modulators), (520, None), (64, None), (36, None)]
+
+
+@pytest.mark.parametrize("recipe,interp,wild,hold", [("c2", 0, 0, False), ("c2", 0, 3, True), ("c2", 1, 4, False), ("c1", 0, 2, True)])
+def test_skewed_blocks_state_probes_and_mix(dev, recipe, interp, wild, hold):
+    n = 4096
+    bank, tables, g = fm_bank(recipe, n, wild, hold)
+    bank["voice_amp"][8:12] = 0.0                      # a copy that is off altogether, a copy whose modulator alone is off
+    bank["voice_amp"][19] = 0.0
+    ids = _probe_ids(n)
+    ref_mix, ref_state, ref_stems = oracle(bank, tables, g, interp, SEGS, ids)
+    res = {}
+    for skew in (1, 0):
+        mix, state, probes, kernels = run(dev, bank, tables, g, interp, SEGS, skew, ids)
+        assert kernels == [1] * len(SEGS), kernels
+        bad = state.rw_equal(ref_state)
+        assert not bad, (skew, bad)
+        for k, (got, want) in enumerate(zip(probes, ref_stems)):
+            d = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+            assert len(d) == 0, f"skew={skew} launch {k}: {len(d)} probed values differ; first (frame, probe, ch) {d[0]}, voice {ids[d[0][1]]}: {got[tuple(d[0])]} vs {want[tuple(d[0])]}"
+        assert rel_rms(mix, ref_mix) <= 1e-5
+        res[skew] = mix
+    assert gio.bits_equal(res[1], res[0]), "skewed blocks and per-frame exchange: same products, same sums"
+
+
+def test_waves_that_must_not_be_skewed(dev):
+    """An audible modulator (its (L, R) belong to the frame it is on), a modulator that is frequency-modulated itself (a chain:
+    7.sk's shape) and a carrier reading a modulator 40 lanes away, in three wavefronts of a bank whose other wavefronts are
+    skewed: every voice's state and samples against the oracle."""
+    n = 1024
+    bank, tables, g = fm_bank("c2", n)
+    bank["voice_disconnect"][64 + 7] = 0               # wave 1: one modulator is heard
+    bank["voice_freq_mod_osc"][128 + 11] = 128 + 15    # wave 2: modulator 11 takes modulator 15's sample
+    bank["voice_freq_mod_depth"][128 + 11] = np.float32(0.3)
+    bank["voice_freq_scale"][128 + 11] = np.float32(1.0)
+    bank["voice_freq_mod_osc"][192 + 1] = 192 + 43     # wave 3: still skewed, a far modulator
+    ids = np.unique(np.concatenate([np.arange(64, 80), np.arange(128 + 8, 128 + 16), [192, 193, 194, 195, 192 + 43], np.arange(0, 8)])).astype(np.int32)
+    segs = [(512, None), (100, None)]
+    ref_mix, ref_state, ref_stems = oracle(bank, tables, g, 0, segs, ids)
+    mix, state, probes, kernels = run(dev, bank, tables, g, 0, segs, 1, ids)
+    assert kernels == [1, 1]
+    assert not state.rw_equal(ref_state), state.rw_equal(ref_state)
+    for got, want in zip(probes, ref_stems):
+        assert gio.bits_equal(got, want)
+    assert rel_rms(mix, ref_mix) <= 1e-5
+
+
+def test_patch_3sk_bank_skewed_equals_exchange(dev):
+    """banks.bank_patch("3sk") at 2^16 voices, 512-frame blocks (tools/measure_banks `patches` at a sixteenth of its size): skewed
+    blocks against the per-frame exchange and the oracle."""
+    n = 1 << 16
+    bank, tables, g = banks.bank_patch("3sk", n)
+    segs = [(512, None), (512, None)]
+    ref_mix, ref_state, _ = oracle(bank, tables, g, 0, segs)
+    res = {}
+    for skew in (1, 0):
+        mix, state, _, kernels = run(dev, bank, tables, g, 0, segs, skew)
+        assert kernels == [1, 1]
+        assert not state.rw_equal(ref_state), (skew, state.rw_equal(ref_state))
+        assert rel_rms(mix, ref_mix) <= 1e-5
+        res[skew] = mix
+    assert gio.bits_equal(res[1], res[0])

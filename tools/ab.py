@@ -6,7 +6,7 @@ build, `tools/ab_libs.sh ab.py ...` runs it once per build under _ab/).  It repl
   steady   sustained banks of one recipe at several sizes:            --sizes c1:4096,c2:65536,...  [--split N] [--one-voice] [--interp I] [--f F]
   frames   one bank, several block lengths (per-frame + fixed cost):  --bank c2:65536 --lengths 64,256,512,2048
   live     a 2^20-voice C3 bank from its first frame, then under note traffic:  [--notes 104,524,5242] [--in-place M] [--voices N]
-  patch    reference patches tiled over a bank (banks.bank_patch):    [--patches 3sk,37sk,7sk,1sk,18sk] [--voices N]
+  patch    reference patches tiled over a bank (banks.bank_patch):    [--patches 3sk,37sk,7sk,1sk,18sk] [--voices N] [--fm-skew 0|1]
   fx       the fixed-point bank (fxbank.bank_fx) at several sizes, both lookups, with and without the biquad:  [--fx-sizes 65536,1048576]
   stamps   `steady` on a -DSKS_STAMPS build of the split kernel: what its waves recorded (cycles, waits, in-kernel clock)
 """
@@ -53,6 +53,7 @@ def open_bank(rec, n, a, bank=None):
     if a.split is not None: db.set_split(a.split)
     if a.in_place is not None: db.in_place(a.in_place)
     if a.pack is not None: db.set_pack(a.pack)
+    if a.fm_skew is not None: db.set_fm_skew(a.fm_skew)
     return db, b
 
 
@@ -140,7 +141,7 @@ def patch(a):
         out = torch.zeros(512, 2, device="cuda")
         settle(db, out, 512, 0, blocks=12)
         best, med = timed(lambda: db.render_mix(512, out.data_ptr(), 2, 0, 0), 40, 3)
-        print(f"patch {p:5s} tiled over {a.voices} voices: {best / 1e3:7.3f} ms per block (med {med / 1e3:7.3f}) kernel={db.last_kernel()} pack={db.last_pack()}  lib={LIB}", flush=True)
+        print(f"patch {p:5s} tiled over {a.voices} voices: {best / 1e3:7.3f} ms per block (med {med / 1e3:7.3f}) kernel={db.last_kernel()} pack={db.last_pack()} fm_skew={a.fm_skew}  lib={LIB}", flush=True)
         db.close()
 
 
@@ -180,6 +181,7 @@ def main():
     ap.add_argument("--mixed", action="store_true")
     ap.add_argument("--sparse", type=float, default=0.0)
     ap.add_argument("--pack", type=int, default=None)
+    ap.add_argument("--fm-skew", type=int, default=None)
     ap.add_argument("--patches", default="3sk,37sk,7sk,1sk,18sk")
     a = ap.parse_args()
     {"steady": steady, "stamps": steady, "frames": frames, "live": live, "patch": patch, "fx": fx}[a.scenario](a)

@@ -368,7 +368,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // frames for the whole wave: the lead block (modulators alone, EXEC-masked) opens the first skewed step of a pass, the last
 // whole block of the launch is rendered with the modulators' state put back afterwards (they have been there already).
 // Condition (skew_ok, per wave and pass): every modulator lane is silent (its (L, R) are zeros whatever frame it is on: the
-// tile rows stay those of the carriers' frames; no probe row) and is not frequency-modulated itself.  Same products and sums
+// tile rows stay those of the carriers' frames; no probe row) and is not frequency-modulated itself; no lane of the wave holds,
+// crushes or runs without its smoother (the steps carry no per-frame feature tests: one scheduling region per step).  Same products and sums
 // per voice as SK_FAST_FM_FRAME; a step whose vote fails takes the general frame with the ring's samples (fast_frame<EXTMS>).
 #define SK_SKEW_RING (8 * 64)    /* floats per wave */
 #define SK_FAST_SKEW_LEAD()                                                                              \
@@ -377,9 +378,9 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     SK_FAST_OSC8(s_)                                                                                     \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
       float u0_, u1_, w_;                                                                                \
-      fast_post_v<FILTER, ENV, false, STOPS, true, false>(r, pk, s_[q_], xx, yy, u0_, w_, xf);           \
+      fast_post_v<FILTER, ENV, false, STOPS, true, false>(r, pk, s_[q_], xx, yy, u0_, w_, 0);            \
       ring[q_ * 64 + lane] = u0_;                                                                        \
-      fast_post_v<FILTER, ENV, false, STOPS, false, false>(r, pk, s_[q_ + 1], xx, yy, u1_, w_, xf);      \
+      fast_post_v<FILTER, ENV, false, STOPS, false, false>(r, pk, s_[q_ + 1], xx, yy, u1_, w_, 0);       \
       ring[(q_ + 1) * 64 + lane] = u1_;                                                                  \
     }                                                                                                    \
   }
@@ -391,7 +392,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
     xt[(Q) * SK_XT + lane] = fold_lr(l, rr);                                                             \
   }
-#define SK_FAST_SKEW_STEP(J)                                                                             \
+/* LOZ_: no lane of the wave has a loop window (fast_advance<LOZ>); STALL_: no smoother of the wave moves any more (per chunk).
+   The vote: an increment in [+0, span/2] is, as an unsigned integer, at most the bits of span/2 (negative numbers carry the sign
+   bit, NaNs sit above every finite number), so the largest of the eight patterns decides for all of them. */
+#define SK_FAST_SKEW_STEP(J, LOZ_, STALL_)                                                               \
   {                                                                                                      \
     if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
     float mq_[8], inc_[8];          /* per frame of the step: the modulator's previous sample, the increment */ \
@@ -400,20 +404,20 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     _Pragma("unroll") for (int q_ = 1; q_ < 8; ++q_) mq_[q_] = ring[(q_ - 1) * 64 + fm_src];             \
     prev7 = ring[7 * 64 + fm_src];                                                                       \
     SK_FAST_WAVE_SYNC()                                                                                  \
-    bool ok_ = true;                                                                                     \
+    uint32_t top_ = 0u;                                                                                  \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                   \
       inc_[q_] = r.fm_addr >= 0 ? r.inc + r.fm_k * (mq_[q_] * r.fm_depth) : r.inc;      /* synth.c:551-554 */ \
-      ok_ = ok_ && inc_[q_] >= 0.0f && inc_[q_] <= half_span;                                            \
+      top_ = max(top_, __float_as_uint(inc_[q_]));                                                       \
     }                                                                                                    \
-    if (__all(ok_)) {                                                                                    \
+    if (__all(top_ <= __float_as_uint(half_span))) {                                                     \
       float s_[8];                                                                                       \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                   \
-        s_[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false>(r, inc_[q_])); \
+        s_[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false, LOZ_>(r, inc_[q_])); \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
         float s0_, s1_, u_, f0_, f1_;                                                                    \
-        fast_post_v<FILTER, ENV, false, STOPS, true, false>(r, pk, s_[q_], xx, yy, s0_, u_, xf);         \
+        fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, s_[q_], xx, yy, s0_, u_, 0);         \
         ring[q_ * 64 + lane] = s0_;                                                                      \
-        fast_post_v<FILTER, ENV, false, STOPS, false, false>(r, pk, s_[q_ + 1], xx, yy, s1_, u_, xf);    \
+        fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, s_[q_ + 1], xx, yy, s1_, u_, 0);    \
         ring[(q_ + 1) * 64 + lane] = s1_;                                                                \
         s0_ = silent ? 0.0f : s0_; s1_ = silent ? 0.0f : s1_;                                            \
         fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                          \
@@ -429,6 +433,24 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       SK_FAST_REPACK()                                                                                   \
     }                                                                                                    \
     pend_j = (J);                                                                                        \
+  }
+/* all whole blocks of a chunk: the lead block where the skew begins, the take-back on the last whole block of the LAUNCH (the
+   modulators have rendered it already: their recurrences are put back behind the step) */
+#define SK_FAST_SKEW_CHUNK(LOZ_, STALL_)                                                                 \
+  for (; j + 8 <= cn; j += 8) {                                                                          \
+    if (!skewed) {                                                                                       \
+      prev7 = __int_as_float(__builtin_amdgcn_ds_bpermute(fm_src << 2, __float_as_int(r.sample)));   /* voice_sample[m] as the frame before left it */ \
+      SK_FAST_WAVE_SYNC()                                                                                \
+      if (is_mod) SK_FAST_SKEW_LEAD()                                                                    \
+      skewed = true;                                                                                     \
+    }                                                                                                    \
+    const float p_ = r.phase, g_ = r.sgain, sm_ = r.sample;                                              \
+    const v2f xs_ = xx, ys_ = yy;                                                                        \
+    SK_FAST_SKEW_STEP(j, LOZ_, STALL_)                                                                   \
+    if (c0 + j + 16 > a.num_frames) {                                                                    \
+      if (is_mod) { r.phase = p_; r.sgain = g_; r.sample = sm_; xx = xs_; yy = ys_; }                    \
+      skewed = false;                                                                                    \
+    }                                                                                                    \
   }
 // eight steady frames of a tame wave of a global-table bank through the table window
 #define SK_FAST_WIN_BLOCK_(J, STALL_, RAMP_, NOISE_)                                                                  \
@@ -681,7 +703,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       is_mod = ring[lane] != 0.0f;
       SK_FAST_WAVE_SYNC()
       if (r.fm_addr >= 0) fm_src = r.fm_addr >> 2;
-      skew_ok = a.num_frames >= 32 && !__any(is_mod && (!silent || r.fm_addr >= 0));
+      skew_ok = a.num_frames >= 32 && (xf & (XF_HOLDQ | XF_NOSMOOTH)) == 0 && !__any(is_mod && (!silent || r.fm_addr >= 0));
     }
     (void)is_mod; (void)skew_ok; (void)skewed; (void)fm_src; (void)prev7;
 
@@ -768,24 +790,9 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
           int pend_j = -1;
           SK_FAST_PACK_IN()
           if (TAB_LDS && skew_ok) {
-            for (; j + 8 <= cn; j += 8) {
-              if (!skewed) {                 // the first skewed step of the pass: the modulators' lead block
-                prev7 = __int_as_float(__builtin_amdgcn_ds_bpermute(fm_src << 2, __float_as_int(r.sample)));   // voice_sample[m] as the frame before left it
-                SK_FAST_WAVE_SYNC()
-                if (is_mod) SK_FAST_SKEW_LEAD()
-                skewed = true;
-              }
-              if (c0 + j + 16 > a.num_frames) {   // the last whole block of the launch: the modulators have rendered it already
-                const float p_ = r.phase, g_ = r.sgain, sm_ = r.sample, h_ = r.hold;
-                const int hc_ = r.hold_count;
-                const v2f xs_ = xx, ys_ = yy;
-                SK_FAST_SKEW_STEP(j)
-                if (is_mod) { r.phase = p_; r.sgain = g_; r.sample = sm_; r.hold = h_; r.hold_count = hc_; xx = xs_; yy = ys_; }
-                skewed = false;
-              } else {
-                SK_FAST_SKEW_STEP(j)
-              }
-            }
+            const bool stall_ = fast_smoother_stalled<ENV>(r);
+            if (loz) { if (stall_) SK_FAST_SKEW_CHUNK(true, true) else SK_FAST_SKEW_CHUNK(true, false) }
+            else { if (stall_) SK_FAST_SKEW_CHUNK(false, true) else SK_FAST_SKEW_CHUNK(false, false) }
           } else {
             for (; j + 8 <= cn; j += 8) SK_FAST_FM_BLOCK(j)
           }

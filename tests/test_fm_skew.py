@@ -9,8 +9,9 @@ ds_bpermute exchange per frame.  Checked here, bit for bit:
     with ragged block lengths (the skew must be taken back before the frames behind the last whole block), launches too short
     for it, envelopes that only become steady in the middle of a launch (the skew starts there), wild modulation depths (a
     step whose tameness vote fails takes the general frames with the ring's samples), modulators switched off between launches,
-    sample & hold on carriers and modulators, linear lookup;
-  * wavefronts that must NOT be skewed (an audible modulator, a modulator that is itself modulated) next to ones that are;
+    linear lookup;
+  * wavefronts that must NOT be skewed (an audible modulator, a modulator that is itself modulated, sample & hold or bit-crush
+    lanes) next to ones that are;
   * the mix of the skewed form equals the mix of the per-frame exchange to the last bit (same products, same tile sums).
 """
 import numpy as np
@@ -48,10 +49,11 @@ def fm_bank(recipe, n, wild_every=0, hold=False):
     if wild_every:                         # whole 64-voice groups with deep modulation: increments negative / beyond half a loop
         w = car[(car // 64) % wild_every == 0]
         bank["voice_freq_mod_depth"][w] = (np.float32(1.5) * (1 + (w % 7))).astype(np.float32)
-    if hold:                               # sample & hold / bit-crush on some carriers and some modulators
-        bank["voice_sample_hold_max"][v[v % 24 == 1]] = 5
-        bank["voice_sample_hold_max"][v[v % 40 == 3]] = 3
-        bank["voice_quantize"][v[v % 36 == 2]] = 6
+    if hold:                               # sample & hold / bit-crush on some carriers and some modulators of every third wavefront
+        h = (v // 64) % 3 == 1             # (such a wavefront keeps the per-frame exchange: the skewed steps carry no feature tests)
+        bank["voice_sample_hold_max"][v[h & (v % 24 == 1)]] = 5
+        bank["voice_sample_hold_max"][v[h & (v % 40 == 3)]] = 3
+        bank["voice_quantize"][v[h & (v % 36 == 2)]] = 6
     return bank, tables, g
 
 

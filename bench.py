@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--no-low-latency", action="store_true", help="(older name of --no-extra)")
     ap.add_argument("--no-fixed-point", action="store_true", help="skip the fixed-point leg")
     ap.add_argument("--no-scaling-proxy", action="store_true", help="skip the strong_scaling_proxy leg (shard blocks of 2^17 .. 2^19 voices)")
+    ap.add_argument("--no-patches", action="store_true", help="skip the shipped_patches leg (the reference's .sk patches tiled over the bank)")
     ap.add_argument("--no-event-calibration", action="store_true", help="report bracketed kernel times as read (no empty-pair correction)")
     ap.add_argument("--no-recipe-warmup", action="store_true",
                     help="skip the recipe's own 0.11 s of untimed rendering (to time launches with envelopes still ramping)")
@@ -674,6 +675,37 @@ def main():
                 if form + "_ms" in ent:
                     ent[form + "_speedup_if_collective_were_free"] = one / ent[form + "_ms"]
         res["strong_scaling_proxy"] = proxy
+
+    # ---- the reference's SHIPPED PATCHES tiled over a bank of the headline size (banks.bank_patch: the voice state the unmodified
+    # reference holds after loading the patch, repeated; routings of synth.c:548-558,584-587,597-602 -- a modulator shared by three
+    # carriers, frequency + amplitude + pan modulation, chains, sample & hold, a modulator BELOW its carrier).  Parity of exactly
+    # these banks: tests/test_patch_banks.py, tests/test_fm_skew.py.
+    if not a.no_extra and a.workload == "c3" and not a.no_patches:
+        pat = {"what": "ms per 512-frame block of a 2^20-voice bank made by tiling one of the reference's .sk patches; kernel 1: one voice per "
+                       "lane (previous-frame modulation: source lanes a block ahead of their readers, samples through an LDS ring -- "
+                       "SKRED_OPT_FM_SKEW), 2: the modulated kernel (same-frame dependencies); pack: lanes per 64-voice group when the "
+                       "bank is sparse (SKRED_OPT_PACK)", "banks": {}}
+        for pname in ("3sk", "1sk", "7sk", "37sk", "18sk"):
+            try:
+                pb, pt, pg = banks.bank_patch(pname, bank_voices)
+                pdb = device.DeviceBank(bank_voices, local)
+                pdb.set_tables(pt); pdb.upload(pb); pdb.set_globals(pg); pdb.kernel_timing(0)
+                pout = torch.zeros(512, 2, device=dev, dtype=torch.float32)
+
+                def pblk(frames, _db=pdb, _o=pout):
+                    _db.render_mix(frames, _o.data_ptr(), 2, 0, 0, stream)
+                for _ in range(12):
+                    pblk(512)
+                steps_q = max(20, a.steps)
+                dtq, _, _, _ = timed(pblk, pdb, 512, steps_q, 5, 0)
+                pat["banks"][pname] = {"ms_per_step": dtq / steps_q * 1e3, "value": bank_voices * 512 * steps_q / dtq, "unit": "voice-samples/s",
+                                       "kernel": int(pdb.last_kernel()), "pack": int(pdb.last_pack()),
+                                       "output_finite": bool(torch.isfinite(pout).all().item())}
+                pdb.close()
+                del pb
+            except Exception as ex:
+                pat["banks"][pname] = {"error": repr(ex)[:200]}
+        res["shipped_patches"] = pat
 
     # ---- the fixed-point LUT path (include/skred_amd_fxpt.h; integer mix, exact)
     if not a.no_extra and not a.no_fixed_point and a.workload != "c4":

@@ -439,25 +439,27 @@ __device__ __forceinline__ bool fast_smoother_stalled(const FastRegs &r) {
 // caller has set r.tf / r.trf to this frame's envelope clocks.
 // TAME: the caller has proved for every lane that lo <= phase <= hi and 0 <= inc <= span/2, which
 // by induction keeps phase+inc in [lo, hi + span/2]: the only wrap that can occur is the simple one.
-// EXTMS: the caller hands in the frequency modulator's previous sample (`ms_ext`: the skewed blocks of skred_render_fast.hip,
-// whose modulator lanes run a block ahead and leave their samples in an LDS ring) instead of the ds_bpermute exchange.
+// EXTMS: the caller hands in the modulators' previous samples (`ms_ext`, `am_ext`, `pm_ext`: the skewed blocks of
+// skred_render_fast.hip, whose modulator lanes run ahead and leave their samples in an LDS ring) instead of the ds_bpermute
+// exchange.
 template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false, bool EXTMS = false>
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r,
                                            const int xf = 0, const bool muted = false, const float white = 0.0f,
-                                           const float ms_ext = 0.0f) {
+                                           const float ms_ext = 0.0f, const float am_ext = 0.0f, const float pm_ext = 0.0f) {
   float inc = r.inc;
   if (STOPS && (xf & (XF_FM | XF_AP))) {                // wave-uniform: some lane of the wave is modulated
     // voice_sample[m] as the previous frame left it (a modulator that is skipped this frame holds exact zero)
     const int mine = __float_as_int(r.sample);
+    (void)mine;
     if (xf & XF_FM) {
       const float ms = EXTMS ? ms_ext : __int_as_float(__builtin_amdgcn_ds_bpermute(r.fm_addr, mine));
       if (r.fm_addr >= 0) inc = r.inc + r.fm_k * (ms * r.fm_depth);      // synth.c:551-554
     }
     if (xf & XF_AP) {
-      r.am_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.am_addr, 0), mine));
-      r.pm_prev = __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.pm_addr, 0), mine));
+      r.am_prev = EXTMS ? am_ext : __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.am_addr, 0), mine));
+      r.pm_prev = EXTMS ? pm_ext : __int_as_float(__builtin_amdgcn_ds_bpermute(max(r.pm_addr, 0), mine));
     }
   }
   if (STOPS && (xf & XF_REV) && r.rev) inc = -inc;      // reverse playback, applied to the modulated increment

@@ -357,59 +357,84 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     }                                                                                                    \
     pend_j = (J);                                                                                        \
   }
-// ---- skewed blocks (round 4, SKRED_OPT_FM_SKEW): the same frequency modulation WITHOUT a per-frame exchange ----
-// The modulator of such a patch (`v3 w0 f5 a5 m1`) is itself unmodulated, so nothing it renders depends on its carriers: the
-// per-frame ds_bpermute above only exists because all lanes of a wave walk the frames in lock step.  Here the modulator lanes
-// of the wave run ONE 8-FRAME BLOCK AHEAD of the other lanes: in every step a modulator renders frames J+8 .. J+15 and leaves
-// its eight voice_sample values in the wave's LDS ring (ring[q][lane]), a carrier renders frames J .. J+7 from the eight values
-// the previous step left there (plus `prev7`, the last one of the step before: frame J's increment takes the sample of frame
-// J-1, synth.c:551).  A carrier's eight increments are known at the top of its step, so its oscillator runs eight gathers deep
-// like a clean bank's and the tameness vote is one per block.  Ahead and behind lanes meet again before anything that counts
-// frames for the whole wave: the lead block (modulators alone, EXEC-masked) opens the first skewed step of a pass, the last
-// whole block of the launch is rendered with the modulators' state put back afterwards (they have been there already).
-// Condition (skew_ok, per wave and pass): every modulator lane is silent (its (L, R) are zeros whatever frame it is on: the
-// tile rows stay those of the carriers' frames; no probe row) and is not frequency-modulated itself; no lane of the wave holds,
-// crushes or runs without its smoother (the steps carry no per-frame feature tests: one scheduling region per step).  Same products and sums
-// per voice as SK_FAST_FM_FRAME; a step whose vote fails takes the general frame with the ring's samples (fast_frame<EXTMS>).
+// ---- skewed blocks (round 4, SKRED_OPT_FM_SKEW): previous-frame modulation WITHOUT a per-frame exchange ----
+// The modulators of the shipped patches (`v3 w0 f5 a5 m1`) are heard by nobody and read nobody below them, so nothing they
+// render depends on their carriers: the per-frame ds_bpermute of SK_FAST_FM_FRAME / fast_frame only exists because all lanes of a
+// wave walk the frames in lock step.  Here a lane that is read by others runs 8-FRAME BLOCKS AHEAD of them: `lead` blocks,
+// one more than every lane that reads it (3.sk, 1.sk, 37.sk: modulators 1, carriers 0; 7.sk's chain v2 -> v1 -> v0: 2, 1, 0).
+// In every step a lane renders the block `lead` ahead of the step's and leaves its eight voice_sample values in the wave's LDS
+// ring (ring[q][lane]); a reader takes, at the top of its step, the eight values its source left there in the step before --
+// exactly the block it is about to render -- plus the carried last value of the block before (`prev7*`: frame q's increment,
+// gain and pan take the modulator's sample of frame q - 1, synth.c:551,586,599).  All of a step's modulation is known at its
+// top: the oscillators run eight gathers deep and the tameness vote is one per block.  The lanes meet again before anything
+// that counts frames for the whole wave: EXEC-masked lead-in steps open the first skewed step of a pass (the deepest sources
+// first), and on the launch's last whole blocks a lane that has rendered them already gets its recurrences put back behind
+// the step (`lead > blocks left`).
+// Condition (skew_ok, per wave and pass): every lane that is read by another is silent (its (L, R) are zeros whatever frame it
+// is on, so the tile rows stay those of the audible lanes' frames; no probe row), every source is exactly one block ahead of
+// each of its readers, chains at most SK_SKEW_LMAX deep, geometry tame, no reverse / noise / stopping / smoother-off lanes.
+// Two forms: LEAN (only frequency modulation, one level: the pair-register chain of the plain blocks, no per-frame feature
+// tests) and RICH (amplitude / pan modulation, sample & hold, chains: fast_frame itself with the ring's samples handed in).
+// Same products and sums per voice as the exchange forms; a step whose vote fails takes the general frames.
 #define SK_SKEW_RING (8 * 64)    /* floats per wave */
-#define SK_FAST_SKEW_LEAD()                                                                              \
-  {                                                                                                      \
-    float s_[8];                                                                                         \
-    SK_FAST_OSC8(s_)                                                                                     \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
-      float u0_, u1_, w_;                                                                                \
-      fast_post_v<FILTER, ENV, false, STOPS, true, false>(r, pk, s_[q_], xx, yy, u0_, w_, 0);            \
-      ring[q_ * 64 + lane] = u0_;                                                                        \
-      fast_post_v<FILTER, ENV, false, STOPS, false, false>(r, pk, s_[q_ + 1], xx, yy, u1_, w_, 0);       \
-      ring[(q_ + 1) * 64 + lane] = u1_;                                                                  \
-    }                                                                                                    \
-  }
-#define SK_FAST_SKEW_FRAME(Q, XN, XO, YN, YO)                                                            \
+#define SK_SKEW_LMAX 3
+#define SK_FAST_SKEW_RFRAME(Q, TAME_, XN, XO, YN, YO, TILE_)                                             \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast_frame<TAB_LDS, FILTER, ENV, true, false, INTERP, STOPS, true>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, 0.0f, mq_[Q]); \
+    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP, STOPS, true>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, 0.0f, mq_[Q], aq_[Q], pq_[Q]); \
     ring[(Q) * 64 + lane] = r.sample;                                                                    \
-    l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                      \
-    xt[(Q) * SK_XT + lane] = fold_lr(l, rr);                                                             \
+    if (TILE_) {                                                                                         \
+      l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                    \
+      xt[(Q) * SK_XT + lane] = fold_lr(l, rr);                                                           \
+    }                                                                                                    \
   }
-/* LOZ_: no lane of the wave has a loop window (fast_advance<LOZ>); STALL_: no smoother of the wave moves any more (per chunk).
-   The vote: an increment in [+0, span/2] is, as an unsigned integer, at most the bits of span/2 (negative numbers carry the sign
-   bit, NaNs sit above every finite number), so the largest of the eight patterns decides for all of them. */
-#define SK_FAST_SKEW_STEP(J, LOZ_, STALL_)                                                               \
-  {                                                                                                      \
-    if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
-    float mq_[8], inc_[8];          /* per frame of the step: the modulator's previous sample, the increment */ \
+/* the top of a step: this block's modulator samples (frame q takes the source's sample of frame q - 1) and the vote.  An
+   increment in [+0, span/2] is, as an unsigned integer, at most the bits of span/2 (negative numbers carry the sign bit, NaNs
+   sit above every finite number), so the largest of the eight patterns decides for all of them. */
+#define SK_FAST_SKEW_TOP(AP_)                                                                            \
+    float mq_[8], aq_[8], pq_[8];                                                                        \
     SK_FAST_WAVE_SYNC()                                                                                  \
-    mq_[0] = prev7;                                                                                      \
-    _Pragma("unroll") for (int q_ = 1; q_ < 8; ++q_) mq_[q_] = ring[(q_ - 1) * 64 + fm_src];             \
+    mq_[0] = prev7; aq_[0] = prev7a; pq_[0] = prev7p;                                                    \
+    _Pragma("unroll") for (int q_ = 1; q_ < 8; ++q_) {                                                   \
+      mq_[q_] = ring[(q_ - 1) * 64 + fm_src];                                                            \
+      aq_[q_] = (AP_) ? ring[(q_ - 1) * 64 + am_src] : 0.0f;                                             \
+      pq_[q_] = (AP_) ? ring[(q_ - 1) * 64 + pm_src] : 0.0f;                                             \
+    }                                                                                                    \
     prev7 = ring[7 * 64 + fm_src];                                                                       \
+    if (AP_) { prev7a = ring[7 * 64 + am_src]; prev7p = ring[7 * 64 + pm_src]; }                         \
     SK_FAST_WAVE_SYNC()                                                                                  \
+    float inc_[8];                                                                                       \
     uint32_t top_ = 0u;                                                                                  \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                   \
       inc_[q_] = r.fm_addr >= 0 ? r.inc + r.fm_k * (mq_[q_] * r.fm_depth) : r.inc;      /* synth.c:551-554 */ \
       top_ = max(top_, __float_as_uint(inc_[q_]));                                                       \
     }                                                                                                    \
-    if (__all(top_ <= __float_as_uint(half_span))) {                                                     \
+    const bool tame_ = __all(top_ <= __float_as_uint(half_span));                                        \
+    (void)aq_; (void)pq_;
+#define SK_FAST_SKEW_GENERAL(TILE_)                                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
+      SK_FAST_SKEW_RFRAME(q_, false, r.x1, r.x2, r.y1, r.y2, TILE_)                                      \
+      SK_FAST_SKEW_RFRAME(q_ + 1, false, r.x2, r.x1, r.y2, r.y1, TILE_)                                  \
+    }
+/* RICH step (delay line in r.x1 ...): fast_frame on both sides of the vote */
+#define SK_FAST_SKEW_RSTEP(J, TILE_)                                                                     \
+  {                                                                                                      \
+    if (TILE_) { if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j) }                                          \
+    SK_FAST_SKEW_TOP((xf & XF_AP) != 0)                                                                  \
+    if (tame_ && (TILE_)) {           /* (the lead-in steps run once per pass: the general frames only) */ \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
+        SK_FAST_SKEW_RFRAME(q_, true, r.x1, r.x2, r.y1, r.y2, TILE_)                                     \
+        SK_FAST_SKEW_RFRAME(q_ + 1, true, r.x2, r.x1, r.y2, r.y1, TILE_)                                 \
+      }                                                                                                  \
+    } else {                                                                                             \
+      SK_FAST_SKEW_GENERAL(TILE_)                                                                        \
+    }                                                                                                    \
+    if (TILE_) pend_j = (J);                                                                             \
+  }
+/* LEAN step (delay line in the register pairs xx / yy).  LOZ_: no lane of the wave has a loop window (fast_advance<LOZ>);
+   STALL_: no smoother of the wave moves any more (per chunk) */
+#define SK_FAST_SKEW_LEAN_BODY(LOZ_, STALL_)                                                             \
+    {                                                                                                    \
       float s_[8];                                                                                       \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                   \
         s_[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false, LOZ_>(r, inc_[q_])); \
@@ -424,32 +449,45 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
         xt[q_ * SK_XT + lane] = f0_;                                                                     \
         xt[(q_ + 1) * SK_XT + lane] = f1_;                                                               \
       }                                                                                                  \
+    }
+#define SK_FAST_SKEW_STEP(J)                                                                             \
+  {                                                                                                      \
+    if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
+    SK_FAST_SKEW_TOP(false)                                                                              \
+    if (tame_) {                                                                                         \
+      if (loz) { if (stall_) SK_FAST_SKEW_LEAN_BODY(true, true) else SK_FAST_SKEW_LEAN_BODY(true, false) } \
+      else { if (stall_) SK_FAST_SKEW_LEAN_BODY(false, true) else SK_FAST_SKEW_LEAN_BODY(false, false) } \
     } else {                                                                                             \
       SK_FAST_PACK_OUT()                                                                                 \
-      _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
-        SK_FAST_SKEW_FRAME(q_, r.x1, r.x2, r.y1, r.y2)                                                   \
-        SK_FAST_SKEW_FRAME(q_ + 1, r.x2, r.x1, r.y2, r.y1)                                               \
-      }                                                                                                  \
+      SK_FAST_SKEW_GENERAL(true)                                                                         \
       SK_FAST_REPACK()                                                                                   \
     }                                                                                                    \
     pend_j = (J);                                                                                        \
   }
-/* all whole blocks of a chunk: the lead block where the skew begins, the take-back on the last whole block of the LAUNCH (the
-   modulators have rendered it already: their recurrences are put back behind the step) */
-#define SK_FAST_SKEW_CHUNK(LOZ_, STALL_)                                                                 \
-  for (; j + 8 <= cn; j += 8) {                                                                          \
-    if (!skewed) {                                                                                       \
-      prev7 = __int_as_float(__builtin_amdgcn_ds_bpermute(fm_src << 2, __float_as_int(r.sample)));   /* voice_sample[m] as the frame before left it */ \
-      SK_FAST_WAVE_SYNC()                                                                                \
-      if (is_mod) SK_FAST_SKEW_LEAD()                                                                    \
-      skewed = true;                                                                                     \
+/* where the skew begins: the carried samples (voice_sample[m] as the frame before left it), then the lead-in steps -- the
+   lanes that must be `s_` blocks ahead render a block on their own, the deepest sources first */
+#define SK_FAST_SKEW_BEGIN()                                                                             \
+  {                                                                                                      \
+    const int mine_ = __float_as_int(r.sample);                                                          \
+    prev7 = __int_as_float(__builtin_amdgcn_ds_bpermute(fm_src << 2, mine_));                            \
+    prev7a = __int_as_float(__builtin_amdgcn_ds_bpermute(am_src << 2, mine_));                           \
+    prev7p = __int_as_float(__builtin_amdgcn_ds_bpermute(pm_src << 2, mine_));                           \
+    for (int s_ = lmax; s_ >= 1; --s_) {                                                                 \
+      if (lead >= s_) SK_FAST_SKEW_RSTEP(0, false)                                                       \
     }                                                                                                    \
-    const float p_ = r.phase, g_ = r.sgain, sm_ = r.sample;                                              \
-    const v2f xs_ = xx, ys_ = yy;                                                                        \
-    SK_FAST_SKEW_STEP(j, LOZ_, STALL_)                                                                   \
-    if (c0 + j + 16 > a.num_frames) {                                                                    \
-      if (is_mod) { r.phase = p_; r.sgain = g_; r.sample = sm_; xx = xs_; yy = ys_; }                    \
-      skewed = false;                                                                                    \
+    skewed = true;                                                                                       \
+  }
+/* all whole blocks of a chunk.  A lane `lead` blocks ahead has rendered the launch's last `lead` whole blocks already: behind
+   those steps its recurrences (and what it carries of its own sources) are put back */
+#define SK_FAST_SKEW_CHUNK(STEP_, BEGIN_)                                                                \
+  for (; j + 8 <= cn; j += 8) {                                                                          \
+    if (!skewed) BEGIN_                                                                                  \
+    const int left_ = ((a.num_frames - (c0 + j)) >> 3) - 1;        /* whole blocks of the launch behind this one */ \
+    SK_SKEW_SAVE()                                                                                       \
+    STEP_                                                                                                \
+    if (left_ < lmax) {                                                                                  \
+      if (lead > left_) SK_SKEW_RESTORE()                                                                \
+      if (left_ == 0) skewed = false;                                                                    \
     }                                                                                                    \
   }
 // eight steady frames of a tame wave of a global-table bank through the table window
@@ -690,22 +728,37 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     (void)fm_only; (void)half_span;
     const bool loz = __all(dead || r.lo == 0.0f);     // (wave-uniform) no lane has a loop window: fast_advance<LOZ>
     (void)loz;
-    // skewed blocks (SK_FAST_SKEW_STEP): which lanes are modulators, and whether this wave qualifies
-    bool is_mod = false, skew_ok = false, skewed = false;
-    int fm_src = lane;
-    float prev7 = 0.0f;
-    if (STOPS && TAB_LDS && a.fm_skew && fm_only) {
-      SK_FAST_WAVE_SYNC()
-      ring[lane] = 0.0f;
-      SK_FAST_WAVE_SYNC()
-      if (r.fm_addr >= 0) ring[r.fm_addr >> 2] = 1.0f;
-      SK_FAST_WAVE_SYNC()
-      is_mod = ring[lane] != 0.0f;
-      SK_FAST_WAVE_SYNC()
+    // skewed blocks (SK_FAST_SKEW_STEP / _RSTEP): every lane's lead, and whether this wave qualifies
+    int lead = 0, lmax = 0;
+    bool skew_ok = false, skew_lean = false, skewed = false;
+    int fm_src = lane, am_src = lane, pm_src = lane;       // the lane whose ring column this lane reads (its own: none)
+    float prev7 = 0.0f, prev7a = 0.0f, prev7p = 0.0f;
+    if (STOPS && TAB_LDS && a.fm_skew && tame_geom && a.num_frames >= 32 && (xf & (XF_FM | XF_AP)) && (xf & ~(XF_FM | XF_AP | XF_HOLDQ)) == 0) {
       if (r.fm_addr >= 0) fm_src = r.fm_addr >> 2;
-      skew_ok = a.num_frames >= 32 && (xf & (XF_HOLDQ | XF_NOSMOOTH)) == 0 && !__any(is_mod && (!silent || r.fm_addr >= 0));
+      if (r.am_addr >= 0) am_src = r.am_addr >> 2;
+      if (r.pm_addr >= 0) pm_src = r.pm_addr >> 2;
+      const bool self_fm = r.fm_addr >= 0 && fm_src == lane;
+      int *lead_w = reinterpret_cast<int *>(ring);          // (row 0 of the ring, as 64 words)
+      SK_FAST_WAVE_SYNC()
+      lead_w[lane] = 0;
+      SK_FAST_WAVE_SYNC()
+      for (int it = 0; it <= SK_SKEW_LMAX; ++it) {         // a source runs one block ahead of every lane that reads it
+        const int mine_ = lead_w[lane];
+        SK_FAST_WAVE_SYNC()
+        if (fm_src != lane) atomicMax(&lead_w[fm_src], mine_ + 1);
+        if (am_src != lane) atomicMax(&lead_w[am_src], mine_ + 1);
+        if (pm_src != lane) atomicMax(&lead_w[pm_src], mine_ + 1);
+        SK_FAST_WAVE_SYNC()
+      }
+      lead = lead_w[lane];
+      const int lf_ = lead_w[fm_src], la_ = lead_w[am_src], lp_ = lead_w[pm_src];
+      SK_FAST_WAVE_SYNC()
+      const bool edges_ = (fm_src == lane || lf_ == lead + 1) && (am_src == lane || la_ == lead + 1) && (pm_src == lane || lp_ == lead + 1);
+      skew_ok = __all(edges_ && !self_fm && lead <= SK_SKEW_LMAX && (lead == 0 || silent));
+      lmax = __any(lead >= 3) ? 3 : __any(lead >= 2) ? 2 : __any(lead >= 1) ? 1 : 0;
+      skew_lean = skew_ok && xf == XF_FM && lmax == 1;
     }
-    (void)is_mod; (void)skew_ok; (void)skewed; (void)fm_src; (void)prev7;
+    (void)lead; (void)lmax; (void)skew_ok; (void)skew_lean; (void)skewed; (void)fm_src; (void)am_src; (void)pm_src; (void)prev7; (void)prev7a; (void)prev7p;
 
     bool moved = false;                               // (wave-uniform) some chunk of this pass had an envelope in motion
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
@@ -713,6 +766,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
       // a stopping voice that cannot reach its table end within this chunk (forward, unmodulated: phase + 64*inc,
       // rounding included, stays below it) needs no per-frame finish test yet
       const bool stop_near = STOPS && any_stop && __any(r.stop && !(r.phase + (float)SK_CHUNK * r.inc + 2.0f < r.hi));
+      // skewed blocks in this chunk: under way already, or enough whole blocks left for every lead (a lane `lead` blocks ahead
+      // renders `lead` blocks in the lead-in steps)
+      const bool skew_now = skew_ok && (skewed || lmax <= ((a.num_frames - c0) >> 3));
+      (void)skew_now;
       const int xf_blk = xf;                          // the feature mask the block paths test per frame (shadowed by a literal 0
       (void)xf_blk;                                   //  where a wave has nothing to test: one scheduling region per block)
       FastEnv ev_;                                    // (RAMPK) envelopes in motion on the block paths; per chunk
@@ -786,18 +843,34 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
             else for (; j + 8 <= cn; j += 8) SK_FAST_WIN_BLOCK(j, false)
           }
           SK_FAST_PACK_OUT()
+        } else if (TAB_LDS && skew_now && !skew_lean && !stems_on) {    // skewed blocks, RICH form
+          int pend_j = -1;
+#define SK_SKEW_SAVE() const float p_ = r.phase, g_ = r.sgain, sm_ = r.sample, h_ = r.hold, x1_ = r.x1, x2_ = r.x2, y1_ = r.y1, y2_ = r.y2, \
+                                   c7_ = prev7, c7a_ = prev7a, c7p_ = prev7p; const int hc_ = r.hold_count;
+#define SK_SKEW_RESTORE() { r.phase = p_; r.sgain = g_; r.sample = sm_; r.hold = h_; r.hold_count = hc_; r.x1 = x1_; r.x2 = x2_; r.y1 = y1_; r.y2 = y2_; \
+                            prev7 = c7_; prev7a = c7a_; prev7p = c7p_; }
+          SK_FAST_SKEW_CHUNK(SK_FAST_SKEW_RSTEP(j, true), SK_FAST_SKEW_BEGIN())
+#undef SK_SKEW_SAVE
+#undef SK_SKEW_RESTORE
+          SK_FAST_LDS_FLUSH()
         } else if (fm_only && !stems_on) {
           int pend_j = -1;
-          SK_FAST_PACK_IN()
-          if (TAB_LDS && skew_ok) {
+          if (TAB_LDS && skew_now && skew_lean) {                     // skewed blocks, LEAN form
             const bool stall_ = fast_smoother_stalled<ENV>(r);
-            if (loz) { if (stall_) SK_FAST_SKEW_CHUNK(true, true) else SK_FAST_SKEW_CHUNK(true, false) }
-            else { if (stall_) SK_FAST_SKEW_CHUNK(false, true) else SK_FAST_SKEW_CHUNK(false, false) }
+            SK_FAST_PACK_IN()
+#define SK_SKEW_SAVE() const float p_ = r.phase, g_ = r.sgain, sm_ = r.sample, c7_ = prev7; const v2f xs_ = xx, ys_ = yy;
+#define SK_SKEW_RESTORE() { r.phase = p_; r.sgain = g_; r.sample = sm_; prev7 = c7_; xx = xs_; yy = ys_; }
+            SK_FAST_SKEW_CHUNK(SK_FAST_SKEW_STEP(j), { SK_FAST_PACK_OUT() SK_FAST_SKEW_BEGIN() SK_FAST_REPACK() })
+#undef SK_SKEW_SAVE
+#undef SK_SKEW_RESTORE
+            SK_FAST_LDS_FLUSH()
+            SK_FAST_PACK_OUT()
           } else {
+            SK_FAST_PACK_IN()
             for (; j + 8 <= cn; j += 8) SK_FAST_FM_BLOCK(j)
+            SK_FAST_LDS_FLUSH()
+            SK_FAST_PACK_OUT()
           }
-          SK_FAST_LDS_FLUSH()
-          SK_FAST_PACK_OUT()
         } else {
           int pend_j = -1;
           for (; j + 8 <= cn; j += 8) SK_FAST_X_BLOCK(j)

@@ -10,8 +10,9 @@ ds_bpermute exchange per frame.  Checked here, bit for bit:
     for it, envelopes that only become steady in the middle of a launch (the skew starts there), wild modulation depths (a
     step whose tameness vote fails takes the general frames with the ring's samples), modulators switched off between launches,
     linear lookup;
-  * wavefronts that must NOT be skewed (an audible modulator, a modulator that is itself modulated, sample & hold or bit-crush
-    lanes) next to ones that are;
+  * chains (7.sk: v2 -> v1 -> v0, the head two blocks ahead), amplitude and pan modulation from other voices and from the voice
+    itself, sample & hold and bit-crush (the RICH form: fast_frame with the ring's samples handed in);
+  * wavefronts that must NOT be skewed (an audible modulator, a source read by lanes of different leads) next to ones that are;
   * the mix of the skewed form equals the mix of the per-frame exchange to the last bit (same products, same tile sums).
 """
 import numpy as np
@@ -144,9 +145,9 @@ def test_skewed_blocks_state_probes_and_mix(dev, recipe, interp, wild, hold):
 
 
 def test_waves_that_must_not_be_skewed(dev):
-    """An audible modulator (its (L, R) belong to the frame it is on), a modulator that is frequency-modulated itself (a chain:
-    7.sk's shape) and a carrier reading a modulator 40 lanes away, in three wavefronts of a bank whose other wavefronts are
-    skewed: every voice's state and samples against the oracle."""
+    """An audible modulator (its (L, R) belong to the frame it is on), a modulator read by lanes of different leads (by three
+    carriers AND by another modulator: it cannot be one block ahead of all of them) and a carrier reading a modulator 40 lanes
+    away, in three wavefronts of a bank whose other wavefronts are skewed: every voice's state and samples against the oracle."""
     n = 1024
     bank, tables, g = fm_bank("c2", n)
     bank["voice_disconnect"][64 + 7] = 0               # wave 1: one modulator is heard
@@ -165,11 +166,71 @@ def test_waves_that_must_not_be_skewed(dev):
     assert rel_rms(mix, ref_mix) <= 1e-5
 
 
-def test_patch_3sk_bank_skewed_equals_exchange(dev):
-    """banks.bank_patch("3sk") at 2^16 voices, 512-frame blocks (tools/measure_banks `patches` at a sixteenth of its size): skewed
+def mod_bank(recipe, n, wild_every=0):
+    """The shipped patches' richer routings over a recipe bank, in copies of four voices.  Even copies, 7.sk's shape: v0 F1 P3,
+    v1 F2 m1, v2 m1, v3 m1 -- a chain (v2 two blocks ahead, v1 and v3 one).  Odd copies, 1.sk's / 37.sk's shape: v0 F3 A2 P1
+    (frequency, amplitude and pan modulation from three muted voices), some of them with sample & hold and bit-crush, some
+    modulating their own amplitude or pan (synth.c:584-587,597-602: the voice's own sample of THIS frame)."""
+    bank, tables, g = banks.RECIPES[recipe](n)
+    v = np.arange(n)
+    c = v[v % 4 == 0]
+    even, odd = c[(c // 4) % 2 == 0], c[(c // 4) % 2 == 1]
+    bank["voice_disconnect"][v[v % 4 != 0]] = 1
+    bank["voice_freq_scale"][v] = (np.float32(0.5) + np.float32(0.01) * (v % 50)).astype(np.float32)
+    bank["voice_freq_mod_osc"][even] = even + 1
+    bank["voice_freq_mod_depth"][even] = (np.float32(0.03) * (1 + (even % 11))).astype(np.float32)
+    bank["voice_pan_mod_osc"][even] = even + 3
+    bank["voice_pan_mod_depth"][even] = np.float32(0.7)
+    bank["voice_freq_mod_osc"][even + 1] = even + 2
+    bank["voice_freq_mod_depth"][even + 1] = np.float32(0.2)
+    bank["voice_freq_mod_osc"][odd] = odd + 3
+    bank["voice_freq_mod_depth"][odd] = (np.float32(0.02) * (1 + (odd % 9))).astype(np.float32)
+    bank["voice_amp_mod_osc"][odd] = odd + 2
+    bank["voice_amp_mod_depth"][odd] = np.float32(1.5)
+    bank["voice_pan_mod_osc"][odd] = odd + 1
+    bank["voice_pan_mod_depth"][odd] = np.float32(0.9)
+    bank["voice_sample_hold_max"][odd[::3]] = 5
+    bank["voice_quantize"][odd[1::5]] = 5
+    bank["voice_sample_hold_max"][odd[::7] + 3] = 4                    # a modulator that holds
+    self_am = odd[2::9]
+    bank["voice_amp_mod_osc"][self_am] = self_am
+    self_pm = even[3::8]
+    bank["voice_pan_mod_osc"][self_pm] = self_pm
+    if wild_every:
+        w = c[(c // 64) % wild_every == 0]
+        bank["voice_freq_mod_depth"][w] = (np.float32(2.0) * (1 + (w % 5))).astype(np.float32)
+    return bank, tables, g
+
+
+@pytest.mark.parametrize("recipe,interp,wild", [("c2", 0, 0), ("c2", 1, 3), ("c1", 0, 2)])
+def test_rich_skewed_blocks_chains_amp_pan_hold(dev, recipe, interp, wild):
+    n = 4096
+    bank, tables, g = mod_bank(recipe, n, wild)
+    bank["voice_amp"][16:20] = 0.0
+    bank["voice_amp"][27] = 0.0                        # one source of a 1.sk-shaped copy is off
+    bank["voice_amp"][34] = 0.0                        # the head of a chain is off
+    ids = np.unique(np.concatenate([np.arange(0, n, 4)[:: n // 4 // 56], [0, 4, 8, 12, 24, 32, n - 4, n - 8]])).astype(np.int32)[:64]
+    ref_mix, ref_state, ref_stems = oracle(bank, tables, g, interp, SEGS, ids)
+    res = {}
+    for skew in (1, 0):
+        mix, state, probes, kernels = run(dev, bank, tables, g, interp, SEGS, skew, ids)
+        assert kernels == [1] * len(SEGS), kernels
+        bad = state.rw_equal(ref_state)
+        assert not bad, (skew, bad)
+        for k, (got, want) in enumerate(zip(probes, ref_stems)):
+            d = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+            assert len(d) == 0, f"skew={skew} launch {k}: {len(d)} probed values differ; first (frame, probe, ch) {d[0]}, voice {ids[d[0][1]]}: {got[tuple(d[0])]} vs {want[tuple(d[0])]}"
+        assert rel_rms(mix, ref_mix) <= 1e-5
+        res[skew] = mix
+    assert gio.bits_equal(res[1], res[0])
+
+
+@pytest.mark.parametrize("patch", ["3sk", "1sk", "7sk", "37sk"])
+def test_patch_bank_skewed_equals_exchange(dev, patch):
+    """banks.bank_patch(...) at 2^16 voices, 512-frame blocks (tools/measure_banks `patches` at a sixteenth of its size): skewed
     blocks against the per-frame exchange and the oracle."""
     n = 1 << 16
-    bank, tables, g = banks.bank_patch("3sk", n)
+    bank, tables, g = banks.bank_patch(patch, n)
     segs = [(512, None), (512, None)]
     ref_mix, ref_state, _ = oracle(bank, tables, g, 0, segs)
     res = {}

@@ -364,8 +364,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // one more than every lane that reads it (3.sk, 1.sk, 37.sk: modulators 1, carriers 0; 7.sk's chain v2 -> v1 -> v0: 2, 1, 0).
 // In every step a lane renders the block `lead` ahead of the step's and leaves its eight voice_sample values in the wave's LDS
 // ring (ring[q][lane]); a reader takes, at the top of its step, the eight values its source left there in the step before --
-// exactly the block it is about to render -- plus the carried last value of the block before (`prev7*`: frame q's increment,
-// gain and pan take the modulator's sample of frame q - 1, synth.c:551,586,599).  All of a step's modulation is known at its
+// exactly the block it is about to render -- plus, from row 8, the last value of the block before (frame q's increment, gain
+// and pan take the modulator's sample of frame q - 1, synth.c:551,586,599).  All of a step's modulation is known at its
 // top: the oscillators run eight gathers deep and the tameness vote is one per block.  The lanes meet again before anything
 // that counts frames for the whole wave: EXEC-masked lead-in steps open the first skewed step of a pass (the deepest sources
 // first), and on the launch's last whole blocks a lane that has rendered them already gets its recurrences put back behind
@@ -376,13 +376,21 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // Two forms: LEAN (only frequency modulation, one level: the pair-register chain of the plain blocks, no per-frame feature
 // tests) and RICH (amplitude / pan modulation, sample & hold, chains: fast_frame itself with the ring's samples handed in).
 // Same products and sums per voice as the exchange forms; a step whose vote fails takes the general frames.
-#define SK_SKEW_RING (8 * 64)    /* floats per wave */
+#define SK_SKEW_RING (9 * 64)    /* floats per wave: rows 0..7 the lanes' samples of their latest block, row 8 the last sample of the block
+                                    before it (what frame 0 of a reader's block takes).  (A tenth row cost 3.sk's bank -- 32 KB of
+                                    tables -- its third workgroup per CU: 0.38 -> 0.52 ms; the leads live in the pad floats of
+                                    the reduction tile's rows, a byte per lane: SK_SKEW_LEAD) */
+#define SK_SKEW_LEAD() (reinterpret_cast<unsigned char *>(xt + (lane >> 4) * SK_XT + 64 + ((lane >> 2) & 3))[lane & 3])
+#define SK_SKEW_COL(ADDR_) ((ADDR_) >= 0 ? ((ADDR_) >> 2) : lane)   /* the ring column a lane reads: its source's, or (unused) its own */
 #define SK_SKEW_LMAX 3
 #define SK_FAST_SKEW_RFRAME(Q, TAME_, XN, XO, YN, YO, TILE_)                                             \
   {                                                                                                      \
     float l, rr;                                                                                         \
-    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP, STOPS, true>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, 0.0f, mq_[Q], aq_[Q], pq_[Q]); \
-    ring[(Q) * 64 + lane] = r.sample;                                                                    \
+    /* (amplitude / pan sources: read when the frame needs them -- nobody writes the ring before the end of the step) */ \
+    const float aq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.am_addr)];        \
+    const float pq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.pm_addr)];        \
+    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP, STOPS, true>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, 0.0f, mq_[Q], aq_, pq_); \
+    own_[Q] = r.sample;                                                                                  \
     if (TILE_) {                                                                                         \
       l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                    \
       xt[(Q) * SK_XT + lane] = fold_lr(l, rr);                                                           \
@@ -391,18 +399,14 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 /* the top of a step: this block's modulator samples (frame q takes the source's sample of frame q - 1) and the vote.  An
    increment in [+0, span/2] is, as an unsigned integer, at most the bits of span/2 (negative numbers carry the sign bit, NaNs
    sit above every finite number), so the largest of the eight patterns decides for all of them. */
-#define SK_FAST_SKEW_TOP(AP_)                                                                            \
-    float mq_[8], aq_[8], pq_[8];                                                                        \
+#define SK_FAST_SKEW_TOP()                                                                               \
+    float mq_[8];                                                                                        \
     SK_FAST_WAVE_SYNC()                                                                                  \
-    mq_[0] = prev7; aq_[0] = prev7a; pq_[0] = prev7p;                                                    \
-    _Pragma("unroll") for (int q_ = 1; q_ < 8; ++q_) {                                                   \
-      mq_[q_] = ring[(q_ - 1) * 64 + fm_src];                                                            \
-      aq_[q_] = (AP_) ? ring[(q_ - 1) * 64 + am_src] : 0.0f;                                             \
-      pq_[q_] = (AP_) ? ring[(q_ - 1) * 64 + pm_src] : 0.0f;                                             \
+    {                                                                                                    \
+      const float *col_ = ring + SK_SKEW_COL(r.fm_addr);                                                 \
+      mq_[0] = col_[8 * 64];                                                                             \
+      _Pragma("unroll") for (int q_ = 1; q_ < 8; ++q_) mq_[q_] = col_[(q_ - 1) * 64];                    \
     }                                                                                                    \
-    prev7 = ring[7 * 64 + fm_src];                                                                       \
-    if (AP_) { prev7a = ring[7 * 64 + am_src]; prev7p = ring[7 * 64 + pm_src]; }                         \
-    SK_FAST_WAVE_SYNC()                                                                                  \
     float inc_[8];                                                                                       \
     uint32_t top_ = 0u;                                                                                  \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                   \
@@ -410,24 +414,31 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       top_ = max(top_, __float_as_uint(inc_[q_]));                                                       \
     }                                                                                                    \
     const bool tame_ = __all(top_ <= __float_as_uint(half_span));                                        \
-    (void)aq_; (void)pq_;
-#define SK_FAST_SKEW_GENERAL(TILE_)                                                                      \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                                \
-      SK_FAST_SKEW_RFRAME(q_, false, r.x1, r.x2, r.y1, r.y2, TILE_)                                      \
-      SK_FAST_SKEW_RFRAME(q_ + 1, false, r.x2, r.x1, r.y2, r.y1, TILE_)                                  \
+    (void)inc_;
+/* the general frames of a step (delay line in r.x1 ...); the lane's own eight samples go to the ring when every lane of the wave
+   has read what it needs of this step */
+#define SK_FAST_SKEW_FRAMES(TAME_, TILE_)                                                                \
+    {                                                                                                    \
+      const bool ap_ = (xf & XF_AP) != 0;                                                                \
+      float own_[8];                                                                                     \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
+        SK_FAST_SKEW_RFRAME(q_, TAME_, r.x1, r.x2, r.y1, r.y2, TILE_)                                    \
+        SK_FAST_SKEW_RFRAME(q_ + 1, TAME_, r.x2, r.x1, r.y2, r.y1, TILE_)                                \
+      }                                                                                                  \
+      const float old7_ = ring[7 * 64 + lane];                                                           \
+      SK_FAST_WAVE_SYNC()                                                                                \
+      ring[8 * 64 + lane] = old7_;                                                                       \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) ring[q_ * 64 + lane] = own_[q_];                  \
     }
 /* RICH step (delay line in r.x1 ...): fast_frame on both sides of the vote */
 #define SK_FAST_SKEW_RSTEP(J, TILE_)                                                                     \
   {                                                                                                      \
     if (TILE_) { if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j) }                                          \
-    SK_FAST_SKEW_TOP((xf & XF_AP) != 0)                                                                  \
+    SK_FAST_SKEW_TOP()                                                                                   \
     if (tame_ && (TILE_)) {           /* (the lead-in steps run once per pass: the general frames only) */ \
-      _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
-        SK_FAST_SKEW_RFRAME(q_, true, r.x1, r.x2, r.y1, r.y2, TILE_)                                     \
-        SK_FAST_SKEW_RFRAME(q_ + 1, true, r.x2, r.x1, r.y2, r.y1, TILE_)                                 \
-      }                                                                                                  \
+      SK_FAST_SKEW_FRAMES(true, TILE_)                                                                   \
     } else {                                                                                             \
-      SK_FAST_SKEW_GENERAL(TILE_)                                                                        \
+      SK_FAST_SKEW_FRAMES(false, TILE_)                                                                  \
     }                                                                                                    \
     if (TILE_) pend_j = (J);                                                                             \
   }
@@ -436,6 +447,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_SKEW_LEAN_BODY(LOZ_, STALL_)                                                             \
     {                                                                                                    \
       float s_[8];                                                                                       \
+      ring[8 * 64 + lane] = ring[7 * 64 + lane];      /* (the lane's own column: readers took row 8 at the top) */ \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                   \
         s_[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false, LOZ_>(r, inc_[q_])); \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
@@ -453,41 +465,75 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_FAST_SKEW_STEP(J)                                                                             \
   {                                                                                                      \
     if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j)                                                         \
-    SK_FAST_SKEW_TOP(false)                                                                              \
+    SK_FAST_SKEW_TOP()                                                                                   \
+    SK_FAST_WAVE_SYNC()                                                                                  \
     if (tame_) {                                                                                         \
       if (loz) { if (stall_) SK_FAST_SKEW_LEAN_BODY(true, true) else SK_FAST_SKEW_LEAN_BODY(true, false) } \
       else { if (stall_) SK_FAST_SKEW_LEAN_BODY(false, true) else SK_FAST_SKEW_LEAN_BODY(false, false) } \
     } else {                                                                                             \
       SK_FAST_PACK_OUT()                                                                                 \
-      SK_FAST_SKEW_GENERAL(true)                                                                         \
+      SK_FAST_SKEW_FRAMES(false, true)                                                                   \
       SK_FAST_REPACK()                                                                                   \
     }                                                                                                    \
     pend_j = (J);                                                                                        \
   }
-/* where the skew begins: the carried samples (voice_sample[m] as the frame before left it), then the lead-in steps -- the
-   lanes that must be `s_` blocks ahead render a block on their own, the deepest sources first */
+/* where the skew begins: row 8 takes voice_sample as the frame before left it, then the lead-in steps -- the lanes that must be
+   `s_` blocks ahead render a block on their own, the deepest sources first */
 #define SK_FAST_SKEW_BEGIN()                                                                             \
   {                                                                                                      \
-    const int mine_ = __float_as_int(r.sample);                                                          \
-    prev7 = __int_as_float(__builtin_amdgcn_ds_bpermute(fm_src << 2, mine_));                            \
-    prev7a = __int_as_float(__builtin_amdgcn_ds_bpermute(am_src << 2, mine_));                           \
-    prev7p = __int_as_float(__builtin_amdgcn_ds_bpermute(pm_src << 2, mine_));                           \
+    SK_FAST_WAVE_SYNC()                                                                                  \
+    ring[8 * 64 + lane] = r.sample;       /* what frame 0 of a reader's first block takes ... */           \
+    ring[7 * 64 + lane] = r.sample;       /* ... also where a lane's first flush looks for it (row 7 -> row 8) */ \
+    SK_FAST_WAVE_SYNC()                                                                                  \
     for (int s_ = lmax; s_ >= 1; --s_) {                                                                 \
-      if (lead >= s_) SK_FAST_SKEW_RSTEP(0, false)                                                       \
+      if ((int)SK_SKEW_LEAD() >= s_) SK_FAST_SKEW_RSTEP(0, false)                                        \
     }                                                                                                    \
     skewed = true;                                                                                       \
   }
-/* all whole blocks of a chunk.  A lane `lead` blocks ahead has rendered the launch's last `lead` whole blocks already: behind
-   those steps its recurrences (and what it carries of its own sources) are put back */
-#define SK_FAST_SKEW_CHUNK(STEP_, BEGIN_)                                                                \
+/* all whole blocks of a chunk.  A lane `lead` blocks ahead has rendered the launch's last `lead` whole blocks already: its state
+   is final when the step `lead` blocks before the end begins.  It goes to the state planes there (FREEZE: what the end of the
+   pass stores), the lane keeps running on numbers nobody reads (silent; its ring column has no reader left), and behind the last
+   step it loads its state again (THAW) -- no registers held across the steps for this. */
+#define SK_FAST_SKEW_FREEZE()                                                                            \
+  if ((int)SK_SKEW_LEAD() == left_ + 1 && !dead) {                                                       \
+    uint4 s0, s1;                                                                                        \
+    s0.x = __float_as_uint(r.phase); s0.y = __float_as_uint(r.sgain);                                    \
+    s0.z = __float_as_uint(r.filt ? r.x1 : r.ox1); s0.w = __float_as_uint(r.filt ? r.x2 : r.ox2);        \
+    s1.x = __float_as_uint(r.filt ? r.y1 : r.oy1); s1.y = __float_as_uint(r.filt ? r.y2 : r.oy2);        \
+    s1.z = __float_as_uint(r.sample); s1.w = r.rw;                                                       \
+    *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;                                                  \
+    *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;                                                 \
+    if (r.hold_max) *reinterpret_cast<uint2 *>(&a.rw[SKS_MISC][v]) = make_uint2(__float_as_uint(r.hold), (uint32_t)r.hold_count); \
+  }
+#define SK_FAST_SKEW_THAW()                                                                              \
+  {                                                                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                               \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                               \
+    if (SK_SKEW_LEAD() > 0 && !dead) {                                                                   \
+      const uint4 s0 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_OSC][v]);                     \
+      const uint4 s1 = *reinterpret_cast<const uint4 *>(&a.rw[SKS_FILT][v]);                    \
+      r.phase = __uint_as_float(s0.x); r.sgain = __uint_as_float(s0.y);                                  \
+      r.x1 = __uint_as_float(s0.z);    r.x2 = __uint_as_float(s0.w);                                     \
+      r.y1 = __uint_as_float(s1.x);    r.y2 = __uint_as_float(s1.y);                                     \
+      r.sample = __uint_as_float(s1.z);                                                                  \
+      if (r.hold_max) {                                                                                  \
+        const uint2 s2 = *reinterpret_cast<const uint2 *>(&a.rw[SKS_MISC][v]);                  \
+        r.hold = __uint_as_float(s2.x); r.hold_count = (int)s2.y;                                        \
+      }                                                                                                  \
+    }                                                                                                    \
+  }
+/* OUT_ / IN_: the LEAN form keeps the delay line in the register pairs xx / yy around the steps (SK_FAST_PACK_OUT / _REPACK) */
+#define SK_FAST_SKEW_CHUNK(STEP_, OUT_, IN_)                                                             \
   for (; j + 8 <= cn; j += 8) {                                                                          \
-    if (!skewed) BEGIN_                                                                                  \
+    if (!skewed) { OUT_ SK_FAST_SKEW_BEGIN() IN_ }                                                       \
     const int left_ = ((a.num_frames - (c0 + j)) >> 3) - 1;        /* whole blocks of the launch behind this one */ \
-    SK_SKEW_SAVE()                                                                                       \
+    if (left_ < lmax) { OUT_ SK_FAST_SKEW_FREEZE() }                                                     \
     STEP_                                                                                                \
-    if (left_ < lmax) {                                                                                  \
-      if (lead > left_) SK_SKEW_RESTORE()                                                                \
-      if (left_ == 0) skewed = false;                                                                    \
+    if (left_ == 0) {                                                                                    \
+      OUT_                                                                                               \
+      SK_FAST_SKEW_THAW()                                                                                \
+      IN_                                                                                                \
+      skewed = false;                                                                                    \
     }                                                                                                    \
   }
 // eight steady frames of a tame wave of a global-table bank through the table window
@@ -543,7 +589,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // PROBE: the same kernel compiled with -DSK_PROBE_TU (fast_post / fast_post_v then also write the probe rows of
 // skred_bank_set_probe): a template parameter only so that those instantiations are symbols of their own.
 template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS, bool RAMPK = false, bool PROBE = false>
-__global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES : SK_FAST_MIN_WAVES) : (STOPS ? SK_FAST_WIN_EXT_MIN_WAVES : SK_FAST_WIN_MIN_WAVES)) void sk_render_fast_kernel(const sk_render_args_t a) {
+// (the extended LDS-table instantiation WITHOUT biquad and envelope, truncating lookup -- what every shipped patch but 18.sk runs on -- needs 129
+// registers, three of them holding spilled SGPRs: bounded to 128 it keeps four waves per SIMD where the pool leaves room for
+// four workgroups per CU -- 7.sk, 16 KB of tables: 1.29 -> 1.00 ms)
+__global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? ((FILTER || ENV || INTERP != 0) ? SK_FAST_EXT_MIN_WAVES : 4) : SK_FAST_MIN_WAVES) : (STOPS ? SK_FAST_WIN_EXT_MIN_WAVES : SK_FAST_WIN_MIN_WAVES)) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
   const char *lds_tab = reinterpret_cast<const char *>(lds);
@@ -729,14 +778,10 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
     const bool loz = __all(dead || r.lo == 0.0f);     // (wave-uniform) no lane has a loop window: fast_advance<LOZ>
     (void)loz;
     // skewed blocks (SK_FAST_SKEW_STEP / _RSTEP): every lane's lead, and whether this wave qualifies
-    int lead = 0, lmax = 0;
+    int lmax = 0;
     bool skew_ok = false, skew_lean = false, skewed = false;
-    int fm_src = lane, am_src = lane, pm_src = lane;       // the lane whose ring column this lane reads (its own: none)
-    float prev7 = 0.0f, prev7a = 0.0f, prev7p = 0.0f;
     if (STOPS && TAB_LDS && a.fm_skew && tame_geom && a.num_frames >= 32 && (xf & (XF_FM | XF_AP)) && (xf & ~(XF_FM | XF_AP | XF_HOLDQ)) == 0) {
-      if (r.fm_addr >= 0) fm_src = r.fm_addr >> 2;
-      if (r.am_addr >= 0) am_src = r.am_addr >> 2;
-      if (r.pm_addr >= 0) pm_src = r.pm_addr >> 2;
+      const int fm_src = SK_SKEW_COL(r.fm_addr), am_src = SK_SKEW_COL(r.am_addr), pm_src = SK_SKEW_COL(r.pm_addr);
       const bool self_fm = r.fm_addr >= 0 && fm_src == lane;
       int *lead_w = reinterpret_cast<int *>(ring);          // (row 0 of the ring, as 64 words)
       SK_FAST_WAVE_SYNC()
@@ -750,15 +795,17 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
         if (pm_src != lane) atomicMax(&lead_w[pm_src], mine_ + 1);
         SK_FAST_WAVE_SYNC()
       }
-      lead = lead_w[lane];
+      const int lead = lead_w[lane];
       const int lf_ = lead_w[fm_src], la_ = lead_w[am_src], lp_ = lead_w[pm_src];
       SK_FAST_WAVE_SYNC()
       const bool edges_ = (fm_src == lane || lf_ == lead + 1) && (am_src == lane || la_ == lead + 1) && (pm_src == lane || lp_ == lead + 1);
       skew_ok = __all(edges_ && !self_fm && lead <= SK_SKEW_LMAX && (lead == 0 || silent));
       lmax = __any(lead >= 3) ? 3 : __any(lead >= 2) ? 2 : __any(lead >= 1) ? 1 : 0;
+      SK_SKEW_LEAD() = (unsigned char)lead;
+      SK_FAST_WAVE_SYNC()
       skew_lean = skew_ok && xf == XF_FM && lmax == 1;
     }
-    (void)lead; (void)lmax; (void)skew_ok; (void)skew_lean; (void)skewed; (void)fm_src; (void)am_src; (void)pm_src; (void)prev7; (void)prev7a; (void)prev7p;
+    (void)lmax; (void)skew_ok; (void)skew_lean; (void)skewed;
 
     bool moved = false;                               // (wave-uniform) some chunk of this pass had an envelope in motion
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
@@ -845,24 +892,14 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? SK_FAST_EXT_MIN_WAVES 
           SK_FAST_PACK_OUT()
         } else if (TAB_LDS && skew_now && !skew_lean && !stems_on) {    // skewed blocks, RICH form
           int pend_j = -1;
-#define SK_SKEW_SAVE() const float p_ = r.phase, g_ = r.sgain, sm_ = r.sample, h_ = r.hold, x1_ = r.x1, x2_ = r.x2, y1_ = r.y1, y2_ = r.y2, \
-                                   c7_ = prev7, c7a_ = prev7a, c7p_ = prev7p; const int hc_ = r.hold_count;
-#define SK_SKEW_RESTORE() { r.phase = p_; r.sgain = g_; r.sample = sm_; r.hold = h_; r.hold_count = hc_; r.x1 = x1_; r.x2 = x2_; r.y1 = y1_; r.y2 = y2_; \
-                            prev7 = c7_; prev7a = c7a_; prev7p = c7p_; }
-          SK_FAST_SKEW_CHUNK(SK_FAST_SKEW_RSTEP(j, true), SK_FAST_SKEW_BEGIN())
-#undef SK_SKEW_SAVE
-#undef SK_SKEW_RESTORE
+          SK_FAST_SKEW_CHUNK(SK_FAST_SKEW_RSTEP(j, true), , )
           SK_FAST_LDS_FLUSH()
         } else if (fm_only && !stems_on) {
           int pend_j = -1;
           if (TAB_LDS && skew_now && skew_lean) {                     // skewed blocks, LEAN form
             const bool stall_ = fast_smoother_stalled<ENV>(r);
             SK_FAST_PACK_IN()
-#define SK_SKEW_SAVE() const float p_ = r.phase, g_ = r.sgain, sm_ = r.sample, c7_ = prev7; const v2f xs_ = xx, ys_ = yy;
-#define SK_SKEW_RESTORE() { r.phase = p_; r.sgain = g_; r.sample = sm_; prev7 = c7_; xx = xs_; yy = ys_; }
-            SK_FAST_SKEW_CHUNK(SK_FAST_SKEW_STEP(j), { SK_FAST_PACK_OUT() SK_FAST_SKEW_BEGIN() SK_FAST_REPACK() })
-#undef SK_SKEW_SAVE
-#undef SK_SKEW_RESTORE
+            SK_FAST_SKEW_CHUNK(SK_FAST_SKEW_STEP(j), SK_FAST_PACK_OUT(), SK_FAST_REPACK())
             SK_FAST_LDS_FLUSH()
             SK_FAST_PACK_OUT()
           } else {
@@ -1011,7 +1048,9 @@ extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, 
   sk_render_args_t skew_args;    /* the skewed blocks' sample rings, where they fit under the 64 KB a launch may ask for */
   if (args->fm_skew) {
     skew_args = *args;
-    if (tab_lds && lds_bytes + (size_t)4 * SK_SKEW_RING * sizeof(float) <= 65536) lds_bytes += (size_t)4 * SK_SKEW_RING * sizeof(float);
+    /* (beyond the 64 KB a launch gets by default the kernel's limit is raised below; up to half a CU's LDS, so that a bank with a
+       48 KB pool keeps its two workgroups per CU) */
+    if (tab_lds && lds_bytes + (size_t)4 * SK_SKEW_RING * sizeof(float) <= 81920) lds_bytes += (size_t)4 * SK_SKEW_RING * sizeof(float);
     else skew_args.fm_skew = 0;
     args = &skew_args;
   }
@@ -1020,9 +1059,12 @@ extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, 
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp != 0 ? 1 : 0);
   const bool rampk = !args->skip_env2;   /* envelopes may be moving (skip_env2: a launch has reported that none did) */
   const bool guard = args->interp == 2;  /* linear lookup, every live voice on a guarded whole-table loop (SKF_GUARD; the host counts) */
+#define SK_FAST_BIG_LDS_(K)                                                                                                 \
+  if (lds_bytes > 65536) {   /* (per launch: the attribute belongs to the device the calling thread is on) */              \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) return (int)hipGetLastError(); }
 #define SK_FAST_LAUNCH_(T, F, E, I, X)                                                                                      \
-  { if (E && rampk) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, E, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args);   \
-    else hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, false, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args); }
+  { if (E && rampk) { SK_FAST_BIG_LDS_((sk_render_fast_kernel<T, F, E, I, X, E, SK_PROBE_FLAG>)) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, E, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args); }   \
+    else { SK_FAST_BIG_LDS_((sk_render_fast_kernel<T, F, E, I, X, false, SK_PROBE_FLAG>)) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, false, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args); } }
 #define SK_FAST_CASE(K, T, F, E, I)                                                                                        \
   case K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), false) else SK_FAST_LAUNCH_(T, F, E, I, false) break;      \
   case 16 + K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), true) else SK_FAST_LAUNCH_(T, F, E, I, true) break;

@@ -79,6 +79,9 @@ def run(dev, bank, tables, g, interp, segments, skew, probe_ids=None):
             db.upload(host)
         if buf is not None:
             buf.zero_()
+        # (other kernels' leftovers in LDS between our launches: the sample ring must not depend on what the previous launch of
+        # the same bank left in it -- an uninitialised row once happened to hold exactly the right numbers that way)
+        torch.sort(torch.rand(1 << 22, device="cuda"))
         out = torch.zeros(frames, 2, device="cuda")
         db.render_mix(frames, out.data_ptr(), 2, 0, interp)
         torch.cuda.synchronize()

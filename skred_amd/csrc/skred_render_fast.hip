@@ -383,13 +383,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_SKEW_LEAD() (reinterpret_cast<unsigned char *>(xt + (lane >> 4) * SK_XT + 64 + ((lane >> 2) & 3))[lane & 3])
 #define SK_SKEW_COL(ADDR_) ((ADDR_) >= 0 ? ((ADDR_) >> 2) : lane)   /* the ring column a lane reads: its source's, or (unused) its own */
 #define SK_SKEW_LMAX 3
-#define SK_FAST_SKEW_RFRAME(Q, TAME_, XN, XO, YN, YO, TILE_)                                             \
+#define SK_FAST_SKEW_RFRAME(Q, TAME_, XN, XO, YN, YO, TILE_, XF_)                                        \
   {                                                                                                      \
     float l, rr;                                                                                         \
     /* (amplitude / pan sources: read when the frame needs them -- nobody writes the ring before the end of the step) */ \
     const float aq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.am_addr)];        \
     const float pq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.pm_addr)];        \
-    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP, STOPS, true>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, xf, muted, 0.0f, mq_[Q], aq_, pq_); \
+    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP, STOPS, true>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, XF_, muted, 0.0f, mq_[Q], aq_, pq_); \
     own_[Q] = r.sample;                                                                                  \
     if (TILE_) {                                                                                         \
       l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                    \
@@ -417,13 +417,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     (void)inc_;
 /* the general frames of a step (delay line in r.x1 ...); the lane's own eight samples go to the ring when every lane of the wave
    has read what it needs of this step */
-#define SK_FAST_SKEW_FRAMES(TAME_, TILE_)                                                                \
+#define SK_FAST_SKEW_FRAMES(TAME_, TILE_, XF_)                                                           \
     {                                                                                                    \
-      const bool ap_ = (xf & XF_AP) != 0;                                                                \
+      const bool ap_ = ((XF_) & XF_AP) != 0;                                                             \
       float own_[8];                                                                                     \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
-        SK_FAST_SKEW_RFRAME(q_, TAME_, r.x1, r.x2, r.y1, r.y2, TILE_)                                    \
-        SK_FAST_SKEW_RFRAME(q_ + 1, TAME_, r.x2, r.x1, r.y2, r.y1, TILE_)                                \
+        SK_FAST_SKEW_RFRAME(q_, TAME_, r.x1, r.x2, r.y1, r.y2, TILE_, XF_)                               \
+        SK_FAST_SKEW_RFRAME(q_ + 1, TAME_, r.x2, r.x1, r.y2, r.y1, TILE_, XF_)                           \
       }                                                                                                  \
       const float old7_ = ring[7 * 64 + lane];                                                           \
       SK_FAST_WAVE_SYNC()                                                                                \
@@ -436,9 +436,12 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     if (TILE_) { if (pend_j >= 0) SK_FAST_TILE_REDUCE(pend_j) }                                          \
     SK_FAST_SKEW_TOP()                                                                                   \
     if (tame_ && (TILE_)) {           /* (the lead-in steps run once per pass: the general frames only) */ \
-      SK_FAST_SKEW_FRAMES(true, TILE_)                                                                   \
+      /* the shipped shape -- frequency plus amplitude / pan modulation, nothing else -- with the feature mask a literal: the
+         frames carry no wave-uniform tests (one scheduling region per frame pair) */                    \
+      if (xf == (XF_FM | XF_AP)) SK_FAST_SKEW_FRAMES(true, TILE_, (XF_FM | XF_AP))                       \
+      else SK_FAST_SKEW_FRAMES(true, TILE_, xf)                                                          \
     } else {                                                                                             \
-      SK_FAST_SKEW_FRAMES(false, TILE_)                                                                  \
+      SK_FAST_SKEW_FRAMES(false, TILE_, xf)                                                              \
     }                                                                                                    \
     if (TILE_) pend_j = (J);                                                                             \
   }
@@ -472,7 +475,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       else { if (stall_) SK_FAST_SKEW_LEAN_BODY(false, true) else SK_FAST_SKEW_LEAN_BODY(false, false) } \
     } else {                                                                                             \
       SK_FAST_PACK_OUT()                                                                                 \
-      SK_FAST_SKEW_FRAMES(false, true)                                                                   \
+      SK_FAST_SKEW_FRAMES(false, true, xf)                                                               \
       SK_FAST_REPACK()                                                                                   \
     }                                                                                                    \
     pend_j = (J);                                                                                        \

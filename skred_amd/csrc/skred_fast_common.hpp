@@ -442,7 +442,9 @@ __device__ __forceinline__ bool fast_smoother_stalled(const FastRegs &r) {
 // EXTMS: the caller hands in the modulators' previous samples (`ms_ext`, `am_ext`, `pm_ext`: the skewed blocks of
 // skred_render_fast.hip, whose modulator lanes run ahead and leave their samples in an LDS ring) instead of the ds_bpermute
 // exchange.
-template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false, bool EXTMS = false>
+// NOSTOP (with STOPS): the caller has proved that no lane of the wave is a stopping one-shot (XF_STOP clear), so the finish test and
+// the clamps that only a finishing phase needs are dropped -- r.stop is false in every lane, the results are the same.
+template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false, bool EXTMS = false, bool NOSTOP = false>
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r,
@@ -463,8 +465,8 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     }
   }
   if (STOPS && (xf & XF_REV) && r.rev) inc = -inc;      // reverse playback, applied to the modulated increment
-  const float ph = fast_advance<TAME, STOPS>(r, inc);
-  float s = fast_fetch<TAB_LDS, INTERP, TAME && !STOPS>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
+  const float ph = fast_advance<TAME, STOPS && !NOSTOP>(r, inc);
+  float s = fast_fetch<TAB_LDS, INTERP, TAME && (!STOPS || NOSTOP)>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
   if (STOPS && (xf & XF_NOISE) && r.noise) s = white;   // synth.c:543-546 (the lane's oscillator idles on inert numbers)
   if (STOPS && (xf & XF_HOLDQ)) {
     if (r.hold_max) {                                    // sample & hold, synth.c:560-571

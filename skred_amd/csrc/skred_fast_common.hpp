@@ -444,7 +444,13 @@ __device__ __forceinline__ bool fast_smoother_stalled(const FastRegs &r) {
 // exchange.
 // NOSTOP (with STOPS): the caller has proved that no lane of the wave is a stopping one-shot (XF_STOP clear), so the finish test and
 // the clamps that only a finishing phase needs are dropped -- r.stop is false in every lane, the results are the same.
-template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false, bool EXTMS = false, bool NOSTOP = false>
+// BIDIR (with NOSTOP, instead of TAME): the caller has proved lo <= phase <= hi and |inc| <= span/2 for every lane -- deep
+// frequency modulation that drives the increment below zero (7.sk, 0.sk) --, so phase + inc lies within half a loop length of
+// the loop on either side and both wraps are straight-line: beyond the end lo + ((ph0 - lo) - span) as in TAME; before the start
+// the reference's loop_end - fmodf(loop_start - phase, loop_length) (synth.c:253) with an argument below one loop length, where
+// fmodf returns it unchanged: hi - (lo - ph0).  (That difference can round to hi itself: the fetch keeps its index clamp.)
+template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false, bool EXTMS = false, bool NOSTOP = false,
+          bool BIDIR = false>
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r,
@@ -465,8 +471,15 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     }
   }
   if (STOPS && (xf & XF_REV) && r.rev) inc = -inc;      // reverse playback, applied to the modulated increment
-  const float ph = fast_advance<TAME, STOPS && !NOSTOP>(r, inc);
-  float s = fast_fetch<TAB_LDS, INTERP, TAME && (!STOPS || NOSTOP)>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
+  float ph;
+  if (BIDIR) {
+    const float ph0 = r.phase + inc;
+    ph = ph0 >= r.hi ? r.lo + ((ph0 - r.lo) - r.span) : (ph0 < r.lo ? r.hi - (r.lo - ph0) : ph0);
+    r.phase = ph;
+  } else {
+    ph = fast_advance<TAME, STOPS && !NOSTOP>(r, inc);
+  }
+  float s = fast_fetch<TAB_LDS, INTERP, TAME && !BIDIR && (!STOPS || NOSTOP)>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
   if (STOPS && (xf & XF_NOISE) && r.noise) s = white;   // synth.c:543-546 (the lane's oscillator idles on inert numbers)
   if (STOPS && (xf & XF_HOLDQ)) {
     if (r.hold_max) {                                    // sample & hold, synth.c:560-571

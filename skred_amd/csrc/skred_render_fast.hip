@@ -383,14 +383,14 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_SKEW_LEAD() (reinterpret_cast<unsigned char *>(xt + (lane >> 4) * SK_XT + 64 + ((lane >> 2) & 3))[lane & 3])
 #define SK_SKEW_COL(ADDR_) ((ADDR_) >= 0 ? ((ADDR_) >> 2) : lane)   /* the ring column a lane reads: its source's, or (unused) its own */
 #define SK_SKEW_LMAX 3
-#define SK_FAST_SKEW_RFRAME(Q, TAME_, XN, XO, YN, YO, TILE_, XF_)                                        \
+#define SK_FAST_SKEW_RFRAME(Q, MODE_, XN, XO, YN, YO, TILE_, XF_)     /* MODE_ 0: general frame, 1: tame, 2: bidirectional */ \
   {                                                                                                      \
     float l, rr;                                                                                         \
     /* (amplitude / pan sources: read when the frame needs them -- nobody writes the ring before the end of the step) */ \
     float aq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.am_addr)];              \
     float pq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.pm_addr)];              \
     if (ap_) asm volatile("" : "+v"(aq_), "+v"(pq_));   /* (both reads here, for every lane: left alone, hipcc sinks them into per-lane branches around the two products that use them) */ \
-    fast_frame<TAB_LDS, FILTER, ENV, true, TAME_, INTERP, STOPS, true, TAME_>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, XF_, muted, 0.0f, mq_[Q], aq_, pq_); \
+    fast_frame<TAB_LDS, FILTER, ENV, true, (MODE_) == 1, INTERP, STOPS, true, (MODE_) != 0, (MODE_) == 2>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, XF_, muted, 0.0f, mq_[Q], aq_, pq_); \
     own_[Q] = r.sample;                                                                                  \
     if (TILE_) {                                                                                         \
       l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                    \
@@ -409,22 +409,25 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       _Pragma("unroll") for (int q_ = 1; q_ < 8; ++q_) mq_[q_] = col_[(q_ - 1) * 64];                    \
     }                                                                                                    \
     float inc_[8];                                                                                       \
-    uint32_t top_ = 0u;                                                                                  \
+    uint32_t top_ = 0u, mag_ = 0u;                                                                       \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                   \
       inc_[q_] = r.fm_addr >= 0 ? r.inc + r.fm_k * (mq_[q_] * r.fm_depth) : r.inc;      /* synth.c:551-554 */ \
       top_ = max(top_, __float_as_uint(inc_[q_]));                                                       \
+      mag_ = max(mag_, __float_as_uint(inc_[q_]) & 0x7fffffffu);                                         \
     }                                                                                                    \
     const bool tame_ = __all(top_ <= __float_as_uint(half_span));                                        \
-    (void)inc_;
+    /* ... or within half a loop length on either side (deep modulation: the increment goes negative): fast_frame<BIDIR> */ \
+    const bool bidir_ = !tame_ && __all(mag_ <= __float_as_uint(half_span));                             \
+    (void)inc_; (void)bidir_;
 /* the general frames of a step (delay line in r.x1 ...); the lane's own eight samples go to the ring when every lane of the wave
    has read what it needs of this step */
-#define SK_FAST_SKEW_FRAMES(TAME_, TILE_, XF_)                                                           \
+#define SK_FAST_SKEW_FRAMES(MODE_, TILE_, XF_)                                                           \
     {                                                                                                    \
       const bool ap_ = ((XF_) & XF_AP) != 0;                                                             \
       float own_[8];                                                                                     \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
-        SK_FAST_SKEW_RFRAME(q_, TAME_, r.x1, r.x2, r.y1, r.y2, TILE_, XF_)                               \
-        SK_FAST_SKEW_RFRAME(q_ + 1, TAME_, r.x2, r.x1, r.y2, r.y1, TILE_, XF_)                           \
+        SK_FAST_SKEW_RFRAME(q_, MODE_, r.x1, r.x2, r.y1, r.y2, TILE_, XF_)                               \
+        SK_FAST_SKEW_RFRAME(q_ + 1, MODE_, r.x2, r.x1, r.y2, r.y1, TILE_, XF_)                           \
       }                                                                                                  \
       const float old7_ = ring[7 * 64 + lane];                                                           \
       SK_FAST_WAVE_SYNC()                                                                                \
@@ -439,10 +442,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     if (tame_ && (TILE_)) {           /* (the lead-in steps run once per pass: the general frames only) */ \
       /* the shipped shape -- frequency plus amplitude / pan modulation, nothing else -- with the feature mask a literal: the
          frames carry no wave-uniform tests (one scheduling region per frame pair) */                    \
-      if (xf == (XF_FM | XF_AP)) SK_FAST_SKEW_FRAMES(true, TILE_, (XF_FM | XF_AP))                       \
-      else SK_FAST_SKEW_FRAMES(true, TILE_, xf)                                                          \
+      if (xf == (XF_FM | XF_AP)) SK_FAST_SKEW_FRAMES(1, TILE_, (XF_FM | XF_AP))                          \
+      else SK_FAST_SKEW_FRAMES(1, TILE_, xf)                                                             \
+    } else if (bidir_ && (TILE_)) {                                                                      \
+      if (xf == (XF_FM | XF_AP)) SK_FAST_SKEW_FRAMES(2, TILE_, (XF_FM | XF_AP))                          \
+      else SK_FAST_SKEW_FRAMES(2, TILE_, xf)                                                             \
     } else {                                                                                             \
-      SK_FAST_SKEW_FRAMES(false, TILE_, xf)                                                              \
+      SK_FAST_SKEW_FRAMES(0, TILE_, xf)                                                                  \
     }                                                                                                    \
     if (TILE_) pend_j = (J);                                                                             \
   }
@@ -476,7 +482,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       else { if (stall_) SK_FAST_SKEW_LEAN_BODY(false, true) else SK_FAST_SKEW_LEAN_BODY(false, false) } \
     } else {                                                                                             \
       SK_FAST_PACK_OUT()                                                                                 \
-      SK_FAST_SKEW_FRAMES(false, true, xf)                                                               \
+      if (bidir_) SK_FAST_SKEW_FRAMES(2, true, XF_FM)                                                    \
+      else SK_FAST_SKEW_FRAMES(0, true, xf)                                                              \
       SK_FAST_REPACK()                                                                                   \
     }                                                                                                    \
     pend_j = (J);                                                                                        \

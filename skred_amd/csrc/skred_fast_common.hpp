@@ -45,6 +45,7 @@ struct FastRegs {
   float ox1, ox2, oy1, oy2;     // delay line of an UNfiltered voice as loaded: it is stored back untouched
 #ifdef SK_PROBE_TU
   float2 *probe;                // this frame's probe row of the voice (nullptr: not probed / skipped / muted); skred_bank_set_probe
+  float2 *probe_hold;           // (skewed blocks) the row pointer of a lane that has rendered its last block already, while it runs on
   int probe_stride;             // float2 per frame
   bool probe_any;               // (wave-uniform) some lane of the wave writes probes
 #endif

@@ -371,7 +371,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // first), and on the launch's last whole blocks a lane that has rendered them already gets its recurrences put back behind
 // the step (`lead > blocks left`).
 // Condition (skew_ok, per wave and pass): every lane that is read by another is silent (its (L, R) are zeros whatever frame it
-// is on, so the tile rows stay those of the audible lanes' frames; no probe row), every source is exactly one block ahead of
+// is on, so the tile rows stay those of the audible lanes' frames; no probe row) -- or it is one block ahead with its pan at
+// rest, and its (L, R) are formed a step late from its own ring column (`skew_delay`) --, every source is exactly one block ahead of
 // each of its readers, chains at most SK_SKEW_LMAX deep, geometry tame, no reverse / noise / stopping / smoother-off lanes.
 // Two forms: LEAN (only frequency modulation, one level: the pair-register chain of the plain blocks, no per-frame feature
 // tests) and RICH (amplitude / pan modulation, sample & hold, chains: fast_frame itself with the ring's samples handed in).
@@ -383,7 +384,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_SKEW_LEAD() (reinterpret_cast<unsigned char *>(xt + (lane >> 4) * SK_XT + 64 + ((lane >> 2) & 3))[lane & 3])
 #define SK_SKEW_COL(ADDR_) ((ADDR_) >= 0 ? ((ADDR_) >> 2) : lane)   /* the ring column a lane reads: its source's, or (unused) its own */
 #define SK_SKEW_LMAX 3
-#define SK_FAST_SKEW_RFRAME(Q, MODE_, XN, XO, YN, YO, TILE_, XF_)     /* MODE_ 0: general frame, 1: tame, 2: bidirectional */ \
+#define SK_FAST_SKEW_RFRAME(Q, MODE_, XN, XO, YN, YO, TILE_, XF_, DL_)     /* MODE_ 0: general frame, 1: tame, 2: bidirectional */ \
   {                                                                                                      \
     float l, rr;                                                                                         \
     /* (amplitude / pan sources: read when the frame needs them -- nobody writes the ring before the end of the step) */ \
@@ -393,6 +394,10 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     fast_frame<TAB_LDS, FILTER, ENV, true, (MODE_) == 1, INTERP, STOPS, true, (MODE_) != 0, (MODE_) == 2>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, XF_, muted, 0.0f, mq_[Q], aq_, pq_); \
     own_[Q] = r.sample;                                                                                  \
     if (TILE_) {                                                                                         \
+      if ((DL_) && skew_delay) {     /* an audible source: what it rendered a step ago belongs to THIS frame (same product as fast_post's) */ \
+        const float sd_ = ring[(Q) * 64 + lane];                                                         \
+        l = dl_ ? sd_ * r.pan_l : l; rr = dl_ ? sd_ * r.pan_r : rr;                                      \
+      }                                                                                                  \
       l = silent ? 0.0f : l; rr = silent ? 0.0f : rr;                                                    \
       xt[(Q) * SK_XT + lane] = fold_lr(l, rr);                                                           \
     }                                                                                                    \
@@ -421,13 +426,15 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     (void)inc_; (void)bidir_;
 /* the general frames of a step (delay line in r.x1 ...); the lane's own eight samples go to the ring when every lane of the wave
    has read what it needs of this step */
-#define SK_FAST_SKEW_FRAMES(MODE_, TILE_, XF_)                                                           \
+#define SK_FAST_SKEW_FRAMES(MODE_, TILE_, XF_, DL_)     /* DL_: the copy that also serves audible sources (skew_delay) */ \
     {                                                                                                    \
       const bool ap_ = ((XF_) & XF_AP) != 0;                                                             \
+      const bool dl_ = (TILE_) && (DL_) && skew_delay && (int)SK_SKEW_LEAD() == 1 && !silent;            \
+      (void)dl_;                                                                                         \
       float own_[8];                                                                                     \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
-        SK_FAST_SKEW_RFRAME(q_, MODE_, r.x1, r.x2, r.y1, r.y2, TILE_, XF_)                               \
-        SK_FAST_SKEW_RFRAME(q_ + 1, MODE_, r.x2, r.x1, r.y2, r.y1, TILE_, XF_)                           \
+        SK_FAST_SKEW_RFRAME(q_, MODE_, r.x1, r.x2, r.y1, r.y2, TILE_, XF_, DL_)                          \
+        SK_FAST_SKEW_RFRAME(q_ + 1, MODE_, r.x2, r.x1, r.y2, r.y1, TILE_, XF_, DL_)                      \
       }                                                                                                  \
       const float old7_ = ring[7 * 64 + lane];                                                           \
       SK_FAST_WAVE_SYNC()                                                                                \
@@ -442,13 +449,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     if (tame_ && (TILE_)) {           /* (the lead-in steps run once per pass: the general frames only) */ \
       /* the shipped shape -- frequency plus amplitude / pan modulation, nothing else -- with the feature mask a literal: the
          frames carry no wave-uniform tests (one scheduling region per frame pair) */                    \
-      if (xf == (XF_FM | XF_AP)) SK_FAST_SKEW_FRAMES(1, TILE_, (XF_FM | XF_AP))                          \
-      else SK_FAST_SKEW_FRAMES(1, TILE_, xf)                                                             \
+      if (xf == (XF_FM | XF_AP) && !skew_delay) SK_FAST_SKEW_FRAMES(1, TILE_, (XF_FM | XF_AP), false)    \
+      else SK_FAST_SKEW_FRAMES(1, TILE_, xf, true)                                                       \
     } else if (bidir_ && (TILE_)) {                                                                      \
-      if (xf == (XF_FM | XF_AP)) SK_FAST_SKEW_FRAMES(2, TILE_, (XF_FM | XF_AP))                          \
-      else SK_FAST_SKEW_FRAMES(2, TILE_, xf)                                                             \
+      if (xf == (XF_FM | XF_AP) && !skew_delay) SK_FAST_SKEW_FRAMES(2, TILE_, (XF_FM | XF_AP), false)    \
+      else SK_FAST_SKEW_FRAMES(2, TILE_, xf, true)                                                       \
     } else {                                                                                             \
-      SK_FAST_SKEW_FRAMES(0, TILE_, xf)                                                                  \
+      SK_FAST_SKEW_FRAMES(0, TILE_, xf, true)                                                            \
     }                                                                                                    \
     if (TILE_) pend_j = (J);                                                                             \
   }
@@ -482,8 +489,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       else { if (stall_) SK_FAST_SKEW_LEAN_BODY(false, true) else SK_FAST_SKEW_LEAN_BODY(false, false) } \
     } else {                                                                                             \
       SK_FAST_PACK_OUT()                                                                                 \
-      if (bidir_) SK_FAST_SKEW_FRAMES(2, true, XF_FM)                                                    \
-      else SK_FAST_SKEW_FRAMES(0, true, xf)                                                              \
+      if (bidir_) SK_FAST_SKEW_FRAMES(2, true, XF_FM, false)                                             \
+      else SK_FAST_SKEW_FRAMES(0, true, xf, false)                                                       \
       SK_FAST_REPACK()                                                                                   \
     }                                                                                                    \
     pend_j = (J);                                                                                        \
@@ -505,6 +512,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
    is final when the step `lead` blocks before the end begins.  It goes to the state planes there (FREEZE: what the end of the
    pass stores), the lane keeps running on numbers nobody reads (silent; its ring column has no reader left), and behind the last
    step it loads its state again (THAW) -- no registers held across the steps for this. */
+#ifdef SK_PROBE_TU   /* (an audible source's probe rows: none while it runs on behind its last block, the pointer back for the tail frames) */
+#define SK_SKEW_PROBE_HOLD() { r.probe_hold = r.probe; r.probe = nullptr; }
+#define SK_SKEW_PROBE_BACK() { r.probe = r.probe_hold; }
+#else
+#define SK_SKEW_PROBE_HOLD()
+#define SK_SKEW_PROBE_BACK()
+#endif
 #define SK_FAST_SKEW_FREEZE()                                                                            \
   if ((int)SK_SKEW_LEAD() == left_ + 1 && !dead) {                                                       \
     uint4 s0, s1;                                                                                        \
@@ -515,6 +529,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     *reinterpret_cast<uint4 *>(&a.rw[SKS_OSC][v]) = s0;                                                  \
     *reinterpret_cast<uint4 *>(&a.rw[SKS_FILT][v]) = s1;                                                 \
     if (r.hold_max) *reinterpret_cast<uint2 *>(&a.rw[SKS_MISC][v]) = make_uint2(__float_as_uint(r.hold), (uint32_t)r.hold_count); \
+    SK_SKEW_PROBE_HOLD()                                                                                 \
   }
 #define SK_FAST_SKEW_THAW()                                                                              \
   {                                                                                                      \
@@ -527,6 +542,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       r.x1 = __uint_as_float(s0.z);    r.x2 = __uint_as_float(s0.w);                                     \
       r.y1 = __uint_as_float(s1.x);    r.y2 = __uint_as_float(s1.y);                                     \
       r.sample = __uint_as_float(s1.z);                                                                  \
+      SK_SKEW_PROBE_BACK()                                                                               \
       if (r.hold_max) {                                                                                  \
         const uint2 s2 = *reinterpret_cast<const uint2 *>(&a.rw[SKS_MISC][v]);                  \
         r.hold = __uint_as_float(s2.x); r.hold_count = (int)s2.y;                                        \
@@ -790,7 +806,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? ((FILTER || ENV || INT
     (void)loz;
     // skewed blocks (SK_FAST_SKEW_STEP / _RSTEP): every lane's lead, and whether this wave qualifies
     int lmax = 0;
-    bool skew_ok = false, skew_lean = false, skewed = false;
+    bool skew_ok = false, skew_lean = false, skewed = false, skew_delay = false;
     if (STOPS && TAB_LDS && a.fm_skew && tame_geom && a.num_frames >= 32 && (xf & (XF_FM | XF_AP)) && (xf & ~(XF_FM | XF_AP | XF_HOLDQ)) == 0) {
       const int fm_src = SK_SKEW_COL(r.fm_addr), am_src = SK_SKEW_COL(r.am_addr), pm_src = SK_SKEW_COL(r.pm_addr);
       const bool self_fm = r.fm_addr >= 0 && fm_src == lane;
@@ -810,13 +826,17 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? ((FILTER || ENV || INT
       const int lf_ = lead_w[fm_src], la_ = lead_w[am_src], lp_ = lead_w[pm_src];
       SK_FAST_WAVE_SYNC()
       const bool edges_ = (fm_src == lane || lf_ == lead + 1) && (am_src == lane || la_ == lead + 1) && (pm_src == lane || lp_ == lead + 1);
-      skew_ok = __all(edges_ && !self_fm && lead <= SK_SKEW_LMAX && (lead == 0 || silent));
+      // a source that is HEARD (37.sk's v4: a modulator without `m1`): one block ahead at most, its pan at rest -- its (L, R) of a
+      // frame are formed a step later from the sample it left in its own ring column
+      const bool heard_ = lead == 1 && !silent && r.pm_addr == -1;
+      skew_ok = __all(edges_ && !self_fm && lead <= SK_SKEW_LMAX && (lead == 0 || silent || heard_));
+      skew_delay = skew_ok && __any(heard_);
       lmax = __any(lead >= 3) ? 3 : __any(lead >= 2) ? 2 : __any(lead >= 1) ? 1 : 0;
       SK_SKEW_LEAD() = (unsigned char)lead;
       SK_FAST_WAVE_SYNC()
-      skew_lean = skew_ok && xf == XF_FM && lmax == 1;
+      skew_lean = skew_ok && xf == XF_FM && lmax == 1 && !skew_delay;
     }
-    (void)lmax; (void)skew_ok; (void)skew_lean; (void)skewed;
+    (void)lmax; (void)skew_ok; (void)skew_lean; (void)skewed; (void)skew_delay;
 
     bool moved = false;                               // (wave-uniform) some chunk of this pass had an envelope in motion
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
@@ -1038,14 +1058,65 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? ((FILTER || ENV || INT
 // ---------------------------------------------------------------- launcher (C linkage)
 
 // specialisation key: table residency x filter x envelope x interpolation
+//
+// The template matrix is compiled as FOUR translation units from this one source (-DSK_FAST_PART=n; the extended instantiations
+// with the skewed blocks take minutes each): part 0 the clean instantiations and the launcher, part 1 / 2 the extended
+// instantiations of LDS-table banks without / with the biquad, part 3 those of global-table banks.  (-DSK_FAST_ONE_CASE=...:
+// one instantiation pair in one unit, for compile-time experiments.)
+#ifndef SK_FAST_PART
+#define SK_FAST_PART 0
+#endif
 #ifdef SK_PROBE_TU
 #define SK_FAST_LAUNCHER sk_launch_render_fastp
+#define SK_FAST_CASES(N) sk_fast_cases##N##p
 #define SK_PROBE_FLAG true
 #else
 #define SK_FAST_LAUNCHER sk_launch_render_fast
+#define SK_FAST_CASES(N) sk_fast_cases##N
 #define SK_PROBE_FLAG false
 extern "C" int sk_launch_render_fastp(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes, hipStream_t stream);
 #endif
+extern "C" int SK_FAST_CASES(1)(const sk_render_args_t *args, unsigned grid_x, size_t lds_bytes, hipStream_t stream, int key, int rampk, int guard);
+extern "C" int SK_FAST_CASES(2)(const sk_render_args_t *args, unsigned grid_x, size_t lds_bytes, hipStream_t stream, int key, int rampk, int guard);
+extern "C" int SK_FAST_CASES(3)(const sk_render_args_t *args, unsigned grid_x, size_t lds_bytes, hipStream_t stream, int key, int rampk, int guard);
+
+#define SK_FAST_BIG_LDS_(K)                                                                                                 \
+  if (lds_bytes > 65536) {   /* (per launch: the attribute belongs to the device the calling thread is on) */              \
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) return (int)hipGetLastError(); }
+#define SK_FAST_LAUNCH_(T, F, E, I, X)                                                                                      \
+  { if (E && rampk) { SK_FAST_BIG_LDS_((sk_render_fast_kernel<T, F, E, I, X, E, SK_PROBE_FLAG>)) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, E, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args); }   \
+    else { SK_FAST_BIG_LDS_((sk_render_fast_kernel<T, F, E, I, X, false, SK_PROBE_FLAG>)) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, false, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args); } }
+#define SK_FAST_CASE_C(K, T, F, E, I) case K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), false) else SK_FAST_LAUNCH_(T, F, E, I, false) break;
+#define SK_FAST_CASE_X(K, T, F, E, I) case 16 + K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), true) else SK_FAST_LAUNCH_(T, F, E, I, true) break;
+
+#if SK_FAST_PART != 0 && !defined(SK_FAST_ONE_CASE)
+// the extended instantiations of this part
+#if SK_FAST_PART == 1
+extern "C" int SK_FAST_CASES(1)
+#elif SK_FAST_PART == 2
+extern "C" int SK_FAST_CASES(2)
+#else
+extern "C" int SK_FAST_CASES(3)
+#endif
+    (const sk_render_args_t *args, unsigned grid_x, size_t lds_bytes, hipStream_t stream, int key, int rampk, int guard) {
+  dim3 grid(grid_x), block(SK_GROUP);
+  switch (key) {
+#if SK_FAST_PART == 1
+    SK_FAST_CASE_X(8, true, false, false, 0)  SK_FAST_CASE_X(9, true, false, false, 1)
+    SK_FAST_CASE_X(10, true, false, true, 0)  SK_FAST_CASE_X(11, true, false, true, 1)
+#elif SK_FAST_PART == 2
+    SK_FAST_CASE_X(12, true, true, false, 0)  SK_FAST_CASE_X(13, true, true, false, 1)
+    SK_FAST_CASE_X(14, true, true, true, 0)   SK_FAST_CASE_X(15, true, true, true, 1)
+#else
+    SK_FAST_CASE_X(0, false, false, false, 0) SK_FAST_CASE_X(1, false, false, false, 1)
+    SK_FAST_CASE_X(2, false, false, true, 0)  SK_FAST_CASE_X(3, false, false, true, 1)
+    SK_FAST_CASE_X(4, false, true, false, 0)  SK_FAST_CASE_X(5, false, true, false, 1)
+    SK_FAST_CASE_X(6, false, true, true, 0)   SK_FAST_CASE_X(7, false, true, true, 1)
+#endif
+  }
+  return (int)hipGetLastError();
+}
+#else
 extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, size_t lds_bytes,
                                 hipStream_t stream) {
 #ifndef SK_PROBE_TU
@@ -1056,10 +1127,10 @@ extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, 
   // window's 5 KB per wave as well: 12 KB per workgroup that cost banks with 32 KB of tables their third workgroup per CU)
   lds_bytes += (size_t)4 * (8 * SK_XT) * sizeof(float);
   if (args->lds_table_floats == 0) lds_bytes += (size_t)4 * (SK_WIN * 64) * sizeof(float);
-  sk_render_args_t skew_args;    /* the skewed blocks' sample rings, where they fit under the 64 KB a launch may ask for */
+  sk_render_args_t skew_args;    /* the skewed blocks' sample rings */
   if (args->fm_skew) {
     skew_args = *args;
-    /* (beyond the 64 KB a launch gets by default the kernel's limit is raised below; up to half a CU's LDS, so that a bank with a
+    /* (beyond the 64 KB a launch gets by default the kernel's limit is raised; up to half a CU's LDS, so that a bank with a
        48 KB pool keeps its two workgroups per CU) */
     if (tab_lds && lds_bytes + (size_t)4 * SK_SKEW_RING * sizeof(float) <= 81920) lds_bytes += (size_t)4 * SK_SKEW_RING * sizeof(float);
     else skew_args.fm_skew = 0;
@@ -1070,31 +1141,23 @@ extern "C" int SK_FAST_LAUNCHER(const sk_render_args_t *args, int n_workgroups, 
                   ((args->fast_mode & SKM_ENV_ALL) ? 2 : 0) | (args->interp != 0 ? 1 : 0);
   const bool rampk = !args->skip_env2;   /* envelopes may be moving (skip_env2: a launch has reported that none did) */
   const bool guard = args->interp == 2;  /* linear lookup, every live voice on a guarded whole-table loop (SKF_GUARD; the host counts) */
-#define SK_FAST_BIG_LDS_(K)                                                                                                 \
-  if (lds_bytes > 65536) {   /* (per launch: the attribute belongs to the device the calling thread is on) */              \
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, 81920) != hipSuccess) return (int)hipGetLastError(); }
-#define SK_FAST_LAUNCH_(T, F, E, I, X)                                                                                      \
-  { if (E && rampk) { SK_FAST_BIG_LDS_((sk_render_fast_kernel<T, F, E, I, X, E, SK_PROBE_FLAG>)) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, E, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args); }   \
-    else { SK_FAST_BIG_LDS_((sk_render_fast_kernel<T, F, E, I, X, false, SK_PROBE_FLAG>)) hipLaunchKernelGGL((sk_render_fast_kernel<T, F, E, I, X, false, SK_PROBE_FLAG>), grid, block, lds_bytes, stream, *args); } }
-#define SK_FAST_CASE(K, T, F, E, I)                                                                                        \
-  case K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), false) else SK_FAST_LAUNCH_(T, F, E, I, false) break;      \
-  case 16 + K: if (I && guard) SK_FAST_LAUNCH_(T, F, E, (I ? 2 : 0), true) else SK_FAST_LAUNCH_(T, F, E, I, true) break;
-  switch (key) {
 #ifdef SK_FAST_ONE_CASE   /* (compile-time experiments: one instantiation pair) */
-#define SK_FAST_CASE_X(...) SK_FAST_CASE(__VA_ARGS__)
-    SK_FAST_CASE_X(SK_FAST_ONE_CASE)
+#define SK_FAST_CASE_BOTH(...) SK_FAST_CASE_C(__VA_ARGS__) SK_FAST_CASE_X(__VA_ARGS__)
+  switch (key) { SK_FAST_CASE_BOTH(SK_FAST_ONE_CASE) }
 #else
-    SK_FAST_CASE(0, false, false, false, 0) SK_FAST_CASE(1, false, false, false, 1)
-    SK_FAST_CASE(2, false, false, true, 0)  SK_FAST_CASE(3, false, false, true, 1)
-    SK_FAST_CASE(4, false, true, false, 0)  SK_FAST_CASE(5, false, true, false, 1)
-    SK_FAST_CASE(6, false, true, true, 0)   SK_FAST_CASE(7, false, true, true, 1)
-    SK_FAST_CASE(8, true, false, false, 0)  SK_FAST_CASE(9, true, false, false, 1)
-    SK_FAST_CASE(10, true, false, true, 0)  SK_FAST_CASE(11, true, false, true, 1)
-    SK_FAST_CASE(12, true, true, false, 0)  SK_FAST_CASE(13, true, true, false, 1)
-    SK_FAST_CASE(14, true, true, true, 0)   SK_FAST_CASE(15, true, true, true, 1)
-#endif
+  if (key >= 24) return (key & 4) ? SK_FAST_CASES(2)(args, grid.x, lds_bytes, stream, key, rampk, guard) : SK_FAST_CASES(1)(args, grid.x, lds_bytes, stream, key, rampk, guard);
+  if (key >= 16) return SK_FAST_CASES(3)(args, grid.x, lds_bytes, stream, key, rampk, guard);
+  switch (key) {
+    SK_FAST_CASE_C(0, false, false, false, 0) SK_FAST_CASE_C(1, false, false, false, 1)
+    SK_FAST_CASE_C(2, false, false, true, 0)  SK_FAST_CASE_C(3, false, false, true, 1)
+    SK_FAST_CASE_C(4, false, true, false, 0)  SK_FAST_CASE_C(5, false, true, false, 1)
+    SK_FAST_CASE_C(6, false, true, true, 0)   SK_FAST_CASE_C(7, false, true, true, 1)
+    SK_FAST_CASE_C(8, true, false, false, 0)  SK_FAST_CASE_C(9, true, false, false, 1)
+    SK_FAST_CASE_C(10, true, false, true, 0)  SK_FAST_CASE_C(11, true, false, true, 1)
+    SK_FAST_CASE_C(12, true, true, false, 0)  SK_FAST_CASE_C(13, true, true, false, 1)
+    SK_FAST_CASE_C(14, true, true, true, 0)   SK_FAST_CASE_C(15, true, true, true, 1)
   }
-#undef SK_FAST_CASE
-#undef SK_FAST_LAUNCH_
+#endif
   return (int)hipGetLastError();
 }
+#endif

@@ -148,9 +148,10 @@ def test_skewed_blocks_state_probes_and_mix(dev, recipe, interp, wild, hold):
 
 
 def test_waves_that_must_not_be_skewed(dev):
-    """An audible modulator (its (L, R) belong to the frame it is on), a modulator read by lanes of different leads (by three
-    carriers AND by another modulator: it cannot be one block ahead of all of them) and a carrier reading a modulator 40 lanes
-    away, in three wavefronts of a bank whose other wavefronts are skewed: every voice's state and samples against the oracle."""
+    """An audible modulator (skewed all the same: its (L, R) are formed a step late from its own ring column -- probed here, every
+    frame), a modulator read by lanes of different leads (by three carriers AND by another modulator: it cannot be one block ahead
+    of all of them: that wavefront keeps the exchange) and a carrier reading a modulator 40 lanes away, in three wavefronts of a
+    bank whose other wavefronts are skewed: every voice's state and samples against the oracle."""
     n = 1024
     bank, tables, g = fm_bank("c2", n)
     bank["voice_disconnect"][64 + 7] = 0               # wave 1: one modulator is heard
@@ -220,6 +221,36 @@ def test_rich_skewed_blocks_chains_amp_pan_hold(dev, recipe, interp, wild):
         assert kernels == [1] * len(SEGS), kernels
         bad = state.rw_equal(ref_state)
         assert not bad, (skew, bad)
+        for k, (got, want) in enumerate(zip(probes, ref_stems)):
+            d = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+            assert len(d) == 0, f"skew={skew} launch {k}: {len(d)} probed values differ; first (frame, probe, ch) {d[0]}, voice {ids[d[0][1]]}: {got[tuple(d[0])]} vs {want[tuple(d[0])]}"
+        assert rel_rms(mix, ref_mix) <= 1e-5
+        res[skew] = mix
+    assert gio.bits_equal(res[1], res[0])
+
+
+def test_audible_sources(dev):
+    """37.sk's shape: a modulator WITHOUT `m1` -- heard, and read by a carrier.  Such a lane runs a block ahead like any source;
+    what it adds to the mix of a frame is formed a step later from the sample it left in its own ring column (same product).
+    Every copy of a mod_bank gets one audible source (some pan-modulated themselves: those wavefronts keep the exchange); probes
+    on the audible sources and their carriers, ragged lengths, state, mix."""
+    n = 2048
+    bank, tables, g = mod_bank("c2", n, 4)
+    v = np.arange(n)
+    heard = v[(v % 4 == 3) & ((v // 4) % 2 == 0)]      # v3 of the 7.sk-shaped copies: the pan source of v0
+    bank["voice_disconnect"][heard] = 0
+    heard2 = v[(v % 4 == 2) & ((v // 4) % 2 == 1)]     # v2 of the 1.sk-shaped copies: the amplitude source of v0
+    bank["voice_disconnect"][heard2[::2]] = 0
+    pm = heard[(heard // 64) % 5 == 4]                 # in every fifth wavefront the audible source is pan-modulated itself
+    bank["voice_pan_mod_osc"][pm] = pm
+    bank["voice_pan_mod_depth"][pm] = np.float32(0.5)
+    ids = np.unique(np.concatenate([heard[::9], heard2[::14], np.arange(0, n, 4)[::23], [3, 7, 259, 263]])).astype(np.int32)[:64]
+    ref_mix, ref_state, ref_stems = oracle(bank, tables, g, 0, SEGS, ids)
+    res = {}
+    for skew in (1, 0):
+        mix, state, probes, kernels = run(dev, bank, tables, g, 0, SEGS, skew, ids)
+        assert kernels == [1] * len(SEGS), kernels
+        assert not state.rw_equal(ref_state), (skew, state.rw_equal(ref_state))
         for k, (got, want) in enumerate(zip(probes, ref_stems)):
             d = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
             assert len(d) == 0, f"skew={skew} launch {k}: {len(d)} probed values differ; first (frame, probe, ch) {d[0]}, voice {ids[d[0][1]]}: {got[tuple(d[0])]} vs {want[tuple(d[0])]}"

@@ -335,11 +335,13 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
                              2: whenever any disappear (tests, small banks).  The modulated kernel packs the same way.  Launches with the full stem buffer and banks on the generic / modulated / FM-pair
                              kernels are never packed.  Per-voice state is bit-identical either way; the mix differs by
                              summation order only */,
-       SKRED_OPT_FM_SKEW = 10 /* previous-frame frequency modulation on the one-voice-per-lane kernel (`v0 ... F3,1` with the modulator
-                             above its carriers, synth.c:548-555, as in 3.sk / 0.sk): 1 (default) the modulator lanes of a wavefront
-                             run one 8-frame block AHEAD of their carriers and hand their samples over through an LDS ring, so the
-                             carriers' blocks have no per-frame exchange (wavefronts whose modulators are all silent -- `m1` --
-                             and themselves unmodulated); 0: the per-frame ds_bpermute exchange everywhere.  Same bits either way */ };
+       SKRED_OPT_FM_SKEW = 10 /* previous-frame modulation on the one-voice-per-lane kernel (`v0 ... F3,1` / `A` / `P` with the modulator
+                             above its carriers, synth.c:548-555,584-587,597-602, as in 3.sk / 1.sk / 7.sk / 37.sk / 0.sk): 1 (default) a lane
+                             that is read by others runs 8-frame blocks AHEAD of its readers (chains up to three levels) and hands
+                             its samples over through an LDS ring, so the readers' blocks have no per-frame exchange -- wavefronts
+                             whose sources are silent (`m1`) or heard with their pan at rest, each exactly one block ahead of every
+                             lane that reads it, and without reverse / noise / stopping / smoother-off lanes; other wavefronts keep
+                             the exchange.  0: the per-frame ds_bpermute exchange everywhere.  Same bits either way */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */

@@ -461,18 +461,23 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
   }
 /* LEAN step (delay line in the register pairs xx / yy).  LOZ_: no lane of the wave has a loop window (fast_advance<LOZ>);
    STALL_: no smoother of the wave moves any more (per chunk) */
-#define SK_FAST_SKEW_LEAN_BODY(LOZ_, STALL_)                                                             \
+#define SK_FAST_SKEW_LEAN_BODY(LOZ_, STALL_, DL_)     /* DL_: the copy that also serves audible sources (skew_delay) */ \
     {                                                                                                    \
       float s_[8];                                                                                       \
+      const bool dl_ = (DL_) && (int)SK_SKEW_LEAD() == 1 && !silent;                                     \
+      (void)dl_;                                                                                         \
       ring[8 * 64 + lane] = ring[7 * 64 + lane];      /* (the lane's own column: readers took row 8 at the top) */ \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_)                                                   \
         s_[q_] = fast_fetch<TAB_LDS, INTERP, true>(lds_tab, glb_tab, r, fast_advance<true, false, LOZ_>(r, inc_[q_])); \
       _Pragma("unroll") for (int q_ = 0; q_ < 8; q_ += 2) {                                              \
         float s0_, s1_, u_, f0_, f1_;                                                                    \
+        float d0_ = 0.0f, d1_ = 0.0f;      /* (an audible source: what it rendered a step ago belongs to THESE frames) */ \
+        if (DL_) { d0_ = ring[q_ * 64 + lane]; d1_ = ring[(q_ + 1) * 64 + lane]; }                       \
         fast_post_v<FILTER, ENV, STALL_, STOPS, true, false>(r, pk, s_[q_], xx, yy, s0_, u_, 0);         \
         ring[q_ * 64 + lane] = s0_;                                                                      \
         fast_post_v<FILTER, ENV, STALL_, STOPS, false, false>(r, pk, s_[q_ + 1], xx, yy, s1_, u_, 0);    \
         ring[(q_ + 1) * 64 + lane] = s1_;                                                                \
+        if (DL_) { s0_ = dl_ ? d0_ : s0_; s1_ = dl_ ? d1_ : s1_; }                                       \
         s0_ = silent ? 0.0f : s0_; s1_ = silent ? 0.0f : s1_;                                            \
         fast_pan_fold2(s0_, s1_, pk.pan.x, pk.pan.y, f0_, f1_);                                          \
         xt[q_ * SK_XT + lane] = f0_;                                                                     \
@@ -485,12 +490,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     SK_FAST_SKEW_TOP()                                                                                   \
     SK_FAST_WAVE_SYNC()                                                                                  \
     if (tame_) {                                                                                         \
-      if (loz) { if (stall_) SK_FAST_SKEW_LEAN_BODY(true, true) else SK_FAST_SKEW_LEAN_BODY(true, false) } \
-      else { if (stall_) SK_FAST_SKEW_LEAN_BODY(false, true) else SK_FAST_SKEW_LEAN_BODY(false, false) } \
+      if (skew_delay) SK_FAST_SKEW_LEAN_BODY(false, false, true)                                         \
+      else if (loz) { if (stall_) SK_FAST_SKEW_LEAN_BODY(true, true, false) else SK_FAST_SKEW_LEAN_BODY(true, false, false) } \
+      else { if (stall_) SK_FAST_SKEW_LEAN_BODY(false, true, false) else SK_FAST_SKEW_LEAN_BODY(false, false, false) } \
     } else {                                                                                             \
       SK_FAST_PACK_OUT()                                                                                 \
-      if (bidir_) SK_FAST_SKEW_FRAMES(2, true, XF_FM, false)                                             \
-      else SK_FAST_SKEW_FRAMES(0, true, xf, false)                                                       \
+      if (bidir_ && !skew_delay) SK_FAST_SKEW_FRAMES(2, true, XF_FM, false)                              \
+      else SK_FAST_SKEW_FRAMES(0, true, xf, true)                                                        \
       SK_FAST_REPACK()                                                                                   \
     }                                                                                                    \
     pend_j = (J);                                                                                        \
@@ -834,7 +840,7 @@ __global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? ((FILTER || ENV || INT
       lmax = __any(lead >= 3) ? 3 : __any(lead >= 2) ? 2 : __any(lead >= 1) ? 1 : 0;
       SK_SKEW_LEAD() = (unsigned char)lead;
       SK_FAST_WAVE_SYNC()
-      skew_lean = skew_ok && xf == XF_FM && lmax == 1 && !skew_delay;
+      skew_lean = skew_ok && xf == XF_FM && lmax == 1;
     }
     (void)lmax; (void)skew_ok; (void)skew_lean; (void)skewed; (void)skew_delay;
 

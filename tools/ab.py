@@ -7,6 +7,7 @@ build, `tools/ab_libs.sh ab.py ...` runs it once per build under _ab/).  It repl
   frames   one bank, several block lengths (per-frame + fixed cost):  --bank c2:65536 --lengths 64,256,512,2048
   live     a 2^20-voice C3 bank from its first frame, then under note traffic:  [--notes 104,524,5242] [--in-place M] [--voices N]
   patch    reference patches tiled over a bank (banks.bank_patch):    [--patches 3sk,37sk,7sk,1sk,18sk] [--voices N] [--fm-skew 0|1]
+  fm       the C2 recipe with every eighth voice frequency-modulated (modulators muted / heard):                 [--voices N] [--fm-skew 0|1]
   fx       the fixed-point bank (fxbank.bank_fx) at several sizes, both lookups, with and without the biquad:  [--fx-sizes 65536,1048576]
   stamps   `steady` on a -DSKS_STAMPS build of the split kernel: what its waves recorded (cycles, waits, in-kernel clock)
 """
@@ -145,6 +146,22 @@ def patch(a):
         db.close()
 
 
+def fm(a):
+    """The headline recipe (mixed LUTs + biquad + ADSR) with every eighth voice a carrier of the voice three above it -- muted
+    (`m1`) or heard --: the extended instantiation WITH biquad and envelope on the skewed blocks (--fm-skew 1) or the exchange (0)."""
+    import numpy as np
+    for muted in (1, 0):
+        b, t, g = banks.bank_c2(a.voices)
+        car = np.arange(0, a.voices, 8); b["voice_freq_mod_osc"][car] = car + 3; b["voice_freq_mod_depth"][car] = 0.2
+        if muted: b["voice_disconnect"][car + 3] = 1
+        db, _ = open_bank(None, 0, a, bank=(b, t, g))
+        out = torch.zeros(512, 2, device="cuda")
+        settle(db, out, 512, 0, blocks=25)
+        best, med = timed(lambda: db.render_mix(512, out.data_ptr(), 2, 0, 0), 40, 3)
+        print(f"fm c2 recipe, 1/8 carriers, modulators {'muted' if muted else 'heard'}, {a.voices} voices: {best / 1e3:7.3f} ms per block (med {med / 1e3:7.3f}) kernel={db.last_kernel()} fm_skew={a.fm_skew}  lib={LIB}", flush=True)
+        db.close()
+
+
 def fx(a):
     from skred_amd import fxbank
     for n in [int(x) for x in a.fx_sizes.split(",")]:
@@ -163,7 +180,7 @@ def fx(a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("scenario", choices=["steady", "frames", "live", "patch", "stamps", "fx"])
+    ap.add_argument("scenario", choices=["steady", "frames", "live", "patch", "stamps", "fx", "fm"])
     ap.add_argument("--fx-sizes", default="65536,1048576")
     ap.add_argument("--fx-filter", type=int, default=-1)
     ap.add_argument("--fx-interp", type=int, default=-1)
@@ -184,7 +201,7 @@ def main():
     ap.add_argument("--fm-skew", type=int, default=None)
     ap.add_argument("--patches", default="3sk,37sk,7sk,1sk,18sk")
     a = ap.parse_args()
-    {"steady": steady, "stamps": steady, "frames": frames, "live": live, "patch": patch, "fx": fx}[a.scenario](a)
+    {"steady": steady, "stamps": steady, "frames": frames, "live": live, "patch": patch, "fx": fx, "fm": fm}[a.scenario](a)
 
 
 if __name__ == "__main__":

@@ -195,8 +195,12 @@ __device__ __forceinline__ void fast_post(FastRegs &r, float s, float &xn, float
     gain = r.amp * (e * r.vel);
   }
   // ---- smoother + apply (synth.c:589-593), pan (synth.c:603-604) ----
-  if (XMOD && (xf & XF_AP) && r.am_addr != -1)           // final = amp * env * mod (synth.c:583-588)
-    gain = gain * ((r.am_addr == -2 ? s : r.am_prev) * r.am_depth);
+  if (XMOD && (xf & XF_AP)) {                            // final = amp * env * mod (synth.c:583-588)
+    // (selects, not a branch per lane: hipcc turned `if (am_addr != -1) gain *= ...` into two nested EXEC-masked branches per frame)
+    const float am_ = r.am_addr == -2 ? s : r.am_prev;
+    const float g_am_ = gain * (am_ * r.am_depth);
+    gain = r.am_addr != -1 ? g_am_ : gain;
+  }
   if (XMOD && (xf & XF_NOSMOOTH) && r.nosmooth) {
     s *= gain;                                           // voice_smoother_gain is left alone (synth.c:589-593)
   } else {
@@ -475,7 +479,8 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
   float ph;
   if (BIDIR) {
     const float ph0 = r.phase + inc;
-    ph = ph0 >= r.hi ? r.lo + ((ph0 - r.lo) - r.span) : (ph0 < r.lo ? r.hi - (r.lo - ph0) : ph0);
+    const float over_ = r.lo + ((ph0 - r.lo) - r.span), under_ = r.hi - (r.lo - ph0);   // (both formed: two selects, no branch per lane)
+    ph = ph0 >= r.hi ? over_ : (ph0 < r.lo ? under_ : ph0);
     r.phase = ph;
   } else {
     ph = fast_advance<TAME, STOPS && !NOSTOP>(r, inc);

@@ -388,9 +388,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
   {                                                                                                      \
     float l, rr;                                                                                         \
     /* (amplitude / pan sources: read when the frame needs them -- nobody writes the ring before the end of the step) */ \
-    float aq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.am_addr)];              \
-    float pq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.pm_addr)];              \
-    if (ap_) asm volatile("" : "+v"(aq_), "+v"(pq_));   /* (both reads here, for every lane: left alone, hipcc sinks them into per-lane branches around the two products that use them) */ \
+    const float aq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.am_addr)];        \
+    const float pq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.pm_addr)];        \
     fast_frame<TAB_LDS, FILTER, ENV, true, (MODE_) == 1, INTERP, STOPS, true, (MODE_) != 0, (MODE_) == 2>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, XF_, muted, 0.0f, mq_[Q], aq_, pq_); \
     own_[Q] = r.sample;                                                                                  \
     if (TILE_) {                                                                                         \

@@ -376,7 +376,8 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 // each of its readers, chains at most SK_SKEW_LMAX deep, geometry tame, no reverse / noise / stopping / smoother-off lanes.
 // Two forms: LEAN (only frequency modulation, one level: the pair-register chain of the plain blocks, no per-frame feature
 // tests) and RICH (amplitude / pan modulation, sample & hold, chains: fast_frame itself with the ring's samples handed in).
-// Same products and sums per voice as the exchange forms; a step whose vote fails takes the general frames.
+// Same products and sums per voice as the exchange forms; a step whose vote fails takes straight-line frames with both wraps when
+// its increments stay within half a loop length on either side (fast_frame<BIDIR>), the general frames otherwise.
 #define SK_SKEW_RING (9 * 64)    /* floats per wave: rows 0..7 the lanes' samples of their latest block, row 8 the last sample of the block
                                     before it (what frame 0 of a reader's block takes).  (A tenth row cost 3.sk's bank -- 32 KB of
                                     tables -- its third workgroup per CU: 0.38 -> 0.52 ms; the leads live in the pad floats of

@@ -414,15 +414,20 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
       _Pragma("unroll") for (int q_ = 1; q_ < 8; ++q_) mq_[q_] = col_[(q_ - 1) * 64];                    \
     }                                                                                                    \
     float inc_[8];                                                                                       \
-    uint32_t top_ = 0u, mag_ = 0u;                                                                       \
+    uint32_t top_ = 0u;                                                                                  \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                   \
       inc_[q_] = r.fm_addr >= 0 ? r.inc + r.fm_k * (mq_[q_] * r.fm_depth) : r.inc;      /* synth.c:551-554 */ \
       top_ = max(top_, __float_as_uint(inc_[q_]));                                                       \
-      mag_ = max(mag_, __float_as_uint(inc_[q_]) & 0x7fffffffu);                                         \
     }                                                                                                    \
     const bool tame_ = __all(top_ <= __float_as_uint(half_span));                                        \
-    /* ... or within half a loop length on either side (deep modulation: the increment goes negative): fast_frame<BIDIR> */ \
-    const bool bidir_ = !tame_ && __all(mag_ <= __float_as_uint(half_span));                             \
+    /* ... or within half a loop length on either side (deep modulation: the increment goes negative): fast_frame<BIDIR>; voted
+       only when the first vote failed */                                                                \
+    bool bidir_ = false;                                                                                 \
+    if (!tame_) {                                                                                        \
+      uint32_t mag_ = 0u;                                                                                \
+      _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) mag_ = max(mag_, __float_as_uint(inc_[q_]) & 0x7fffffffu); \
+      bidir_ = __all(mag_ <= __float_as_uint(half_span));                                                \
+    }                                                                                                    \
     (void)inc_; (void)bidir_;
 /* the general frames of a step (delay line in r.x1 ...); the lane's own eight samples go to the ring when every lane of the wave
    has read what it needs of this step */

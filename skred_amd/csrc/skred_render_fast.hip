@@ -613,6 +613,9 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
                                     banks anyway: one-shot bank 0.46 -> 0.40 ms, FM 1.31 -> 1.22 ms.  PCM banks keep 4: there the
                                     occupancy hides the window refills (0.347 -> 0.372 ms with 3) */
 #endif
+#ifndef SK_FAST_EXT_BARE_MIN_WAVES
+#define SK_FAST_EXT_BARE_MIN_WAVES 4   /* the extended LDS-table instantiation without biquad / envelope, truncating lookup (see the kernel) */
+#endif
 #ifndef SK_FAST_MIN_WAVES
 #define SK_FAST_MIN_WAVES 4      /* waves per SIMD the register allocator must leave room for (LDS-table banks: the table copy,
                                     wsum and the reduction tiles take 38..70 KB per workgroup, i.e. 2..4 workgroups per CU anyway) */
@@ -630,7 +633,7 @@ template <bool TAB_LDS, bool FILTER, bool ENV, int INTERP, bool STOPS, bool RAMP
 // (the extended LDS-table instantiation WITHOUT biquad and envelope, truncating lookup -- what every shipped patch but 18.sk runs on -- needs 129
 // registers, three of them holding spilled SGPRs: bounded to 128 it keeps four waves per SIMD where the pool leaves room for
 // four workgroups per CU -- 7.sk, 16 KB of tables: 1.29 -> 1.00 ms)
-__global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? ((FILTER || ENV || INTERP != 0) ? SK_FAST_EXT_MIN_WAVES : 4) : SK_FAST_MIN_WAVES) : (STOPS ? SK_FAST_WIN_EXT_MIN_WAVES : SK_FAST_WIN_MIN_WAVES)) void sk_render_fast_kernel(const sk_render_args_t a) {
+__global__ __launch_bounds__(SK_GROUP, TAB_LDS ? (STOPS ? ((FILTER || ENV || INTERP != 0) ? SK_FAST_EXT_MIN_WAVES : SK_FAST_EXT_BARE_MIN_WAVES) : SK_FAST_MIN_WAVES) : (STOPS ? SK_FAST_WIN_EXT_MIN_WAVES : SK_FAST_WIN_MIN_WAVES)) void sk_render_fast_kernel(const sk_render_args_t a) {
   extern __shared__ float lds[];
   float2 *wsum = reinterpret_cast<float2 *>(lds + (TAB_LDS ? a.lds_table_floats : 0));
   const char *lds_tab = reinterpret_cast<const char *>(lds);

@@ -275,3 +275,49 @@ def test_patch_bank_skewed_equals_exchange(dev, patch):
         assert rel_rms(mix, ref_mix) <= 1e-5
         res[skew] = mix
     assert gio.bits_equal(res[1], res[0])
+
+
+def _copies(bank, copy_ids, K):
+    """The K-voice copies `copy_ids` of a tiled patch bank as a bank of their own (modulator indices moved along): what the oracle
+    renders beside the device for the probed voices -- a copy never reads a voice outside itself."""
+    idx = (np.asarray(copy_ids)[:, None] * K + np.arange(K)[None, :]).reshape(-1)
+    sub = bank.take(idx)
+    shift = np.repeat((np.arange(len(copy_ids)) - np.asarray(copy_ids)) * K, K).astype(np.int32)
+    for f in ("voice_freq_mod_osc", "voice_amp_mod_osc", "voice_pan_mod_osc", "voice_cz_mod_osc"):
+        m = sub.a[f]
+        sub.a[f] = np.where(m >= 0, m + shift, m).astype(np.int32)
+    return sub, idx
+
+
+@pytest.mark.parametrize("patch,K", [("3sk", 4), ("1sk", 4), ("7sk", 4), ("37sk", 16)])
+def test_full_size_patch_bank_probed_inside_the_skewed_blocks(dev, patch, K):
+    """The timed workload itself (`shipped_patches`: 2^20 voices, 512-frame blocks) with 64 probed voices in 16 copies spread over
+    the whole bank: (L, R) of every frame, written from inside the skewed steps, bit for bit against the oracle rendering those
+    copies as a bank of their own."""
+    import torch
+    n, F = 1 << 20, 512
+    bank, tables, g = banks.bank_patch(patch, n)
+    assert bank.n % K == 0 and not np.any(np.asarray(bank["voice_freq_mod_osc"])[K:2 * K] >= 2 * K)
+    rng = np.random.default_rng(11)
+    copy_ids = np.unique(np.concatenate([[0, n // K - 1], rng.choice(n // K, 14, replace=False)]))
+    sub, idx = _copies(bank, copy_ids, K)
+    used = np.where(np.asarray(sub["voice_amp"]) != 0)[0][:64]
+    ids = idx[used].astype(np.int32)
+    db = dev.DeviceBank(n)
+    db.set_tables(tables)
+    db.upload(bank)
+    db.set_globals(g)
+    buf = torch.zeros(F * len(ids) * 2, device="cuda")
+    db.set_probe(ids, buf.data_ptr())
+    sub_g = g.copy()
+    out = torch.zeros(F, 2, device="cuda")
+    for k in range(3):
+        buf.zero_()
+        db.render_mix(F, out.data_ptr(), 2, 0, 0)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy().reshape(F, len(ids), 2)
+        want = cpuref.render(sub, sub_g, tables, F, 0, want_stems=True)["stems"][:, used, :]
+        d = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+        assert len(d) == 0, f"{patch} block {k}: {len(d)} probed values differ; first (frame, probe, ch) {d[0]}, voice {ids[d[0][1]]}: {got[tuple(d[0])]} vs {want[tuple(d[0])]}"
+    db.set_probe([], 0)
+    db.close()

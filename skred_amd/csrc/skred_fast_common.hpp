@@ -454,8 +454,9 @@ __device__ __forceinline__ bool fast_smoother_stalled(const FastRegs &r) {
 // the loop on either side and both wraps are straight-line: beyond the end lo + ((ph0 - lo) - span) as in TAME; before the start
 // the reference's loop_end - fmodf(loop_start - phase, loop_length) (synth.c:253) with an argument below one loop length, where
 // fmodf returns it unchanged: hi - (lo - ph0).  (That difference can round to hi itself: the fetch keeps its index clamp.)
+// LOZ (with TAME and NOSTOP): no lane of the wave has a loop window -- fast_advance<LOZ>'s two-instruction wrap.
 template <bool TAB_LDS, bool FILTER, bool ENV, bool STEADY, bool TAME, int INTERP, bool STOPS = false, bool EXTMS = false, bool NOSTOP = false,
-          bool BIDIR = false>
+          bool BIDIR = false, bool LOZ = false>
 __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, float &yn, float &yo,
                                            const bool released, const char *lds_tab,
                                            const char *__restrict__ glb_tab, float &out_l, float &out_r,
@@ -483,7 +484,7 @@ __device__ __forceinline__ void fast_frame(FastRegs &r, float &xn, float &xo, fl
     ph = ph0 >= r.hi ? over_ : (ph0 < r.lo ? under_ : ph0);
     r.phase = ph;
   } else {
-    ph = fast_advance<TAME, STOPS && !NOSTOP>(r, inc);
+    ph = fast_advance<TAME, STOPS && !NOSTOP, LOZ && TAME && (!STOPS || NOSTOP)>(r, inc);
   }
   float s = fast_fetch<TAB_LDS, INTERP, TAME && !BIDIR && (!STOPS || NOSTOP)>(lds_tab, glb_tab, r, ph);   // a finishing phase needs the index clamp
   if (STOPS && (xf & XF_NOISE) && r.noise) s = white;   // synth.c:543-546 (the lane's oscillator idles on inert numbers)

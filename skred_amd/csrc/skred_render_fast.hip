@@ -385,13 +385,13 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
 #define SK_SKEW_LEAD() (reinterpret_cast<unsigned char *>(xt + (lane >> 4) * SK_XT + 64 + ((lane >> 2) & 3))[lane & 3])
 #define SK_SKEW_COL(ADDR_) ((ADDR_) >= 0 ? ((ADDR_) >> 2) : lane)   /* the ring column a lane reads: its source's, or (unused) its own */
 #define SK_SKEW_LMAX 3
-#define SK_FAST_SKEW_RFRAME(Q, MODE_, XN, XO, YN, YO, TILE_, XF_, DL_)     /* MODE_ 0: general frame, 1: tame, 2: bidirectional */ \
+#define SK_FAST_SKEW_RFRAME(Q, MODE_, XN, XO, YN, YO, TILE_, XF_, DL_)     /* MODE_ 0: general frame, 1: tame, 2: bidirectional, 3: tame and no loop windows (LOZ) */ \
   {                                                                                                      \
     float l, rr;                                                                                         \
     /* (amplitude / pan sources: read when the frame needs them -- nobody writes the ring before the end of the step) */ \
     const float aq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.am_addr)];        \
     const float pq_ = !ap_ ? 0.0f : ring[((Q) == 0 ? 8 : (Q) - 1) * 64 + SK_SKEW_COL(r.pm_addr)];        \
-    fast_frame<TAB_LDS, FILTER, ENV, true, (MODE_) == 1, INTERP, STOPS, true, (MODE_) != 0, (MODE_) == 2>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, XF_, muted, 0.0f, mq_[Q], aq_, pq_); \
+    fast_frame<TAB_LDS, FILTER, ENV, true, ((MODE_) & 1) != 0, INTERP, STOPS, true, (MODE_) != 0, (MODE_) == 2, (MODE_) == 3>(r, XN, XO, YN, YO, released, lds_tab, glb_tab, l, rr, XF_, muted, 0.0f, mq_[Q], aq_, pq_); \
     own_[Q] = r.sample;                                                                                  \
     if (TILE_) {                                                                                         \
       if ((DL_) && skew_delay) {     /* an audible source: what it rendered a step ago belongs to THIS frame (same product as fast_post's) */ \
@@ -454,7 +454,7 @@ __device__ __forceinline__ void fast_finish(const sk_render_args_t &a, FastRegs 
     if (tame_ && (TILE_)) {           /* (the lead-in steps run once per pass: the general frames only) */ \
       /* the shipped shape -- frequency plus amplitude / pan modulation, nothing else -- with the feature mask a literal: the
          frames carry no wave-uniform tests (one scheduling region per frame pair) */                    \
-      if (xf == (XF_FM | XF_AP) && !skew_delay) SK_FAST_SKEW_FRAMES(1, TILE_, (XF_FM | XF_AP), false)    \
+      if (xf == (XF_FM | XF_AP) && !skew_delay) { if (loz) SK_FAST_SKEW_FRAMES(3, TILE_, (XF_FM | XF_AP), false) else SK_FAST_SKEW_FRAMES(1, TILE_, (XF_FM | XF_AP), false) } \
       else SK_FAST_SKEW_FRAMES(1, TILE_, xf, true)                                                       \
     } else if (bidir_ && (TILE_)) {                                                                      \
       if (xf == (XF_FM | XF_AP) && !skew_delay) SK_FAST_SKEW_FRAMES(2, TILE_, (XF_FM | XF_AP), false)    \

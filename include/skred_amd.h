@@ -341,7 +341,10 @@ enum { SKRED_OPT_FORCE_GENERIC = 1, SKRED_OPT_FAST2_MIN_VOICES = 2 /* bank size 
                              its samples over through an LDS ring, so the readers' blocks have no per-frame exchange -- wavefronts
                              whose sources are silent (`m1`) or heard with their pan at rest, each exactly one block ahead of every
                              lane that reads it, and without reverse / noise / stopping / smoother-off lanes; other wavefronts keep
-                             the exchange.  0: the per-frame ds_bpermute exchange everywhere.  Same bits either way */ };
+                             the exchange.  0: the per-frame ds_bpermute exchange everywhere.  The same option
+                             governs the modulated kernel's FRAME-LAG form (a modulator BELOW its carrier -- a same-frame dependency,
+                             18.sk -- with one dependency level: the dependent lanes run one frame behind instead of every frame being
+                             rendered once per level).  Same bits either way */ };
 enum { SKRED_KERNEL_GENERIC = 0, SKRED_KERNEL_FAST = 1, SKRED_KERNEL_MODULATED = 2, SKRED_KERNEL_FAST2 = 3 };
 int  skred_bank_set_option(skred_bank_t *bank, int option, int value);
 int  skred_bank_last_kernel(const skred_bank_t *bank);   /* SKRED_KERNEL_* of the latest render */

@@ -582,6 +582,7 @@ static int render_block(skred_bank_t *b, int num_frames, int interp, float *d_st
    * two-per-lane kernel would take, for a quarter of them. */
   a.pack_shift = 6;
   a.fm_skew = b->fm_skew && (a.fast_mode & SKM_FM) && a.lds_table_floats > 0 && !d_stems;   /* (the launcher drops it when the ring does not fit) */
+  if (modulated) a.fm_skew = b->fm_skew && !d_stems;        /* (the modulated kernel: its frame-lag form, same option) */
   int pack_s = 0;
   if (b->pack_mode && (modulated || ((a.fast_mode & SKM_FAST) && !(a.fast_mode & SKM_FM_PAIR))) && !d_stems) {   /* (the modulated kernel packs the same way) */
     const int most = pack_refresh(b);

@@ -166,8 +166,10 @@ template <bool TAB_LDS>
 __device__ __forceinline__ void voice_frame_mod(VoiceRegs &r, const ModRegs &m, int lane,
                                                 const float *prev, float *cur, const float *incs,
                                                 const float *lds_tab, const float *__restrict__ tab, uint64_t now,
-                                                float white, int interp, float &out_l, float &out_r) {
-  auto other = [&](int src) -> float { return src < lane ? cur[src] : prev[src]; };
+                                                float white, int interp, float &out_l, float &out_r, const bool lag = false) {
+  // (lag: the frame-lag form of sk_render_mod_kernel -- every modulator's sample this lane needs is the one the PREVIOUS
+  // iteration left, whichever side of the lane it sits on)
+  auto other = [&](int src) -> float { return (src < lane && !lag) ? cur[src] : prev[src]; };
   out_l = 0.0f; out_r = 0.0f;
   float raw;
   if (r.flags & SKF_NOISE) {
@@ -335,8 +337,65 @@ __global__ __launch_bounds__(SK_GROUP) void sk_render_mod_kernel(const sk_render
 
     uint64_t rng = a.rng0;
     int cur_i = 1;
+    // FRAME-LAG form (round 4; 18.sk's shape: `v10 ... F0,70`, a modulator BELOW its carrier -- synth.c:548-555 in index order makes
+    // that a same-frame dependency).  The level loop below renders every frame once per dependency level, each pass under the
+    // EXEC mask of its level.  When the wave has exactly one level of same-frame dependencies and every edge fits -- a source
+    // below its reader one level lower, a source above it on the reader's own level -- the level-1 lanes simply run ONE FRAME
+    // BEHIND the level-0 lanes: in iteration i a level-0 lane renders frame i, a level-1 lane frame i - 1, and every sample a
+    // lane needs from another is the one the previous iteration left in the exchange array.  One pass per frame for all lanes;
+    // the level-0 lanes' (L, R) are held one iteration so that a frame's sum still takes all lanes' values of THAT frame; one
+    // iteration more per launch (the first without the level-1 lanes, the last without the level-0 lanes).  Same arithmetic per
+    // voice, same sums.  Waves that do not fit (deeper chains, stems) keep the level loop.
+    bool lag = false;
+    if (!STEMS && a.fm_skew && max_level >= 1 && a.num_frames >= 2) {
+      xch0[64 + lane] = (float)m.level;                        // (the second exchange array is first written in iteration 0)
+      SK_MOD_WAVE_SYNC()
+      auto fits = [&](int s_) -> bool { return s_ < 0 || s_ == lane || (int)xch0[64 + (s_ & 63)] == (s_ < lane ? m.level - 1 : m.level); };
+      const bool ok = m.level <= 1 && fits(m.fm) && fits(m.am) && fits(m.pm) && fits(m.cz);
+      lag = __all(ok) && __any(m.level == 1);
+      SK_MOD_WAVE_SYNC()
+    }
+    float hl = 0.0f, hr = 0.0f, white_prev = 0.0f;            // (lag) the level-0 lanes' (L, R) and the noise draw of the frame before
+    if (lag) {                                                 // iteration 0: the level-0 lanes render frame 0
+      rng = rng * LCG_A + LCG_C;
+      const float white = (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f;
+      float *cur = xch0 + cur_i * 64;
+      const float *prev = xch0 + (cur_i ^ 1) * 64;
+      const bool live = !((r.rw & SKR_FINISHED) || r.amp == 0.0f || (r.flags & SKF_INERT));
+      if (!live) r.sample = 0.0f;
+      SK_MOD_WAVE_SYNC()
+      float l = 0.0f, rr = 0.0f;
+      if (live && m.level == 0) voice_frame_mod<TAB_LDS>(r, m, lane, prev, cur, incs, lds_tab, a.tables, a.count0 + 1, white, a.interp, l, rr, true);
+      cur[lane] = r.sample;                                    // (a lane that sat out carries its sample along)
+      SK_MOD_WAVE_SYNC()
+      hl = l; hr = rr; white_prev = white;
+      cur_i ^= 1;
+    }
     for (int c0 = 0; c0 < a.num_frames; c0 += SK_CHUNK) {
       const int cn = min(SK_CHUNK, a.num_frames - c0);
+      if (lag) {
+        for (int j = 0; j < cn; ++j) {
+          const int i = c0 + j + 1;                            // level-0 lanes: frame i (while there is one); level-1 lanes: frame i - 1
+          const bool more = i < a.num_frames;
+          float white = 0.0f;
+          if (more) { rng = rng * LCG_A + LCG_C; white = (float)((int32_t)(uint32_t)(rng >> 32)) / 2147483648.0f; }
+          float *cur = xch0 + cur_i * 64;
+          const float *prev = xch0 + (cur_i ^ 1) * 64;
+          const bool live = !((r.rw & SKR_FINISHED) || r.amp == 0.0f || (r.flags & SKF_INERT));
+          if (!live) r.sample = 0.0f;
+          SK_MOD_WAVE_SYNC()
+          float l = 0.0f, rr = 0.0f;
+          if (live && (m.level == 1 || more))
+            voice_frame_mod<TAB_LDS>(r, m, lane, prev, cur, incs, lds_tab, a.tables, a.count0 + (uint64_t)(i - m.level) + 1,
+                                     m.level == 0 ? white : white_prev, a.interp, l, rr, true);
+          cur[lane] = r.sample;
+          SK_MOD_WAVE_SYNC()
+          if (m.level == 0) { const float tl = l, tr = rr; l = hl; rr = hr; hl = tl; hr = tr; }   // frame c0 + j: what was held
+          SK_REDUCE_AND_STORE(j)
+          white_prev = white;
+          cur_i ^= 1;
+        }
+      } else
       for (int j = 0; j < cn; ++j) {
         const int i = c0 + j;
         const uint64_t now = a.count0 + (uint64_t)i + 1;

@@ -321,3 +321,59 @@ def test_full_size_patch_bank_probed_inside_the_skewed_blocks(dev, patch, K):
         assert len(d) == 0, f"{patch} block {k}: {len(d)} probed values differ; first (frame, probe, ch) {d[0]}, voice {ids[d[0][1]]}: {got[tuple(d[0])]} vs {want[tuple(d[0])]}"
     db.set_probe([], 0)
     db.close()
+
+
+def below_bank(recipe, n):
+    """Modulators BELOW their carriers (same-frame dependencies: the modulated kernel), in copies of eight voices.
+    Copies 0 mod 4, 18.sk's shape: v0 F1 (previous frame, from above), v1, v2 plain, v6 F0 (SAME frame, from below) -- one level:
+    the frame-lag form.  Copies 1 mod 4: v5 A2 P1 (amplitude and pan from below), v7 is a noise voice modulated in frequency... no:
+    noise ignores it; v7 A3 (a level-1 noise voice: it takes the draw of ITS frame).  Copies 2 mod 4: a two-level chain v1 F0, v2 F1
+    (that wavefront keeps the level loop).  Copies 3 mod 4: v4 F2 from below, and v2 F4 from above -- a previous-frame edge ACROSS
+    levels: not lag-able either."""
+    bank, tables, g = banks.RECIPES[recipe](n)
+    v = np.arange(n)
+    base = v[v % 8 == 0]
+    kind = (base // 8) % 4
+    bank["voice_freq_scale"][v] = (np.float32(0.5) + np.float32(0.01) * (v % 40)).astype(np.float32)
+    def fm(dst, src, depth):
+        bank["voice_freq_mod_osc"][dst] = src
+        bank["voice_freq_mod_depth"][dst] = np.float32(depth)
+    b0 = base[kind == 0]
+    fm(b0, b0 + 1, 0.1); fm(b0 + 6, b0, 0.4)
+    bank["voice_disconnect"][b0 + 1] = 1
+    b1 = base[kind == 1]
+    bank["voice_amp_mod_osc"][b1 + 5] = b1 + 2; bank["voice_amp_mod_depth"][b1 + 5] = np.float32(1.5)
+    bank["voice_pan_mod_osc"][b1 + 5] = b1 + 1; bank["voice_pan_mod_depth"][b1 + 5] = np.float32(0.8)
+    bank["voice_wave_table_index"][b1 + 7] = 6                       # WAVE_TABLE_NOISE_ALT (synth.c:543)
+    bank["voice_amp_mod_osc"][b1 + 7] = b1 + 3; bank["voice_amp_mod_depth"][b1 + 7] = np.float32(0.9)
+    b2 = base[kind == 2]
+    fm(b2 + 1, b2, 0.3); fm(b2 + 2, b2 + 1, 0.3)
+    b3 = base[kind == 3]
+    fm(b3 + 4, b3 + 2, 0.2); fm(b3 + 2, b3 + 4, 0.2)
+    return bank, tables, g
+
+
+@pytest.mark.parametrize("recipe,interp", [("c2", 0), ("c1", 1)])
+def test_frame_lag_form_of_the_modulated_kernel(dev, recipe, interp):
+    """sk_render_mod_kernel with one level of same-frame dependencies: the dependent lanes one frame behind (SKRED_OPT_FM_SKEW 1)
+    against the level loop (0) and the oracle -- state bit for bit after every launch, mix to the last bit between the two forms;
+    launches of 1, 2, 65 and 300 frames, envelopes in motion, a release, a source switched off, a level-1 noise voice."""
+    n = 2048
+    bank, tables, g = below_bank(recipe, n)
+    bank["voice_amp"][0] = 0.0                          # a level-0 source that is off: its level-1 reader takes exact zeros
+    bank["voice_amp"][38] = 0.0
+
+    def kill(host, now):
+        host["voice_amp"][64::96] = 0.0
+
+    segs = [(1, None), (2, None), (65, None), (300, _release_some), (130, kill), (64, None)]
+    ref_mix, ref_state, _ = oracle(bank, tables, g, interp, segs)
+    res = {}
+    for lag in (1, 0):
+        mix, state, _, kernels = run(dev, bank, tables, g, interp, segs, lag)
+        assert kernels == [2] * len(segs), kernels
+        bad = state.rw_equal(ref_state)
+        assert not bad, (lag, bad)
+        assert rel_rms(mix, ref_mix) <= 1e-5
+        res[lag] = mix
+    assert gio.bits_equal(res[1], res[0])
